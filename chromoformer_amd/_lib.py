@@ -1,0 +1,134 @@
+"""ctypes binding of libchromoformer_hip.so (include/chromoformer_hip.h).
+
+The library is the product; this file is plumbing.  There is no fallback: if the shared
+object is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchromoformer_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+MAX_RES = 3
+
+
+class cf_config(C.Structure):
+    _fields_ = [
+        ("n_feats", C.c_int), ("d_emb", C.c_int), ("d_head", C.c_int), ("n_out", C.c_int), ("n_res", C.c_int),
+        ("binsizes", C.c_int * MAX_RES), ("n_bins", C.c_int * MAX_RES), ("i_max", C.c_int),
+        ("embed_layers", C.c_int), ("embed_heads", C.c_int), ("embed_dmodel", C.c_int), ("embed_dff", C.c_int),
+        ("pair_layers", C.c_int), ("pair_heads", C.c_int), ("pair_dmodel", C.c_int), ("pair_dff", C.c_int),
+        ("reg_layers", C.c_int), ("reg_heads", C.c_int), ("reg_dmodel", C.c_int), ("reg_dff", C.c_int),
+        ("max_batch", C.c_int),
+    ]
+
+
+class cf_param_desc(C.Structure):
+    _fields_ = [("name", C.c_char * 120), ("ndim", C.c_int), ("shape", C.c_int * 2), ("offset", C.c_longlong),
+                ("numel", C.c_longlong), ("trainable", C.c_int)]
+
+
+class cf_layout(C.Structure):
+    _fields_ = [("n_tensors", C.c_int), ("n_total", C.c_longlong), ("n_active", C.c_longlong), ("n_elems", C.c_longlong)]
+
+
+class cf_batch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int),
+        ("promoter_feats", C.c_void_p * MAX_RES), ("pcre_feats", C.c_void_p * MAX_RES),
+        ("promoter_mask_row", C.c_void_p * MAX_RES), ("promoter_mask_stride", C.c_longlong * MAX_RES),
+        ("pcre_mask_row", C.c_void_p * MAX_RES), ("pcre_mask_stride", C.c_longlong * MAX_RES),
+        ("interaction_mask", C.c_void_p * MAX_RES), ("interaction_freq", C.c_void_p),
+    ]
+
+
+#: every symbol include/chromoformer_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "cf_abi_version": (C.c_int, []),
+    "cf_last_error": (C.c_char_p, []),
+    "cf_param_layout": (C.c_int, [C.POINTER(cf_config), C.POINTER(cf_layout), C.POINTER(cf_param_desc), C.c_int]),
+    "cf_create": (C.c_int, [C.POINTER(cf_config), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "cf_destroy": (None, [C.c_void_p]),
+    "cf_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cf_forward": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_backward": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "cf_backward_from": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
+    "cf_adamw_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p]),
+    "cf_debug_copy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
+    "cf_debug_names": (C.c_char_p, [C.c_void_p]),
+    "cf_launch_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "cf_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cf_op_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cf_op_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/ for gfx950 into libchromoformer_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("cf_api.hip", "cf_kernels.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "chromoformer_hip.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed",
+           os.path.join(CSRC, "cf_api.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libchromoformer_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no CPU / PyTorch fallback for the Chromoformer hot path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.cf_abi_version() != 1:
+            raise RuntimeError("libchromoformer_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libchromoformer_hip: %s failed: %s" % (what, lib().cf_last_error().decode()))
+
+
+def make_config(n_feats, d_emb, d_head, n_out, binsizes, n_bins, i_max, embed, pair, reg, max_batch):
+    c = cf_config()
+    c.n_feats, c.d_emb, c.d_head, c.n_out, c.n_res = n_feats, d_emb, d_head, n_out, len(binsizes)
+    if len(binsizes) > MAX_RES:
+        raise ValueError("at most %d resolutions" % MAX_RES)
+    for i, (b, n) in enumerate(zip(binsizes, n_bins)):
+        c.binsizes[i], c.n_bins[i] = int(b), int(n)
+    c.i_max = i_max
+    c.embed_layers, c.embed_heads, c.embed_dmodel, c.embed_dff = (embed[k] for k in ("n_layers", "n_heads", "d_model", "d_ff"))
+    c.pair_layers, c.pair_heads, c.pair_dmodel, c.pair_dff = (pair[k] for k in ("n_layers", "n_heads", "d_model", "d_ff"))
+    c.reg_layers, c.reg_heads, c.reg_dmodel, c.reg_dff = (reg[k] for k in ("n_layers", "n_heads", "d_model", "d_ff"))
+    c.max_batch = max_batch
+    return c
+
+
+def param_layout(cfg):
+    """-> (cf_layout, [dict(name, shape, offset, numel, trainable)]) in state_dict order.  Host only."""
+    L = lib()
+    lay = cf_layout()
+    check(L.cf_param_layout(C.byref(cfg), C.byref(lay), None, 0), "cf_param_layout")
+    tab = (cf_param_desc * lay.n_tensors)()
+    check(L.cf_param_layout(C.byref(cfg), C.byref(lay), tab, lay.n_tensors), "cf_param_layout")
+    out = []
+    for d in tab:
+        out.append(dict(name=d.name.decode(), shape=tuple(d.shape[:d.ndim]), offset=int(d.offset), numel=int(d.numel),
+                        trainable=bool(d.trainable)))
+    return lay, out

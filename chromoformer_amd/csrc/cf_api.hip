@@ -1,0 +1,1197 @@
+// cf_api.hip -- host side of libchromoformer_hip.so: parameter layout, workspace,
+// launch sequences for forward / backward / AdamW, and the C ABI of
+// include/chromoformer_hip.h.  No torch, no allocation on the hot path.
+#include "../../include/chromoformer_hip.h"
+#include "cf_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace cf;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LAUNCH_CHECK(name)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) return fail("launch %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// parameter layout (host only)
+// ------------------------------------------------------------------------------------
+struct PDesc {
+    std::string name;
+    int ndim;
+    int shape[2];
+    long long numel, offset;
+    bool trainable;
+};
+
+static std::string fmt(const char* f, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+static void add(std::vector<PDesc>& v, const std::string& name, int d0, int d1, bool trainable) {
+    PDesc p;
+    p.name = name;
+    p.ndim = d1 > 0 ? 2 : 1;
+    p.shape[0] = d0;
+    p.shape[1] = d1 > 0 ? d1 : 0;
+    p.numel = (long long)d0 * (d1 > 0 ? d1 : 1);
+    p.offset = -1;
+    p.trainable = trainable;
+    v.push_back(p);
+}
+// the seven tensors of an attention block, four/three-chunk self attention (modules.py:16-25)
+static void add_self_att(std::vector<PDesc>& v, const std::string& pre, int d_emb, int heads, int dm, bool gate, bool gamma_trains) {
+    add(v, pre + "gamma_f", heads, 0, gamma_trains);
+    add(v, pre + "w_bias.weight", heads, 2, false);
+    add(v, pre + "att.weight", (gate ? 4 : 3) * dm, d_emb, true);
+    add(v, pre + "ff.weight", d_emb, dm, true);
+    add(v, pre + "ff.bias", d_emb, 0, true);
+    add(v, pre + "ln.weight", d_emb, 0, true);
+    add(v, pre + "ln.bias", d_emb, 0, true);
+}
+static void add_ffn(std::vector<PDesc>& v, const std::string& pre, int d_emb, int dff) {
+    add(v, pre + "l1.weight", dff, d_emb, true);
+    add(v, pre + "l1.bias", dff, 0, true);
+    add(v, pre + "l2.weight", d_emb, dff, true);
+    add(v, pre + "l2.bias", d_emb, 0, true);
+    add(v, pre + "ln.weight", d_emb, 0, true);
+    add(v, pre + "ln.bias", d_emb, 0, true);
+}
+
+static int check_config(const cf_config& c) {
+    if (c.d_emb != kD) return fail("d_emb must be 128 (got %d)", c.d_emb);
+    if (c.d_head != kD) return fail("d_head must be 128 (got %d)", c.d_head);
+    if (c.n_feats < 1 || c.n_feats > 8) return fail("n_feats must be in 1..8 (got %d)", c.n_feats);
+    if (c.n_out != 1 && c.n_out != 2) return fail("n_out must be 1 or 2");
+    if (c.n_res != 3) return fail("exactly 3 resolutions are supported (fc_head is Linear(3*d_emb, .), net.py:327)");
+    if (c.i_max < 1 || c.i_max > 16) return fail("i_max must be in 1..16");
+    if (c.embed_layers != 1) return fail("centre-row evaluation needs embed.n_layers == 1 (got %d)", c.embed_layers);
+    if (c.embed_heads != 2 || c.embed_dmodel != 128) return fail("embed: n_heads=2, d_model=128 required");
+    if (c.pair_heads != 2 || c.pair_dmodel != 128) return fail("pairwise_interaction: n_heads=2, d_model=128 required");
+    if (c.pair_layers < 1 || c.pair_layers > 2) return fail("pairwise_interaction.n_layers must be 1 or 2");
+    if (c.reg_heads != 8 || c.reg_dmodel != 256) return fail("regulation: n_heads=8, d_model=256 required");
+    if (c.reg_layers < 1 || c.reg_layers > 32) return fail("regulation.n_layers must be in 1..32");
+    const int dffs[3] = {c.embed_dff, c.pair_dff, c.reg_dff};
+    for (int d : dffs)
+        if (d != 128 && d != 256) return fail("d_ff must be 128 or 256 (got %d)", d);
+    for (int r = 0; r < c.n_res; ++r)
+        if (c.n_bins[r] < 1 || c.n_bins[r] > 1024) return fail("n_bins[%d] must be in 1..1024", r);
+    if (c.max_batch < 1 || c.max_batch > 4096) return fail("max_batch must be in 1..4096");
+    return 0;
+}
+
+static int build_layout(const cf_config& c, std::vector<PDesc>& v, cf_layout& lay) {
+    if (check_config(c)) return -1;
+    v.clear();
+    const int D = c.d_emb;
+    for (int r = 0; r < c.n_res; ++r) {
+        const std::string pre = fmt("embed.%d.", c.binsizes[r]);
+        add(v, pre + "lin_proj.weight", D, c.n_feats, true);
+        for (int l = 0; l < c.embed_layers; ++l) {
+            const std::string lp = pre + fmt("transformer.layers.%d.", l);
+            add_self_att(v, lp + "self_att.", D, c.embed_heads, c.embed_dmodel, false, false);
+            add_ffn(v, lp + "ff.", D, c.embed_dff);
+        }
+    }
+    for (int r = 0; r < c.n_res; ++r) {
+        const std::string pre = fmt("pairwise_interaction.%d.", c.binsizes[r]);
+        add(v, pre + "ln.weight", c.pair_dmodel, 0, false);
+        add(v, pre + "ln.bias", c.pair_dmodel, 0, false);
+        add(v, pre + "lin_proj_p.weight", c.pair_dmodel, D, true);
+        add(v, pre + "lin_proj_pcre.weight", c.pair_dmodel, c.n_feats, true);
+        for (int l = 0; l < c.pair_layers; ++l) {
+            const std::string lp = pre + fmt("transformer.layers.%d.", l);
+            add(v, lp + "self_att.gamma_f", c.pair_heads, 0, false);
+            add(v, lp + "self_att.p_att.weight", c.pair_dmodel, c.pair_dmodel, true);
+            add(v, lp + "self_att.c_att.weight", 2 * c.pair_dmodel, c.pair_dmodel, true);
+            add(v, lp + "self_att.ff.weight", c.pair_dmodel, c.pair_dmodel, true);
+            add(v, lp + "self_att.ff.bias", c.pair_dmodel, 0, true);
+            add(v, lp + "self_att.ln.weight", c.pair_dmodel, 0, true);
+            add(v, lp + "self_att.ln.bias", c.pair_dmodel, 0, true);
+            add_ffn(v, lp + "ff.", c.pair_dmodel, c.pair_dff);
+        }
+    }
+    for (int r = 0; r < c.n_res; ++r) {
+        const std::string pre = fmt("regulation.%d.", c.binsizes[r]);
+        for (int l = 0; l < c.reg_layers; ++l) {
+            const std::string lp = pre + fmt("transformer.layers.%d.", l);
+            add_self_att(v, lp + "self_att.", D, c.reg_heads, c.reg_dmodel, true, true);
+            add_ffn(v, lp + "ff.", D, c.reg_dff);
+        }
+    }
+    add(v, "fc_head.0.weight", c.d_head, 3 * D, true);
+    add(v, "fc_head.0.bias", c.d_head, 0, true);
+    add(v, "fc_head.2.weight", c.n_out, c.d_head, true);
+    add(v, "fc_head.2.bias", c.n_out, 0, true);
+
+    long long off = 0, elems = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (auto& p : v) {
+            if (p.trainable != (pass == 0)) continue;
+            p.offset = off;
+            off += (p.numel + 3) / 4 * 4;     // 16-byte aligned tensors
+            elems += p.numel;
+        }
+        if (pass == 0) lay.n_active = off;
+    }
+    lay.n_tensors = (int)v.size();
+    lay.n_total = off;
+    lay.n_elems = elems;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------
+struct CentreBuf {   // one centre-row attention layer of one resolution
+    float *q, *qt, *p, *w, *xbar, *a, *xh1, *rs1, *y1, *hdn, *xh2, *rs2, *out, *xin;
+    float *dt2, *dpre1, *dt1, *da, *dxbar, *dqt, *du, *dq, *dx, *partial;
+};
+struct RegBuf {
+    float *qkvg, *p, *a, *xh1, *rs1, *y1, *hdn, *xh2, *rs2;
+    float *dt2, *dpre1, *dt1, *da, *dqkvg, *partial, *dgam;
+};
+struct WsEntry {
+    std::string name;
+    size_t n, off;
+};
+
+struct cf_handle {
+    cf_config cfg;
+    std::vector<PDesc> table;
+    std::map<std::string, int> index;
+    cf_layout lay;
+    float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+    // workspace
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    std::vector<WsEntry> ws;
+    std::map<std::string, int> ws_index;
+    std::string ws_names;
+    bool planning = true;
+    // stage buffers
+    float *pe[kMaxRes], *pet[kMaxRes];
+    float *featc[kMaxRes], *ex0[kMaxRes], *edx0[kMaxRes], *edout[kMaxRes];
+    CentreBuf E[kMaxRes];
+    float *xp0[kMaxRes], *dxp0[kMaxRes], *resid[kMaxRes];
+    std::vector<CentreBuf> P[kMaxRes];
+    std::vector<float*> Rx[kMaxRes], dRx[kMaxRes];
+    std::vector<RegBuf> R[kMaxRes];
+    float *hin, *h1, *logits, *dlogits, *dh1, *dhin, *loss;
+    // deferred-gradient tile tables
+    WgTile* wg_tiles = nullptr;
+    int n_wg = 0;
+    CsTile* cs_tiles = nullptr;
+    int n_cs = 0;
+    int last_fwd_B = 0;
+    int n_fwd = 0, n_bwd = 0, n_opt = 0;
+
+    float* ws_get(const std::string& name, size_t n) {
+        n = (n + 3) / 4 * 4;
+        if (planning) {
+            ws_index[name] = (int)ws.size();
+            ws.push_back(WsEntry{name, n, arena_floats});
+            arena_floats += n;
+            return nullptr;
+        }
+        const WsEntry& e = ws[ws_index.at(name)];
+        return arena + e.off;
+    }
+    const float* P_(const std::string& name, long long extra = 0) const { return params + table[index.at(name)].offset + extra; }
+    float* G_(const std::string& name, long long extra = 0) const { return grads + table[index.at(name)].offset + extra; }
+};
+
+static void plan_centre(cf_handle* h, CentreBuf& b, const std::string& pre, size_t N, int L, int dff, bool own_out, bool own_xin) {
+    const size_t tiles = (N + kTile - 1) / kTile;
+    b.q = h->ws_get(pre + "q", N * kD);
+    b.qt = h->ws_get(pre + "qt", N * 256);
+    b.p = h->ws_get(pre + "p", N * 2 * L);
+    b.w = h->ws_get(pre + "w", N * 16);
+    b.xbar = h->ws_get(pre + "xbar", N * 256);
+    b.a = h->ws_get(pre + "a", N * kD);
+    b.xh1 = h->ws_get(pre + "xh1", N * kD);
+    b.rs1 = h->ws_get(pre + "rs1", N);
+    b.y1 = h->ws_get(pre + "y1", N * kD);
+    b.hdn = h->ws_get(pre + "hdn", N * dff);
+    b.xh2 = h->ws_get(pre + "xh2", N * kD);
+    b.rs2 = h->ws_get(pre + "rs2", N);
+    b.out = own_out ? h->ws_get(pre + "out", N * kD) : nullptr;
+    b.xin = own_xin ? h->ws_get(pre + "xin", N * kD) : nullptr;
+    const std::string d = "d" + pre;
+    b.dt2 = h->ws_get(d + "t2", N * kD);
+    b.dpre1 = h->ws_get(d + "pre1", N * dff);
+    b.dt1 = h->ws_get(d + "t1", N * kD);
+    b.da = h->ws_get(d + "a", N * kD);
+    b.dxbar = h->ws_get(d + "xbar", N * 256);
+    b.dqt = h->ws_get(d + "qt", N * 256);
+    b.du = h->ws_get(d + "u", N * 16);
+    b.dq = h->ws_get(d + "q", N * kD);
+    b.dx = h->ws_get(d + "x", N * kD);
+    b.partial = h->ws_get(d + "partial", tiles * post_partial_width(dff));
+}
+
+// executed twice: once to size the arena, once to hand out pointers
+static void plan_workspace(cf_handle* h) {
+    const cf_config& c = h->cfg;
+    const size_t MB = c.max_batch, S = c.i_max, T = S + 1;
+    const size_t NE = MB, NP = MB * S, NR = MB * T;
+    for (int r = 0; r < c.n_res; ++r) {
+        const int L = c.n_bins[r];
+        h->pe[r] = h->ws_get(fmt("pe%d", r), (size_t)L * kD);
+        h->pet[r] = h->ws_get(fmt("pet%d", r), (size_t)L * kD);
+        h->featc[r] = h->ws_get(fmt("E%d.featc", r), NE * 8);
+        h->ex0[r] = h->ws_get(fmt("E%d.x0", r), NE * kD);
+        plan_centre(h, h->E[r], fmt("E%d.", r), NE, L, c.embed_dff, false, false);
+        h->edout[r] = h->ws_get(fmt("dE%d.out", r), NE * kD);
+        h->xp0[r] = h->ws_get(fmt("P%d.xp0", r), NE * kD);
+        h->dxp0[r] = h->ws_get(fmt("dP%d.xp0", r), NE * kD);
+        h->resid[r] = h->ws_get(fmt("dE%d.resid", r), NE * kD);
+        h->P[r].resize(c.pair_layers);
+        for (int l = 0; l < c.pair_layers; ++l)
+            plan_centre(h, h->P[r][l], fmt("P%d.%d.", r, l), NP, L, c.pair_dff, l + 1 < c.pair_layers, l == 0);
+        h->Rx[r].resize(c.reg_layers + 1);
+        h->dRx[r].resize(c.reg_layers + 1);
+        for (int l = 0; l <= c.reg_layers; ++l) {
+            h->Rx[r][l] = h->ws_get(fmt("R%d.x%d", r, l), NR * kD);
+            h->dRx[r][l] = h->ws_get(fmt("dR%d.x%d", r, l), NR * kD);
+        }
+        h->R[r].resize(c.reg_layers);
+        for (int l = 0; l < c.reg_layers; ++l) {
+            RegBuf& b = h->R[r][l];
+            const std::string pre = fmt("R%d.%d.", r, l), d = "d" + pre;
+            const int dff = c.reg_dff;
+            b.qkvg = h->ws_get(pre + "qkvg", NR * kRW);
+            b.p = h->ws_get(pre + "p", MB * kRH * T * T);
+            b.a = h->ws_get(pre + "a", NR * kRDm);
+            b.xh1 = h->ws_get(pre + "xh1", NR * kD);
+            b.rs1 = h->ws_get(pre + "rs1", NR);
+            b.y1 = h->ws_get(pre + "y1", NR * kD);
+            b.hdn = h->ws_get(pre + "hdn", NR * dff);
+            b.xh2 = h->ws_get(pre + "xh2", NR * kD);
+            b.rs2 = h->ws_get(pre + "rs2", NR);
+            b.dt2 = h->ws_get(d + "t2", NR * kD);
+            b.dpre1 = h->ws_get(d + "pre1", NR * dff);
+            b.dt1 = h->ws_get(d + "t1", NR * kD);
+            b.da = h->ws_get(d + "a", NR * kRDm);
+            b.dqkvg = h->ws_get(d + "qkvg", NR * kRW);
+            b.partial = h->ws_get(d + "partial", ((NR + kTile - 1) / kTile) * post_partial_width(dff));
+            b.dgam = h->ws_get(d + "gam", MB * kRH);
+        }
+    }
+    h->hin = h->ws_get("H.in", MB * 3 * kD);
+    h->h1 = h->ws_get("H.h1", MB * kD);
+    h->logits = h->ws_get("H.logits", MB * c.n_out);
+    h->dlogits = h->ws_get("dH.logits", MB * c.n_out);
+    h->dh1 = h->ws_get("dH.h1", MB * kD);
+    h->dhin = h->ws_get("dH.in", MB * 3 * kD);
+    h->loss = h->ws_get("H.loss", 4);
+}
+
+// ------------------------------------------------------------------------------------
+// deferred gradient tables
+// ------------------------------------------------------------------------------------
+struct WgJob {
+    WgSeg seg[4];
+    int nseg;
+    float* C;
+    int ldc, Nn, Kk;
+};
+static void push_wg(std::vector<WgTile>& out, const WgJob& j) {
+    for (int n0 = 0; n0 < j.Nn; n0 += 64)
+        for (int k0 = 0; k0 < j.Kk; k0 += 64) {
+            WgTile t;
+            memset(&t, 0, sizeof t);
+            for (int s = 0; s < j.nseg; ++s) t.seg[s] = j.seg[s];
+            t.nseg = j.nseg;
+            t.C = j.C;
+            t.ldc = j.ldc;
+            t.Nn = j.Nn;
+            t.Kk = j.Kk;
+            t.n0 = n0;
+            t.k0 = k0;
+            out.push_back(t);
+        }
+}
+static WgJob wg1(const float* A, int lda, const float* B, int ldb, int rpg, float* C, int ldc, int Nn, int Kk) {
+    WgJob j;
+    memset(&j, 0, sizeof j);
+    j.seg[0] = WgSeg{A, B, lda, ldb, rpg};
+    j.nseg = 1;
+    j.C = C;
+    j.ldc = ldc;
+    j.Nn = Nn;
+    j.Kk = Kk;
+    return j;
+}
+static void push_cs(std::vector<CsTile>& out, const float* src, int ld, int ncols, int rpg, int div, float* dst) {
+    for (int c0 = 0; c0 < ncols; c0 += 64) out.push_back(CsTile{src, dst, ld, ncols, c0, rpg, div});
+}
+// the bias / LayerNorm gradients carried by one post-chain partial buffer
+static void push_post_cs(std::vector<CsTile>& out, const cf_handle* h, const float* part, int dff, int rpg,
+                         const std::string& att_pre, const std::string& ff_pre) {
+    const int pw = post_partial_width(dff);
+    push_cs(out, part + 0, pw, kD, rpg, kTile, h->G_(ff_pre + "ln.weight"));
+    push_cs(out, part + 128, pw, kD, rpg, kTile, h->G_(ff_pre + "ln.bias"));
+    push_cs(out, part + 256, pw, kD, rpg, kTile, h->G_(ff_pre + "l2.bias"));
+    push_cs(out, part + 384, pw, dff, rpg, kTile, h->G_(ff_pre + "l1.bias"));
+    push_cs(out, part + 384 + dff, pw, kD, rpg, kTile, h->G_(att_pre + "ln.weight"));
+    push_cs(out, part + 512 + dff, pw, kD, rpg, kTile, h->G_(att_pre + "ln.bias"));
+    push_cs(out, part + 640 + dff, pw, kD, rpg, kTile, h->G_(att_pre + "ff.bias"));
+}
+// weight gradients of one centre-row layer (q / k / v projections, out-projection, FFN)
+static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const CentreBuf& b, const float* xin, int ldxin,
+                           int rpg, int dff, float* gWq, float* gWk, float* gWv, const std::string& att_pre,
+                           const std::string& ff_pre) {
+    push_wg(out, wg1(b.dq, kD, xin, ldxin, rpg, gWq, kD, kD, kD));
+    for (int hd = 0; hd < 2; ++hd) {
+        push_wg(out, wg1(b.q + hd * 64, kD, b.dqt + hd * kD, 256, rpg, gWk + (size_t)hd * 64 * kD, kD, 64, kD));
+        push_wg(out, wg1(b.da + hd * 64, kD, b.xbar + hd * kD, 256, rpg, gWv + (size_t)hd * 64 * kD, kD, 64, kD));
+    }
+    push_wg(out, wg1(b.dt1, kD, b.a, kD, rpg, h->G_(att_pre + "ff.weight"), kD, kD, kD));
+    push_wg(out, wg1(b.dpre1, dff, b.y1, kD, rpg, h->G_(ff_pre + "l1.weight"), kD, dff, kD));
+    push_wg(out, wg1(b.dt2, kD, b.hdn, dff, rpg, h->G_(ff_pre + "l2.weight"), dff, kD, dff));
+}
+
+static int build_tables(cf_handle* h) {
+    const cf_config& c = h->cfg;
+    const int S = c.i_max, T = S + 1, F = c.n_feats;
+    std::vector<WgTile> wg;
+    std::vector<CsTile> cs;
+    for (int r = 0; r < c.n_res; ++r) {
+        const int bs = c.binsizes[r];
+        {   // Embedding
+            const std::string pre = fmt("embed.%d.", bs), lp = pre + "transformer.layers.0.";
+            const CentreBuf& b = h->E[r];
+            WgJob j;
+            memset(&j, 0, sizeof j);
+            j.seg[0] = WgSeg{h->edx0[r], h->featc[r], kD, 8, 1};
+            j.seg[1] = WgSeg{b.dxbar, b.w, kD, 8, 2};
+            j.seg[2] = WgSeg{b.qt, b.du, kD, 8, 2};
+            j.nseg = 3;
+            j.C = h->G_(pre + "lin_proj.weight");
+            j.ldc = F;
+            j.Nn = kD;
+            j.Kk = F;
+            push_wg(wg, j);
+            float* gatt = h->G_(lp + "self_att.att.weight");
+            push_centre_wg(wg, h, b, h->ex0[r], kD, 1, c.embed_dff, gatt, gatt + (size_t)kD * kD, gatt + (size_t)2 * kD * kD,
+                           lp + "self_att.", lp + "ff.");
+            push_post_cs(cs, h, b.partial, c.embed_dff, 1, lp + "self_att.", lp + "ff.");
+        }
+        {   // Pairwise
+            const std::string pre = fmt("pairwise_interaction.%d.", bs);
+            push_wg(wg, wg1(h->dxp0[r], kD, h->Rx[r][0], T * kD, 1, h->G_(pre + "lin_proj_p.weight"), kD, kD, kD));
+            WgJob j;
+            memset(&j, 0, sizeof j);
+            // lin_proj_pcre collects two terms per layer; at most 4 segments per tile, so
+            // layers are grouped in pairs and the second group would need accumulation:
+            // with pair_layers <= 2 a single job suffices (checked below).
+            int ns = 0;
+            for (int l = 0; l < c.pair_layers && ns + 2 <= 4; ++l) {
+                j.seg[ns++] = WgSeg{h->P[r][l].dxbar, h->P[r][l].w, kD, 8, 2 * S};
+                j.seg[ns++] = WgSeg{h->P[r][l].qt, h->P[r][l].du, kD, 8, 2 * S};
+            }
+            j.nseg = ns;
+            j.C = h->G_(pre + "lin_proj_pcre.weight");
+            j.ldc = F;
+            j.Nn = kD;
+            j.Kk = F;
+            push_wg(wg, j);
+            for (int l = 0; l < c.pair_layers; ++l) {
+                const std::string lp = pre + fmt("transformer.layers.%d.", l);
+                const CentreBuf& b = h->P[r][l];
+                const float* xin = l == 0 ? b.xin : h->P[r][l - 1].out;
+                float* gc = h->G_(lp + "self_att.c_att.weight");
+                push_centre_wg(wg, h, b, xin, kD, S, c.pair_dff, h->G_(lp + "self_att.p_att.weight"), gc, gc + (size_t)kD * kD,
+                               lp + "self_att.", lp + "ff.");
+                push_post_cs(cs, h, b.partial, c.pair_dff, S, lp + "self_att.", lp + "ff.");
+            }
+        }
+        for (int l = 0; l < c.reg_layers; ++l) {   // Regulation
+            const std::string lp = fmt("regulation.%d.transformer.layers.%d.", bs, l);
+            const RegBuf& b = h->R[r][l];
+            const int dff = c.reg_dff;
+            push_wg(wg, wg1(b.dqkvg, kRW, h->Rx[r][l], kD, T, h->G_(lp + "self_att.att.weight"), kD, kRW, kD));
+            push_wg(wg, wg1(b.dt1, kD, b.a, kRDm, T, h->G_(lp + "self_att.ff.weight"), kRDm, kD, kRDm));
+            push_wg(wg, wg1(b.dpre1, dff, b.y1, kD, T, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
+            push_wg(wg, wg1(b.dt2, kD, b.hdn, dff, T, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
+            push_post_cs(cs, h, b.partial, dff, T, lp + "self_att.", lp + "ff.");
+            push_cs(cs, b.dgam, kRH, kRH, 1, 1, h->G_(lp + "self_att.gamma_f"));
+        }
+    }
+    push_wg(wg, wg1(h->dh1, kD, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, kD, 3 * kD));
+    push_wg(wg, wg1(h->dlogits, c.n_out, h->h1, kD, 1, h->G_("fc_head.2.weight"), kD, c.n_out, kD));
+    push_cs(cs, h->dh1, kD, kD, 1, 1, h->G_("fc_head.0.bias"));
+    push_cs(cs, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
+
+    if (h->wg_tiles) (void)hipFree(h->wg_tiles);
+    if (h->cs_tiles) (void)hipFree(h->cs_tiles);
+    h->n_wg = (int)wg.size();
+    h->n_cs = (int)cs.size();
+    HIP_TRY(hipMalloc(&h->wg_tiles, wg.size() * sizeof(WgTile)));
+    HIP_TRY(hipMalloc(&h->cs_tiles, cs.size() * sizeof(CsTile)));
+    HIP_TRY(hipMemcpy(h->wg_tiles, wg.data(), wg.size() * sizeof(WgTile), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->cs_tiles, cs.data(), cs.size() * sizeof(CsTile), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// C ABI: host-only part
+// ------------------------------------------------------------------------------------
+extern "C" int cf_abi_version(void) { return CF_ABI_VERSION; }
+extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
+
+extern "C" int cf_param_layout(const cf_config* cfg, cf_layout* layout, cf_param_desc* table, int cap) {
+    if (!cfg || !layout) return fail("cf_param_layout: null argument");
+    std::vector<PDesc> v;
+    if (build_layout(*cfg, v, *layout)) return -1;
+    if (table) {
+        if (cap < (int)v.size()) return fail("cf_param_layout: table capacity %d < %d", cap, (int)v.size());
+        for (size_t i = 0; i < v.size(); ++i) {
+            cf_param_desc& d = table[i];
+            memset(&d, 0, sizeof d);
+            snprintf(d.name, sizeof d.name, "%s", v[i].name.c_str());
+            d.ndim = v[i].ndim;
+            d.shape[0] = v[i].shape[0];
+            d.shape[1] = v[i].shape[1];
+            d.offset = v[i].offset;
+            d.numel = v[i].numel;
+            d.trainable = v[i].trainable ? 1 : 0;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------
+extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_handle** out) {
+    if (!cfg || !pe_host || !out) return fail("cf_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("cf_create: no HIP device visible -- libchromoformer_hip has no CPU fallback");
+    cf_handle* h = new cf_handle();
+    h->cfg = *cfg;
+    if (build_layout(h->cfg, h->table, h->lay)) {
+        delete h;
+        return -1;
+    }
+    for (size_t i = 0; i < h->table.size(); ++i) h->index[h->table[i].name] = (int)i;
+    h->planning = true;
+    plan_workspace(h);
+    hipError_t e = hipMalloc(&h->arena, h->arena_floats * sizeof(float));
+    if (e != hipSuccess) {
+        delete h;
+        return fail("cf_create: hipMalloc(%zu bytes) failed: %s", h->arena_floats * sizeof(float), hipGetErrorString(e));
+    }
+    e = hipMemset(h->arena, 0, h->arena_floats * sizeof(float));
+    h->planning = false;
+    plan_workspace(h);
+    for (const auto& en : h->ws) h->ws_names += en.name + "\n";
+    for (int r = 0; r < h->cfg.n_res; ++r) {
+        const int L = h->cfg.n_bins[r];
+        h->edx0[r] = h->E[r].dx;
+        std::vector<float> t((size_t)L * kD);
+        for (int j = 0; j < L; ++j)
+            for (int d = 0; d < kD; ++d) t[(size_t)d * L + j] = pe_host[r][(size_t)j * kD + d];
+        if (hipMemcpy(h->pe[r], pe_host[r], (size_t)L * kD * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->pet[r], t.data(), (size_t)L * kD * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(h->arena);
+            delete h;
+            return fail("cf_create: positional table upload failed");
+        }
+    }
+    // dynamic LDS of the attention kernels
+    const cf_config& c = h->cfg;
+    h->n_fwd = 1 + 3 + 1 + 3 * c.pair_layers + 3 * c.reg_layers + 3;
+    h->n_bwd = 4 + 3 * c.reg_layers + 3 * c.pair_layers + 2 + 3 + 2;
+    h->n_opt = 1;
+    *out = h;
+    return 0;
+}
+
+extern "C" void cf_destroy(cf_handle* h) {
+    if (!h) return;
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->wg_tiles) (void)hipFree(h->wg_tiles);
+    if (h->cs_tiles) (void)hipFree(h->cs_tiles);
+    delete h;
+}
+
+extern "C" int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg, float* exp_avg_sq) {
+    if (!h || !params) return fail("cf_bind: null handle / params");
+    h->params = params;
+    h->grads = grads;
+    h->m = exp_avg;
+    h->v = exp_avg_sq;
+    if (grads) return build_tables(h);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+static inline int tiles_of(int n) { return (n + kTile - 1) / kTile; }
+static size_t attc_smem(int L, int F, bool bwd) { return (size_t)(256 + 256 + 48 + 2 * L + (bwd ? 2 * L : 0) + L * F) * sizeof(float); }
+static size_t attr_smem(int T, bool bwd) {
+    return (size_t)(T * kRW + kRH * T * T + (bwd ? kRH * T * T + T * kRDm + kRH * T : 0)) * sizeof(float);
+}
+
+template <bool VPROJ, int DM>
+static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& a) {
+    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256>), grid, dim3(256), 0, st, a);
+}
+template <bool VPROJ, int DM>
+static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArgs& a) {
+    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256>), grid, dim3(256), 0, st, a);
+}
+
+struct CentreParams {   // weights of one centre-row layer
+    const float *wq, *wk, *wv, *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2, *wlp;
+};
+static CentreParams centre_params(const cf_handle* h, const std::string& att_pre, const std::string& ff_pre, const float* wq,
+                                  const float* wk, const float* wv, const float* wlp) {
+    CentreParams p;
+    p.wq = wq;
+    p.wk = wk;
+    p.wv = wv;
+    p.wlp = wlp;
+    p.wo = h->P_(att_pre + "ff.weight");
+    p.bo = h->P_(att_pre + "ff.bias");
+    p.g1 = h->P_(att_pre + "ln.weight");
+    p.be1 = h->P_(att_pre + "ln.bias");
+    p.w1 = h->P_(ff_pre + "l1.weight");
+    p.b1 = h->P_(ff_pre + "l1.bias");
+    p.w2 = h->P_(ff_pre + "l2.weight");
+    p.b2 = h->P_(ff_pre + "l2.bias");
+    p.g2 = h->P_(ff_pre + "ln.weight");
+    p.be2 = h->P_(ff_pre + "ln.bias");
+    return p;
+}
+static CentreParams embed_params(const cf_handle* h, int r) {
+    const std::string pre = fmt("embed.%d.", h->cfg.binsizes[r]), lp = pre + "transformer.layers.0.";
+    const float* att = h->P_(lp + "self_att.att.weight");
+    return centre_params(h, lp + "self_att.", lp + "ff.", att, att + (size_t)kD * kD, att + (size_t)2 * kD * kD,
+                         h->P_(pre + "lin_proj.weight"));
+}
+static CentreParams pair_params(const cf_handle* h, int r, int l) {
+    const std::string pre = fmt("pairwise_interaction.%d.", h->cfg.binsizes[r]), lp = pre + fmt("transformer.layers.%d.", l);
+    const float* c_att = h->P_(lp + "self_att.c_att.weight");
+    return centre_params(h, lp + "self_att.", lp + "ff.", h->P_(lp + "self_att.p_att.weight"), c_att, c_att + (size_t)kD * kD,
+                         h->P_(pre + "lin_proj_pcre.weight"));
+}
+
+static int check_batch(const cf_handle* h, const cf_batch* b) {
+    if (!h || !b) return fail("null handle / batch");
+    if (!h->params) return fail("cf_bind has not been called");
+    if (b->B < 1 || b->B > h->cfg.max_batch) return fail("batch size %d outside 1..max_batch=%d", b->B, h->cfg.max_batch);
+    for (int r = 0; r < h->cfg.n_res; ++r)
+        if (!b->promoter_feats[r] || !b->pcre_feats[r] || !b->promoter_mask_row[r] || !b->pcre_mask_row[r] || !b->interaction_mask[r])
+            return fail("batch pointer for resolution %d is null", r);
+    if (!b->interaction_freq) return fail("interaction_freq is null");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int save, void* stream) {
+    if (check_batch(h, bt)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const cf_config& c = h->cfg;
+    const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
+    const int NE = B, NP = B * S, NR = B * T;
+    const float scale_c = sqrtf(64.f);
+    CentreParams ep[kMaxRes], pp[kMaxRes];
+    for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
+
+    {   // Embedding centre-row input
+        X0Args a;
+        for (int r = 0; r < nres; ++r) {
+            a.feats[r] = bt->promoter_feats[r];
+            a.pe[r] = h->pe[r];
+            a.wlp[r] = ep[r].wlp;
+            a.x0[r] = h->ex0[r];
+            a.featc[r] = h->featc[r];
+            a.L[r] = c.n_bins[r];
+        }
+        a.F = F;
+        hipLaunchKernelGGL(k_embed_x0, dim3(B, nres), dim3(128), 0, st, a);
+        LAUNCH_CHECK("k_embed_x0");
+    }
+    // one centre-row layer: query chain -> attention -> post chain
+    auto centre_layer = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* xin, RowMap xmap,
+                            const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff,
+                            float* const* outp, RowMap omap, bool copy_x) -> int {
+        QChainArgs q;
+        AttcArgs at;
+        PostArgs po;
+        size_t smem = 0;
+        for (int r = 0; r < nres; ++r) {
+            CentreBuf& b = *bufs[r];
+            q.x[r] = xin[r];
+            q.wq[r] = prm[r].wq;
+            q.wk[r] = prm[r].wk;
+            q.q[r] = b.q;
+            q.qt[r] = b.qt;
+            q.xcopy[r] = copy_x ? b.xin : nullptr;
+            at.feats[r] = feats[r];
+            at.mask[r] = mask[r];
+            at.mstride[r] = mstride[r];
+            at.pe[r] = h->pe[r];
+            at.pet[r] = h->pet[r];
+            at.wlp[r] = prm[r].wlp;
+            at.vin[r] = b.qt;
+            at.p[r] = b.p;
+            at.w[r] = b.w;
+            at.vout[r] = b.xbar;
+            at.L[r] = c.n_bins[r];
+            smem = std::max(smem, attc_smem(c.n_bins[r], F, false));
+            po.x[r] = xin[r];
+            po.ain[r] = b.xbar;
+            po.wv[r] = prm[r].wv;
+            po.wo[r] = prm[r].wo;
+            po.bo[r] = prm[r].bo;
+            po.g1[r] = prm[r].g1;
+            po.be1[r] = prm[r].be1;
+            po.w1[r] = prm[r].w1;
+            po.b1[r] = prm[r].b1;
+            po.w2[r] = prm[r].w2;
+            po.b2[r] = prm[r].b2;
+            po.g2[r] = prm[r].g2;
+            po.be2[r] = prm[r].be2;
+            po.a_out[r] = b.a;
+            po.xh1[r] = b.xh1;
+            po.rs1[r] = b.rs1;
+            po.y1[r] = b.y1;
+            po.hdn[r] = b.hdn;
+            po.xh2[r] = b.xh2;
+            po.rs2[r] = b.rs2;
+            po.out[r] = outp[r];
+        }
+        q.xmap = xmap;
+        q.N = N;
+        at.F = F;
+        at.scale = scale_c;
+        po.xmap = xmap;
+        po.omap = omap;
+        po.N = N;
+        po.save = save;
+        hipLaunchKernelGGL(k_qchain_fwd, dim3(tiles_of(N), nres), dim3(256), 0, st, q);
+        LAUNCH_CHECK("k_qchain_fwd");
+        hipLaunchKernelGGL((k_attc<false>), dim3(N, nres), dim3(256), smem, st, at);
+        LAUNCH_CHECK("k_attc<fwd>");
+        launch_post_fwd<true, 128>(dff, dim3(tiles_of(N), nres), st, po);
+        LAUNCH_CHECK("k_post_fwd<centre>");
+        return 0;
+    };
+
+    {   // Embedding
+        CentreBuf* bufs[kMaxRes];
+        const float* xin[kMaxRes];
+        float* outp[kMaxRes];
+        for (int r = 0; r < nres; ++r) {
+            bufs[r] = &h->E[r];
+            xin[r] = h->ex0[r];
+            outp[r] = h->Rx[r][0];
+        }
+        if (centre_layer(bufs, ep, xin, identity_map(), bt->promoter_feats, bt->promoter_mask_row, bt->promoter_mask_stride, NE,
+                         c.embed_dff, outp, RowMap{1, T, 0, 0}, false))
+            return -1;
+    }
+    {   // lin_proj_p on the promoter centre embedding (net.py:118)
+        LinArgs a;
+        for (int r = 0; r < nres; ++r) {
+            a.x[r] = h->Rx[r][0];
+            a.w[r] = h->P_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
+            a.b[r] = nullptr;
+            a.y[r] = h->xp0[r];
+        }
+        a.xmap = RowMap{1, T, 0, 0};
+        a.ldx = kD;
+        a.ldy = kD;
+        a.N = NE;
+        a.K = kD;
+        a.Nout = kD;
+        a.relu = 0;
+        hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of(NE), 1, nres), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_linear_fwd<lin_proj_p>");
+    }
+    for (int l = 0; l < c.pair_layers; ++l) {   // Pairwise layers
+        CentreBuf* bufs[kMaxRes];
+        const float* xin[kMaxRes];
+        float* outp[kMaxRes];
+        const bool last = l + 1 == c.pair_layers;
+        for (int r = 0; r < nres; ++r) {
+            pp[r] = pair_params(h, r, l);
+            bufs[r] = &h->P[r][l];
+            xin[r] = l == 0 ? h->xp0[r] : h->P[r][l - 1].out;
+            outp[r] = last ? h->Rx[r][0] : h->P[r][l].out;
+        }
+        const RowMap xmap = l == 0 ? RowMap{S, 1, 0, 0} : identity_map();
+        const RowMap omap = last ? RowMap{S, T, 1, 1} : identity_map();
+        if (centre_layer(bufs, pp, xin, xmap, bt->pcre_feats, bt->pcre_mask_row, bt->pcre_mask_stride, NP, c.pair_dff, outp, omap,
+                         l == 0))
+            return -1;
+    }
+    for (int l = 0; l < c.reg_layers; ++l) {   // Regulation layers
+        LinArgs la;
+        AttrArgs at;
+        PostArgs po;
+        for (int r = 0; r < nres; ++r) {
+            const std::string lp = fmt("regulation.%d.transformer.layers.%d.", c.binsizes[r], l);
+            RegBuf& b = h->R[r][l];
+            la.x[r] = h->Rx[r][l];
+            la.w[r] = h->P_(lp + "self_att.att.weight");
+            la.b[r] = nullptr;
+            la.y[r] = b.qkvg;
+            at.qkvg[r] = b.qkvg;
+            at.mask[r] = bt->interaction_mask[r];
+            at.gamma[r] = h->P_(lp + "self_att.gamma_f");
+            at.p[r] = b.p;
+            at.a[r] = b.a;
+            at.dqkvg[r] = nullptr;
+            at.dgam[r] = nullptr;
+            po.x[r] = h->Rx[r][l];
+            po.ain[r] = b.a;
+            po.wv[r] = nullptr;
+            po.wo[r] = h->P_(lp + "self_att.ff.weight");
+            po.bo[r] = h->P_(lp + "self_att.ff.bias");
+            po.g1[r] = h->P_(lp + "self_att.ln.weight");
+            po.be1[r] = h->P_(lp + "self_att.ln.bias");
+            po.w1[r] = h->P_(lp + "ff.l1.weight");
+            po.b1[r] = h->P_(lp + "ff.l1.bias");
+            po.w2[r] = h->P_(lp + "ff.l2.weight");
+            po.b2[r] = h->P_(lp + "ff.l2.bias");
+            po.g2[r] = h->P_(lp + "ff.ln.weight");
+            po.be2[r] = h->P_(lp + "ff.ln.bias");
+            po.a_out[r] = nullptr;
+            po.xh1[r] = b.xh1;
+            po.rs1[r] = b.rs1;
+            po.y1[r] = b.y1;
+            po.hdn[r] = b.hdn;
+            po.xh2[r] = b.xh2;
+            po.rs2[r] = b.rs2;
+            po.out[r] = h->Rx[r][l + 1];
+        }
+        la.xmap = identity_map();
+        la.ldx = kD;
+        la.ldy = kRW;
+        la.N = NR;
+        la.K = kD;
+        la.Nout = kRW;
+        la.relu = 0;
+        at.freq = bt->interaction_freq;
+        at.T = T;
+        po.xmap = identity_map();
+        po.omap = identity_map();
+        po.N = NR;
+        po.save = save;
+        hipLaunchKernelGGL((k_linear_fwd<4>), dim3(tiles_of(NR), kRW / 256, nres), dim3(256), 0, st, la);
+        LAUNCH_CHECK("k_linear_fwd<qkvg>");
+        hipLaunchKernelGGL((k_attr<false>), dim3(B, nres), dim3(256), attr_smem(T, false), st, at);
+        LAUNCH_CHECK("k_attr<fwd>");
+        launch_post_fwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+        LAUNCH_CHECK("k_post_fwd<reg>");
+    }
+    {   // head
+        HeadInArgs hi;
+        for (int r = 0; r < nres; ++r) {
+            hi.xl[r] = h->Rx[r][c.reg_layers];
+            hi.x0[r] = h->Rx[r][0];
+        }
+        hi.hin = h->hin;
+        hi.T = T;
+        hi.n_res = nres;
+        hipLaunchKernelGGL(k_head_in, dim3(B, nres), dim3(128), 0, st, hi);
+        LAUNCH_CHECK("k_head_in");
+        LinArgs a;
+        memset(&a, 0, sizeof a);
+        a.x[0] = h->hin;
+        a.w[0] = h->P_("fc_head.0.weight");
+        a.b[0] = h->P_("fc_head.0.bias");
+        a.y[0] = h->h1;
+        a.xmap = identity_map();
+        a.ldx = 3 * kD;
+        a.ldy = kD;
+        a.N = B;
+        a.K = 3 * kD;
+        a.Nout = kD;
+        a.relu = 1;
+        hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of(B), 1, 1), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_linear_fwd<head>");
+        hipLaunchKernelGGL(k_head_out, dim3(B), dim3(64), 0, st, h->h1, h->P_("fc_head.2.weight"), h->P_("fc_head.2.bias"),
+                           h->logits, c.n_out);
+        LAUNCH_CHECK("k_head_out");
+    }
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, h->logits, (size_t)B * c.n_out * sizeof(float), hipMemcpyDeviceToDevice, st));
+    h->last_fwd_B = save ? B : 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------
+static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
+    const cf_config& c = h->cfg;
+    const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
+    const int NE = B, NP = B * S, NR = B * T;
+    const float scale_c = sqrtf(64.f);
+    // head
+    hipLaunchKernelGGL(k_head_bwd1, dim3(B), dim3(128), 0, st, h->dlogits, h->P_("fc_head.2.weight"), h->h1, h->dh1, c.n_out);
+    LAUNCH_CHECK("k_head_bwd1");
+    {
+        DgradArgs a;
+        memset(&a, 0, sizeof a);
+        a.dy[0] = h->dh1;
+        a.lddy = kD;
+        a.w[0] = h->P_("fc_head.0.weight");
+        a.ldw = 3 * kD;
+        a.res[0] = nullptr;
+        a.rmap = identity_map();
+        a.dx[0] = h->dhin;
+        a.lddx = 3 * kD;
+        a.N = B;
+        a.K = kD;
+        a.Ncols = 3 * kD;
+        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(B), 3, 1), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_dgrad<head>");
+        HeadScatterArgs sc;
+        sc.dhin = h->dhin;
+        for (int r = 0; r < nres; ++r) sc.dxl[r] = h->dRx[r][c.reg_layers];
+        sc.T = T;
+        sc.n_res = nres;
+        hipLaunchKernelGGL(k_head_scatter, dim3(B, nres), dim3(128), 0, st, sc);
+        LAUNCH_CHECK("k_head_scatter");
+    }
+    for (int l = c.reg_layers - 1; l >= 0; --l) {   // Regulation
+        PostBwdArgs pb;
+        AttrArgs at;
+        DgradArgs dg;
+        for (int r = 0; r < nres; ++r) {
+            const std::string lp = fmt("regulation.%d.transformer.layers.%d.", c.binsizes[r], l);
+            RegBuf& b = h->R[r][l];
+            pb.dout[r] = h->dRx[r][l + 1];
+            pb.xh2[r] = b.xh2;
+            pb.rs2[r] = b.rs2;
+            pb.g2[r] = h->P_(lp + "ff.ln.weight");
+            pb.hdn[r] = b.hdn;
+            pb.w2[r] = h->P_(lp + "ff.l2.weight");
+            pb.w1[r] = h->P_(lp + "ff.l1.weight");
+            pb.xh1[r] = b.xh1;
+            pb.rs1[r] = b.rs1;
+            pb.g1[r] = h->P_(lp + "self_att.ln.weight");
+            pb.wo[r] = h->P_(lp + "self_att.ff.weight");
+            pb.wv[r] = nullptr;
+            pb.dt2[r] = b.dt2;
+            pb.dpre1[r] = b.dpre1;
+            pb.dt1[r] = b.dt1;
+            pb.da[r] = b.da;
+            pb.dxbar[r] = nullptr;
+            pb.partial[r] = b.partial;
+            at.qkvg[r] = b.qkvg;
+            at.mask[r] = bt->interaction_mask[r];
+            at.gamma[r] = h->P_(lp + "self_att.gamma_f");
+            at.p[r] = b.p;
+            at.a[r] = b.da;
+            at.dqkvg[r] = b.dqkvg;
+            at.dgam[r] = b.dgam;
+            dg.dy[r] = b.dqkvg;
+            dg.w[r] = h->P_(lp + "self_att.att.weight");
+            dg.res[r] = b.dt1;
+            dg.dx[r] = h->dRx[r][l];
+        }
+        pb.dmap = identity_map();
+        pb.N = NR;
+        at.freq = bt->interaction_freq;
+        at.T = T;
+        dg.lddy = kRW;
+        dg.ldw = kD;
+        dg.rmap = identity_map();
+        dg.ldres = kD;
+        dg.lddx = kD;
+        dg.N = NR;
+        dg.K = kRW;
+        dg.Ncols = kD;
+        launch_post_bwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+        LAUNCH_CHECK("k_post_bwd<reg>");
+        hipLaunchKernelGGL((k_attr<true>), dim3(B, nres), dim3(256), attr_smem(T, true), st, at);
+        LAUNCH_CHECK("k_attr<bwd>");
+        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(NR), 1, nres), dim3(256), 0, st, dg);
+        LAUNCH_CHECK("k_dgrad<qkvg>");
+    }
+    // one centre-row layer backward: post chain -> attention -> query chain
+    auto centre_bwd = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* dout, RowMap dmap,
+                          const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff) -> int {
+        PostBwdArgs pb;
+        AttcArgs at;
+        QBwdArgs qb;
+        size_t smem = 0;
+        for (int r = 0; r < nres; ++r) {
+            CentreBuf& b = *bufs[r];
+            pb.dout[r] = dout[r];
+            pb.xh2[r] = b.xh2;
+            pb.rs2[r] = b.rs2;
+            pb.g2[r] = prm[r].g2;
+            pb.hdn[r] = b.hdn;
+            pb.w2[r] = prm[r].w2;
+            pb.w1[r] = prm[r].w1;
+            pb.xh1[r] = b.xh1;
+            pb.rs1[r] = b.rs1;
+            pb.g1[r] = prm[r].g1;
+            pb.wo[r] = prm[r].wo;
+            pb.wv[r] = prm[r].wv;
+            pb.dt2[r] = b.dt2;
+            pb.dpre1[r] = b.dpre1;
+            pb.dt1[r] = b.dt1;
+            pb.da[r] = b.da;
+            pb.dxbar[r] = b.dxbar;
+            pb.partial[r] = b.partial;
+            at.feats[r] = feats[r];
+            at.mask[r] = mask[r];
+            at.mstride[r] = mstride[r];
+            at.pe[r] = h->pe[r];
+            at.pet[r] = h->pet[r];
+            at.wlp[r] = prm[r].wlp;
+            at.vin[r] = b.dxbar;
+            at.p[r] = b.p;
+            at.w[r] = b.du;
+            at.vout[r] = b.dqt;
+            at.L[r] = c.n_bins[r];
+            smem = std::max(smem, attc_smem(c.n_bins[r], F, true));
+            qb.dqt[r] = b.dqt;
+            qb.dres[r] = b.dt1;
+            qb.wk[r] = prm[r].wk;
+            qb.wq[r] = prm[r].wq;
+            qb.dq[r] = b.dq;
+            qb.dx[r] = b.dx;
+        }
+        pb.dmap = dmap;
+        pb.N = N;
+        at.F = F;
+        at.scale = scale_c;
+        qb.N = N;
+        launch_post_bwd<true, 128>(dff, dim3(tiles_of(N), nres), st, pb);
+        LAUNCH_CHECK("k_post_bwd<centre>");
+        hipLaunchKernelGGL((k_attc<true>), dim3(N, nres), dim3(256), smem, st, at);
+        LAUNCH_CHECK("k_attc<bwd>");
+        hipLaunchKernelGGL(k_qchain_bwd, dim3(tiles_of(N), nres), dim3(256), 0, st, qb);
+        LAUNCH_CHECK("k_qchain_bwd");
+        return 0;
+    };
+    CentreParams prm[kMaxRes];
+    for (int l = c.pair_layers - 1; l >= 0; --l) {   // Pairwise
+        CentreBuf* bufs[kMaxRes];
+        const float* dout[kMaxRes];
+        const bool last = l + 1 == c.pair_layers;
+        for (int r = 0; r < nres; ++r) {
+            prm[r] = pair_params(h, r, l);
+            bufs[r] = &h->P[r][l];
+            dout[r] = last ? h->dRx[r][0] : h->P[r][l + 1].dx;
+        }
+        if (centre_bwd(bufs, prm, dout, last ? RowMap{S, T, 1, 1} : identity_map(), bt->pcre_feats, bt->pcre_mask_row,
+                       bt->pcre_mask_stride, NP, c.pair_dff))
+            return -1;
+    }
+    {   // join the streams meeting at the promoter embedding, back through lin_proj_p
+        JoinArgs j;
+        DgradArgs a;
+        for (int r = 0; r < nres; ++r) {
+            j.dxp[r] = h->P[r][0].dx;
+            j.dx0[r] = h->dRx[r][0];
+            j.dxp0[r] = h->dxp0[r];
+            j.resid[r] = h->resid[r];
+            a.dy[r] = h->dxp0[r];
+            a.w[r] = h->P_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
+            a.res[r] = h->resid[r];
+            a.dx[r] = h->edout[r];
+        }
+        j.dhin = h->dhin;
+        j.S = S;
+        j.T = T;
+        j.n_res = nres;
+        hipLaunchKernelGGL(k_join, dim3(B, nres), dim3(128), 0, st, j);
+        LAUNCH_CHECK("k_join");
+        a.lddy = kD;
+        a.ldw = kD;
+        a.rmap = identity_map();
+        a.ldres = kD;
+        a.lddx = kD;
+        a.N = NE;
+        a.K = kD;
+        a.Ncols = kD;
+        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(NE), 1, nres), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_dgrad<lin_proj_p>");
+    }
+    {   // Embedding
+        CentreBuf* bufs[kMaxRes];
+        const float* dout[kMaxRes];
+        for (int r = 0; r < nres; ++r) {
+            prm[r] = embed_params(h, r);
+            bufs[r] = &h->E[r];
+            dout[r] = h->edout[r];
+        }
+        if (centre_bwd(bufs, prm, dout, identity_map(), bt->promoter_feats, bt->promoter_mask_row, bt->promoter_mask_stride, NE,
+                       c.embed_dff))
+            return -1;
+    }
+    // deferred weight / bias gradients
+    hipLaunchKernelGGL(k_wgrad, dim3(h->n_wg), dim3(256), 0, st, (const WgTile*)h->wg_tiles, B);
+    LAUNCH_CHECK("k_wgrad");
+    hipLaunchKernelGGL(k_colsum, dim3(h->n_cs), dim3(256), 0, st, (const CsTile*)h->cs_tiles, B);
+    LAUNCH_CHECK("k_colsum");
+    return 0;
+}
+
+static int check_bwd(cf_handle* h, const cf_batch* bt) {
+    if (check_batch(h, bt)) return -1;
+    if (!h->grads) return fail("cf_backward: no gradient buffer bound");
+    if (h->last_fwd_B != bt->B) return fail("cf_backward must follow cf_forward(save_for_backward=1) on the same batch");
+    return 0;
+}
+
+extern "C" int cf_backward(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out, void* stream) {
+    if (check_bwd(h, bt)) return -1;
+    if (!labels) return fail("cf_backward: labels is null");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, (const float*)h->logits, labels, bt->B, h->cfg.n_out, loss_scale,
+                       h->dlogits, h->loss);
+    LAUNCH_CHECK("k_loss");
+    if (backward_impl(h, bt, st)) return -1;
+    if (loss_out) HIP_TRY(hipMemcpyAsync(loss_out, h->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int cf_backward_from(cf_handle* h, const cf_batch* bt, const float* dlogits, void* stream) {
+    if (check_bwd(h, bt)) return -1;
+    if (!dlogits) return fail("cf_backward_from: dlogits is null");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->dlogits, dlogits, (size_t)bt->B * h->cfg.n_out * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return backward_impl(h, bt, st);
+}
+
+// ------------------------------------------------------------------------------------
+// optimiser
+// ------------------------------------------------------------------------------------
+extern "C" int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
+                             void* stream) {
+    if (!h || !h->params || !h->grads || !h->m || !h->v) return fail("cf_adamw_step: params / grads / moments not bound");
+    if (step < 1) return fail("cf_adamw_step: step is 1-based");
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)std::sqrt(bc2);
+    const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    const long long n4 = h->lay.n_active / 4;
+    const int grid = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params, (const float*)h->grads, h->m, h->v, n4,
+                       decay, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps);
+    LAUNCH_CHECK("k_adamw");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// introspection
+// ------------------------------------------------------------------------------------
+extern "C" int cf_debug_copy(cf_handle* h, const char* name, float* dst, long long* n_floats, void* stream) {
+    if (!h || !name) return fail("cf_debug_copy: null argument");
+    auto it = h->ws_index.find(name);
+    if (it == h->ws_index.end()) return fail("cf_debug_copy: no workspace buffer named '%s'", name);
+    const WsEntry& e = h->ws[it->second];
+    if (n_floats) *n_floats = (long long)e.n;
+    if (dst) HIP_TRY(hipMemcpyAsync(dst, h->arena + e.off, e.n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+extern "C" const char* cf_debug_names(cf_handle* h) { return h ? h->ws_names.c_str() : ""; }
+extern "C" int cf_launch_counts(cf_handle* h, int* fwd, int* bwd, int* opt) {
+    if (!h) return fail("null handle");
+    if (fwd) *fwd = h->n_fwd;
+    if (bwd) *bwd = h->n_bwd;
+    if (opt) *opt = h->n_opt;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// standalone operators
+// ------------------------------------------------------------------------------------
+extern "C" int cf_op_linear(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int relu, void* stream) {
+    if (K % 16 || N % 32) return fail("cf_op_linear: K %% 16 == 0 and N %% 32 == 0 required");
+    LinArgs a;
+    memset(&a, 0, sizeof a);
+    a.x[0] = A;
+    a.w[0] = W;
+    a.b[0] = bias;
+    a.y[0] = C;
+    a.xmap = identity_map();
+    a.ldx = K;
+    a.ldy = N;
+    a.N = M;
+    a.K = K;
+    a.Nout = N;
+    a.relu = relu;
+    hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of(M), (N + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK("cf_op_linear");
+    return 0;
+}
+extern "C" int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream) {
+    if (N % 16 || K % 32) return fail("cf_op_dgrad: N %% 16 == 0 and K %% 32 == 0 required");
+    DgradArgs a;
+    memset(&a, 0, sizeof a);
+    a.dy[0] = dY;
+    a.lddy = N;
+    a.w[0] = W;
+    a.ldw = K;
+    a.rmap = identity_map();
+    a.dx[0] = dX;
+    a.lddx = K;
+    a.N = M;
+    a.K = N;
+    a.Ncols = K;
+    hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(M), (K + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK("cf_op_dgrad");
+    return 0;
+}
+extern "C" int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, int N, int K, void* stream) {
+    std::vector<WgTile> tiles;
+    push_wg(tiles, wg1(dY, N, X, K, M, dW, K, N, K));
+    WgTile* d = nullptr;
+    HIP_TRY(hipMalloc(&d, tiles.size() * sizeof(WgTile)));
+    HIP_TRY(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(WgTile), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_wgrad, dim3((int)tiles.size()), dim3(256), 0, (hipStream_t)stream, (const WgTile*)d, 1);
+    LAUNCH_CHECK("cf_op_wgrad");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipFree(d));
+    return 0;
+}

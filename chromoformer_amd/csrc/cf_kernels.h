@@ -1,0 +1,1188 @@
+// cf_kernels.h -- gfx950 (MI355X) device code of the Chromoformer hot path.
+//
+// All arithmetic is fp32.  Dense contractions run on the f32-input matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32, bit-equal to an fmaf chain), everything else on
+// the VALU with 64-lane wavefront shuffles for the reductions.  One workgroup = 256
+// threads = 4 wavefronts.  "Row tile" kernels own 16 activation rows (one MFMA M-tile)
+// and walk a chain of Linear / LayerNorm ops with the activations resident in LDS and
+// the weights streamed from L2 straight into MFMA B fragments.
+//
+// Reference semantics (file:line under /root/reference/chromoformer):
+//   attention scores / mask / softmax ....... modules.py:58-77, 170-189
+//   gate, frequency bias ..................... modules.py:63-69, 80-81
+//   out-projection + residual + LayerNorm .... modules.py:28-30, 150-152
+//   FeedForward .............................. modules.py:100-101
+//   centre row, positional table ............. net.py:23-29, 59, 138
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 128;        // d_emb
+constexpr int kTile = 16;      // rows per workgroup (MFMA M)
+constexpr int kMaxRes = 3;
+constexpr float kLnEps = 1e-5f;
+constexpr float kMaskFill = -1e9f;
+
+// physical row = (row / div) * mul + (row % div) * rem + off
+struct RowMap {
+    int div, mul, rem, off;
+};
+__host__ __device__ inline RowMap identity_map() { return RowMap{1, 1, 0, 0}; }
+__device__ __forceinline__ int map_row(const RowMap& m, int row) {
+    return (row / m.div) * m.mul + (row % m.div) * m.rem + m.off;
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA tile products.  A is a 16-row tile in LDS (row stride lda floats, 16-byte aligned
+// rows).  Lane l = (r = l & 15, q = l >> 4).  The 16x16x4 instruction wants
+// A[i = r][k = q] and B[k = q][j = r]; the reduction index is assigned to lanes in
+// blocks of four (k = k0 + 4q + i for the i-th of four MFMAs) so that both operands are
+// read 16 bytes at a time.  Result fragment: acc[t][i] = C[row 4q + i][col t*16 + r].
+// ---------------------------------------------------------------------------------------
+
+// C[16, NT*16] += A[16, K] . W^T,  W row-major [n][K] (an nn.Linear weight); W points at
+// the first output column of this wave.
+template <int NT>
+__device__ __forceinline__ void mm_nt(const float* As, int lda, const float* __restrict__ W, int ldw, int K,
+                                      f32x4 (&acc)[NT]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* ap = As + r * lda + q * 4;
+    const float* wp = W + (size_t)r * ldw + q * 4;
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + k0);
+        float4 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * ldw + k0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = mfma4(a.x, b[t].x, acc[t]);
+            acc[t] = mfma4(a.y, b[t].y, acc[t]);
+            acc[t] = mfma4(a.z, b[t].z, acc[t]);
+            acc[t] = mfma4(a.w, b[t].w, acc[t]);
+        }
+    }
+}
+
+// C[16, NT*16] += A[16, K] . Bm,  Bm row-major [k][ldb]; Bm points at the first output
+// column of this wave.
+template <int NT>
+__device__ __forceinline__ void mm_nn(const float* As, int lda, const float* __restrict__ Bm, int ldb, int K,
+                                      f32x4 (&acc)[NT]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* ap = As + r * lda + q * 4;
+    const float* bp = Bm + (size_t)(q * 4) * ldb + r;
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + k0);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        float b[4][NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[i][t] = bp[(size_t)(k0 + i) * ldb + t * 16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(av[i], b[i][t], acc[t]);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Load a [16, ncols] tile (ncols % 4 == 0) of a row-major global matrix into LDS.
+__device__ __forceinline__ void load_tile(float* dst, int ldd, const float* __restrict__ src, int lds_, int ncols,
+                                          int row0, int nrows, const RowMap& map) {
+    const int c4n = ncols >> 2;
+    for (int i = threadIdx.x; i < kTile * c4n; i += blockDim.x) {
+        const int rr = i / c4n, c4 = i - rr * c4n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + rr < nrows) v = *reinterpret_cast<const float4*>(src + (size_t)map_row(map, row0 + rr) * lds_ + c4 * 4);
+        *reinterpret_cast<float4*>(dst + rr * ldd + c4 * 4) = v;
+    }
+}
+
+// LayerNorm forward over the 128 columns of the 4 rows this wave owns (rows 4w..4w+3 of
+// an LDS tile).  y = xhat * g + b is written back into the tile; xhat / rstd / y go to
+// global (row-major [N,128]) when the pointers are non-null.
+__device__ __forceinline__ void ln_fwd_rows(float* ts, int ld, const float* __restrict__ g, const float* __restrict__ b,
+                                            int row0, int nrows, float* xhat_g, float* rstd_g, float* y_g,
+                                            const RowMap& ymap) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float g0 = g[lane], g1 = g[lane + 64], b0 = b[lane], b1 = b[lane + 64];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = w * 4 + rr;
+        const float v0 = ts[row * ld + lane], v1 = ts[row * ld + lane + 64];
+        const float mean = wave_sum(v0 + v1) * (1.0f / kD);
+        const float d0 = v0 - mean, d1 = v1 - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / kD);
+        const float rstd = 1.0f / sqrtf(var + kLnEps);
+        const float x0 = d0 * rstd, x1 = d1 * rstd;
+        const float y0 = x0 * g0 + b0, y1 = x1 * g1 + b1;
+        ts[row * ld + lane] = y0;
+        ts[row * ld + lane + 64] = y1;
+        const int n = row0 + row;
+        if (n < nrows) {
+            if (xhat_g) {
+                xhat_g[(size_t)n * kD + lane] = x0;
+                xhat_g[(size_t)n * kD + lane + 64] = x1;
+                if (lane == 0) rstd_g[n] = rstd;
+            }
+            if (y_g) {
+                const size_t o = (size_t)map_row(ymap, n) * kD;
+                y_g[o + lane] = y0;
+                y_g[o + lane + 64] = y1;
+            }
+        }
+    }
+}
+
+// LayerNorm backward for the wave's 4 rows: dys holds dL/dy (LDS), xh the saved xhat
+// (LDS); dL/dx overwrites dys and is stored to dx_g.
+__device__ __forceinline__ void ln_bwd_rows(float* dys, int ld, const float* xh, int ldx, const float* __restrict__ g,
+                                            const float* __restrict__ rstd_g, int row0, int nrows, float* dx_g) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float g0 = g[lane], g1 = g[lane + 64];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = w * 4 + rr, n = row0 + row;
+        const float a0 = dys[row * ld + lane] * g0, a1 = dys[row * ld + lane + 64] * g1;
+        const float x0 = xh[row * ldx + lane], x1 = xh[row * ldx + lane + 64];
+        const float m1 = wave_sum(a0 + a1) * (1.0f / kD);
+        const float m2 = wave_sum(a0 * x0 + a1 * x1) * (1.0f / kD);
+        const float rs = (n < nrows) ? rstd_g[n] : 0.f;
+        const float o0 = rs * (a0 - m1 - x0 * m2), o1 = rs * (a1 - m1 - x1 * m2);
+        dys[row * ld + lane] = o0;
+        dys[row * ld + lane + 64] = o1;
+        if (n < nrows) {
+            dx_g[(size_t)n * kD + lane] = o0;
+            dx_g[(size_t)n * kD + lane + 64] = o1;
+        }
+    }
+}
+
+// column sums over the 16 rows of an LDS tile: out[c] = sum_r A[r][c] (* Bt[r][c])
+__device__ __forceinline__ void colsum16(const float* A, int lda, const float* Bt, int ldb, int ncols, float* out) {
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kTile; ++rr) s += Bt ? A[rr * lda + c] * Bt[rr * ldb + c] : A[rr * lda + c];
+        out[c] = s;
+    }
+}
+
+// =======================================================================================
+// Embedding: centre-row input  x0 = Wlp f_c + PE_c   (net.py:42-53 at row L//2)
+// also emits the centre features padded to 8 (operand of the lin_proj weight gradient)
+// =======================================================================================
+struct X0Args {
+    const float* feats[kMaxRes];
+    const float* pe[kMaxRes];
+    const float* wlp[kMaxRes];
+    float* x0[kMaxRes];
+    float* featc[kMaxRes];
+    int L[kMaxRes];
+    int F;
+};
+__global__ __launch_bounds__(128) void k_embed_x0(X0Args a) {
+    const int r = blockIdx.y, n = blockIdx.x, e = threadIdx.x;
+    const int L = a.L[r], c = L / 2, F = a.F;
+    const float* f = a.feats[r] + ((size_t)n * L + c) * F;
+    float acc = 0.f;
+    for (int i = 0; i < F; ++i) acc = fmaf(f[i], a.wlp[r][e * F + i], acc);
+    a.x0[r][(size_t)n * kD + e] = acc + a.pe[r][(size_t)c * kD + e];
+    if (e < 8) a.featc[r][(size_t)n * 8 + e] = e < F ? f[e] : 0.f;
+}
+
+// =======================================================================================
+// Query chain:  q = x Wq^T ;  qt[h] = q[h] Wk[h]   (the key projection absorbed into the
+// single query of each sequence; modules.py:38-58 / 159-170 for one query row)
+// =======================================================================================
+struct QChainArgs {
+    const float* x[kMaxRes];
+    RowMap xmap;
+    const float* wq[kMaxRes];   // [128,128]
+    const float* wk[kMaxRes];   // [128,128] rows = h*64+d
+    float* q[kMaxRes];          // [N,128]
+    float* qt[kMaxRes];         // [N,2,128]
+    float* xcopy[kMaxRes];      // optional: the (row-mapped) input rows, materialised [N,128]
+    int N;
+};
+__global__ __launch_bounds__(256) void k_qchain_fwd(QChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
+    const int r = blockIdx.y, row0 = blockIdx.x * kTile;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, a.N, a.xmap);
+    __syncthreads();
+    if (a.xcopy[r])
+        for (int i = threadIdx.x; i < kTile * kD; i += 256)
+            if (row0 + (i >> 7) < a.N) a.xcopy[r][(size_t)(row0 + (i >> 7)) * kD + (i & 127)] = xs[i >> 7][i & 127];
+    {
+        f32x4 acc[2];
+        zero_acc(acc);
+        mm_nt<2>(&xs[0][0], kD + 4, a.wq[r] + (size_t)(w * 32) * kD, kD, kD, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                qs[row][col] = acc[t][i];
+                if (row0 + row < a.N) a.q[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+            }
+    }
+    __syncthreads();
+    {
+        const int h = w >> 1, e0 = (w & 1) * 64;
+        f32x4 acc[4];
+        zero_acc(acc);
+        mm_nn<4>(&qs[0][h * 64], kD + 4, a.wk[r] + (size_t)(h * 64) * kD + e0, kD, 64, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i;
+                if (row0 + row < a.N) a.qt[r][(size_t)(row0 + row) * 256 + h * kD + e0 + t * 16 + lr] = acc[t][i];
+            }
+    }
+}
+
+struct QBwdArgs {
+    const float* dqt[kMaxRes];   // [N,2,128]
+    const float* dres[kMaxRes];  // [N,128] gradient arriving through the residual
+    const float* wk[kMaxRes];
+    const float* wq[kMaxRes];
+    float* dq[kMaxRes];          // [N,128]
+    float* dx[kMaxRes];          // [N,128]
+    int N;
+};
+__global__ __launch_bounds__(256) void k_qchain_bwd(QBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float ds[kTile][256 + 4];
+    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
+    const int r = blockIdx.y, row0 = blockIdx.x * kTile;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    load_tile(&ds[0][0], 260, a.dqt[r], 256, 256, row0, a.N, identity_map());
+    __syncthreads();
+    {   // dq[:, h*64+d] = sum_e dqt[:, h, e] Wk[h*64+d, e]
+        const int h = w >> 1;
+        f32x4 acc[2];
+        zero_acc(acc);
+        mm_nt<2>(&ds[0][h * kD], 260, a.wk[r] + (size_t)(w * 32) * kD, kD, kD, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                qs[row][col] = acc[t][i];
+                if (row0 + row < a.N) a.dq[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+            }
+    }
+    __syncthreads();
+    {   // dx = dres + dq Wq
+        f32x4 acc[2];
+        zero_acc(acc);
+        mm_nn<2>(&qs[0][0], kD + 4, a.wq[r] + w * 32, kD, kD, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                if (row0 + row < a.N) {
+                    const size_t o = (size_t)(row0 + row) * kD + col;
+                    a.dx[r][o] = acc[t][i] + a.dres[r][o];
+                }
+            }
+    }
+}
+
+// =======================================================================================
+// Centre-row attention over the bins of one region (one workgroup per sequence).
+//   forward : score_j = (f_j . u + PE_j . qt) / sqrt(dh),  u = Wlp^T qt
+//             p = softmax(masked_fill(score, -1e9));  xbar = Wlp (sum p_j f_j) + sum p_j PE_j
+//   backward: the same five passes with (dxbar, p) in and (dqt, du) out.
+// The features are the only HBM stream (L*F floats per sequence, read once, coalesced);
+// the positional table is shared by every sequence and stays in L2.  Two layouts of it
+// are kept: PE^T [128][L] for the bin-parallel pass and PE [L][128] for the
+// channel-parallel pass, so that both are unit-stride across lanes.
+// =======================================================================================
+struct AttcArgs {
+    const float* feats[kMaxRes];
+    const uint8_t* mask[kMaxRes];
+    long long mstride[kMaxRes];
+    const float* pe[kMaxRes];
+    const float* pet[kMaxRes];
+    const float* wlp[kMaxRes];
+    const float* vin[kMaxRes];   // fwd: qt, bwd: dxbar   [N,2,128]
+    float* p[kMaxRes];           // [N,2,L]   fwd: out, bwd: in
+    float* w[kMaxRes];           // [N,2,8]   fwd: w (out), bwd: du (out)
+    float* vout[kMaxRes];        // fwd: xbar, bwd: dqt   [N,2,128]
+    int L[kMaxRes];
+    int F;
+    float scale;                 // sqrt(d_head)
+};
+
+// two simultaneous block reductions (one per head); red is 16 floats of LDS scratch
+template <bool IS_MAX>
+__device__ __forceinline__ void block_reduce2(float& v0, float& v1, float* red) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    v0 = IS_MAX ? wave_max(v0) : wave_sum(v0);
+    v1 = IS_MAX ? wave_max(v1) : wave_sum(v1);
+    __syncthreads();
+    if (lane == 0) {
+        red[w] = v0;
+        red[4 + w] = v1;
+    }
+    __syncthreads();
+    if (IS_MAX) {
+        v0 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        v1 = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    } else {
+        v0 = (red[0] + red[1]) + (red[2] + red[3]);
+        v1 = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = blockIdx.y, n = blockIdx.x, tid = threadIdx.x;
+    const int L = a.L[r], F = a.F;
+    float* vin_s = smem;              // 256
+    float* half_s = vin_s + 256;      // 256
+    float* u_s = half_s + 256;        // 16  (h*8+f)
+    float* w_s = u_s + 16;            // 16
+    float* red_s = w_s + 16;          // 16
+    float* sc_s = red_s + 16;         // 2*L  scores -> p (fwd) / p -> ds (bwd)
+    float* dp_s = sc_s + 2 * L;       // 2*L  (bwd only)
+    float* feats_s = dp_s + (BWD ? 2 * L : 0);   // L*F
+
+    vin_s[tid] = a.vin[r][(size_t)n * 256 + tid];
+    if (tid < 16) {
+        u_s[tid] = 0.f;
+        w_s[tid] = 0.f;
+    }
+    const float* fg = a.feats[r] + (size_t)n * L * F;
+    for (int i = tid; i < L * F; i += 256) feats_s[i] = fg[i];
+    if (BWD) {
+        const float* pg = a.p[r] + (size_t)n * 2 * L;
+        for (int i = tid; i < 2 * L; i += 256) sc_s[i] = pg[i];
+    }
+    __syncthreads();
+
+    const float* wlp = a.wlp[r];
+    const int grp = tid >> 4, sub = tid & 15;
+    const int gh = grp / F, gf = grp - gh * F;      // valid when grp < 2F
+    // (1) u[h][f] = sum_e vin[h][e] Wlp[e][f]
+    if (grp < 2 * F) {
+        float s = 0.f;
+        for (int e = sub; e < kD; e += 16) s = fmaf(vin_s[gh * kD + e], wlp[e * F + gf], s);
+        s = group16_sum(s);
+        if (sub == 0) u_s[gh * 8 + gf] = s;
+    }
+    __syncthreads();
+
+    // (2) per-bin pass: t[h][j] = f_j . u[h] + PE_j . vin[h]
+    const uint8_t* mrow = a.mask[r] + (size_t)n * a.mstride[r];
+    const float* pet = a.pet[r];
+    for (int j = tid; j < L; j += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float fv = feats_s[j * F + f];
+            s0 = fmaf(fv, u_s[f], s0);
+            s1 = fmaf(fv, u_s[8 + f], s1);
+        }
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll 8
+        for (int e = 0; e < kD; ++e) {
+            const float pv = pet[(size_t)e * L + j];
+            t0 = fmaf(pv, vin_s[e], t0);
+            t1 = fmaf(pv, vin_s[kD + e], t1);
+        }
+        s0 += t0;
+        s1 += t1;
+        if (!BWD) {
+            s0 = s0 / a.scale;
+            s1 = s1 / a.scale;
+            if (mrow[j]) {
+                s0 = kMaskFill;
+                s1 = kMaskFill;
+            }
+            sc_s[j] = s0;
+            sc_s[L + j] = s1;
+        } else {
+            dp_s[j] = s0;
+            dp_s[L + j] = s1;
+        }
+    }
+    __syncthreads();
+
+    // (3) softmax (fwd) / softmax backward (bwd) over the bins, both heads at once
+    if (!BWD) {
+        float m0 = -INFINITY, m1 = -INFINITY;
+        for (int j = tid; j < L; j += 256) {
+            m0 = fmaxf(m0, sc_s[j]);
+            m1 = fmaxf(m1, sc_s[L + j]);
+        }
+        block_reduce2<true>(m0, m1, red_s);
+        float z0 = 0.f, z1 = 0.f;
+        for (int j = tid; j < L; j += 256) {
+            const float e0 = expf(sc_s[j] - m0), e1 = expf(sc_s[L + j] - m1);
+            sc_s[j] = e0;
+            sc_s[L + j] = e1;
+            z0 += e0;
+            z1 += e1;
+        }
+        block_reduce2<false>(z0, z1, red_s);
+        float* pg = a.p[r] + (size_t)n * 2 * L;
+        for (int j = tid; j < L; j += 256) {
+            const float p0 = sc_s[j] / z0, p1 = sc_s[L + j] / z1;
+            sc_s[j] = p0;
+            sc_s[L + j] = p1;
+            pg[j] = p0;
+            pg[L + j] = p1;
+        }
+    } else {
+        float d0 = 0.f, d1 = 0.f;
+        for (int j = tid; j < L; j += 256) {
+            d0 = fmaf(sc_s[j], dp_s[j], d0);
+            d1 = fmaf(sc_s[L + j], dp_s[L + j], d1);
+        }
+        block_reduce2<false>(d0, d1, red_s);
+        for (int j = tid; j < L; j += 256) {
+            const bool m = mrow[j] != 0;     // masked_fill passes no gradient
+            sc_s[j] = m ? 0.f : sc_s[j] * (dp_s[j] - d0) / a.scale;
+            sc_s[L + j] = m ? 0.f : sc_s[L + j] * (dp_s[L + j] - d1) / a.scale;
+        }
+    }
+    __syncthreads();
+
+    // (4) w[h][f] = sum_j sc[h][j] f_j[f]
+    if (grp < 2 * F) {
+        float s = 0.f;
+        for (int j = sub; j < L; j += 16) s = fmaf(sc_s[gh * L + j], feats_s[j * F + gf], s);
+        s = group16_sum(s);
+        if (sub == 0) w_s[gh * 8 + gf] = s;
+    }
+    // (5) pi[h][e] = sum_j sc[h][j] PE[j][e]   (two halves of the bin range)
+    const int e = tid & 127, half = tid >> 7;
+    const int Lh = (L + 1) >> 1;
+    const int j0 = half * Lh, j1 = min(L, j0 + Lh);
+    const float* pe = a.pe[r];
+    float c0 = 0.f, c1 = 0.f;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const float pv = pe[(size_t)j * kD + e];
+        c0 = fmaf(sc_s[j], pv, c0);
+        c1 = fmaf(sc_s[L + j], pv, c1);
+    }
+    if (half == 1) {
+        half_s[e] = c0;
+        half_s[kD + e] = c1;
+    }
+    __syncthreads();
+    if (tid < 16) a.w[r][(size_t)n * 16 + tid] = w_s[tid];
+    if (half == 0) {
+        c0 += half_s[e];
+        c1 += half_s[kD + e];
+        float x0 = 0.f, x1 = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float wv = wlp[e * F + f];
+            x0 = fmaf(w_s[f], wv, x0);
+            x1 = fmaf(w_s[8 + f], wv, x1);
+        }
+        a.vout[r][(size_t)n * 256 + e] = x0 + c0;
+        a.vout[r][(size_t)n * 256 + kD + e] = x1 + c1;
+    }
+}
+
+// =======================================================================================
+// Post-attention chain on a 16-row tile:
+//   [a = xbar[h] Wv[h]^T]  ->  y1 = LN(x + a Wo^T + bo)  ->  h = relu(y1 W1^T + b1)
+//   ->  out = LN(y1 + h W2^T + b2)          (modules.py:28-30 / 150-152, 100-101)
+// =======================================================================================
+struct PostArgs {
+    const float* x[kMaxRes];
+    RowMap xmap;
+    const float* ain[kMaxRes];   // VPROJ: xbar [N,2,128]   else: a [N,DM]
+    const float* wv[kMaxRes];
+    const float* wo[kMaxRes];
+    const float* bo[kMaxRes];
+    const float* g1[kMaxRes];
+    const float* be1[kMaxRes];
+    const float* w1[kMaxRes];
+    const float* b1[kMaxRes];
+    const float* w2[kMaxRes];
+    const float* b2[kMaxRes];
+    const float* g2[kMaxRes];
+    const float* be2[kMaxRes];
+    float* a_out[kMaxRes];
+    float* xh1[kMaxRes];
+    float* rs1[kMaxRes];
+    float* y1[kMaxRes];
+    float* hdn[kMaxRes];
+    float* xh2[kMaxRes];
+    float* rs2[kMaxRes];
+    float* out[kMaxRes];
+    RowMap omap;
+    int N;
+    int save;    // 0: inference, skip the activation saves
+};
+
+template <bool VPROJ, int DM, int DFF>
+__global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
+    constexpr int HW = (DFF > 256 ? DFF : 256);
+    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float as_[kTile][DM + 4];
+    __shared__ __attribute__((aligned(16))) float ts[kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float hs[kTile][HW + 4];
+    const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, N, a.xmap);
+    if (VPROJ) {
+        load_tile(&hs[0][0], HW + 4, a.ain[r], 256, 256, row0, N, identity_map());
+        __syncthreads();
+        const int h = w >> 1;
+        f32x4 acc[2];
+        zero_acc(acc);
+        mm_nt<2>(&hs[0][h * kD], HW + 4, a.wv[r] + (size_t)(w * 32) * kD, kD, kD, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                as_[row][col] = acc[t][i];
+                if (a.save && row0 + row < N) a.a_out[r][(size_t)(row0 + row) * DM + col] = acc[t][i];
+            }
+    } else {
+        load_tile(&as_[0][0], DM + 4, a.ain[r], DM, DM, row0, N, identity_map());
+    }
+    __syncthreads();
+    {   // t1 = x + a Wo^T + bo
+        f32x4 acc[2];
+        zero_acc(acc);
+        mm_nt<2>(&as_[0][0], DM + 4, a.wo[r] + (size_t)(w * 32) * DM, DM, DM, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                ts[row][col] = acc[t][i] + a.bo[r][col] + xs[row][col];
+            }
+    }
+    __syncthreads();
+    ln_fwd_rows(&ts[0][0], kD + 4, a.g1[r], a.be1[r], row0, N, a.save ? a.xh1[r] : nullptr, a.rs1[r],
+                a.save ? a.y1[r] : nullptr, identity_map());
+    __syncthreads();
+    {   // hdn = relu(y1 W1^T + b1)
+        constexpr int NT = DFF / 64;
+        f32x4 acc[NT];
+        zero_acc(acc);
+        mm_nt<NT>(&ts[0][0], kD + 4, a.w1[r] + (size_t)(w * (DFF / 4)) * kD, kD, kD, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * (DFF / 4) + t * 16 + lr;
+                const float v = fmaxf(acc[t][i] + a.b1[r][col], 0.f);
+                hs[row][col] = v;
+                if (a.save && row0 + row < N) a.hdn[r][(size_t)(row0 + row) * DFF + col] = v;
+            }
+    }
+    __syncthreads();
+    {   // t2 = y1 + hdn W2^T + b2
+        f32x4 acc[2];
+        zero_acc(acc);
+        mm_nt<2>(&hs[0][0], HW + 4, a.w2[r] + (size_t)(w * 32) * DFF, DFF, DFF, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                xs[row][col] = acc[t][i] + a.b2[r][col] + ts[row][col];
+            }
+    }
+    __syncthreads();
+    ln_fwd_rows(&xs[0][0], kD + 4, a.g2[r], a.be2[r], row0, N, a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+}
+
+// backward of the chain.  Per tile it also emits the column sums that make up the
+// bias / LayerNorm gradients:  partial[tile] = [dg2 | db2' | dbias2 | dbias1(DFF) | dg1 | db1' | dbo]
+struct PostBwdArgs {
+    const float* dout[kMaxRes];
+    RowMap dmap;
+    const float* xh2[kMaxRes];
+    const float* rs2[kMaxRes];
+    const float* g2[kMaxRes];
+    const float* hdn[kMaxRes];
+    const float* w2[kMaxRes];
+    const float* w1[kMaxRes];
+    const float* xh1[kMaxRes];
+    const float* rs1[kMaxRes];
+    const float* g1[kMaxRes];
+    const float* wo[kMaxRes];
+    const float* wv[kMaxRes];
+    float* dt2[kMaxRes];
+    float* dpre1[kMaxRes];
+    float* dt1[kMaxRes];
+    float* da[kMaxRes];
+    float* dxbar[kMaxRes];
+    float* partial[kMaxRes];
+    int N;
+};
+__host__ __device__ constexpr int post_partial_width(int dff) { return 768 + dff; }
+
+template <bool VPROJ, int DM, int DFF>
+__global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
+    constexpr int WW = (DFF > DM ? DFF : DM);
+    __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1
+    __shared__ __attribute__((aligned(16))) float xh[kTile][kD + 4];    // xhat2 -> xhat1
+    __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2 -> dt1
+    __shared__ __attribute__((aligned(16))) float wide[kTile][WW + 4];  // dpre1 -> da
+    const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    float* part = a.partial[r] + (size_t)blockIdx.x * post_partial_width(DFF);
+    load_tile(&ds[0][0], kD + 4, a.dout[r], kD, kD, row0, N, a.dmap);
+    load_tile(&xh[0][0], kD + 4, a.xh2[r], kD, kD, row0, N, identity_map());
+    __syncthreads();
+    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0);      // d ln2.weight
+    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128);           // d ln2.bias
+    __syncthreads();
+    // LN2 backward -> dt2  (kept in t2; ds keeps dout*... no longer needed)
+    for (int i = threadIdx.x; i < kTile * kD; i += 256) t2[i >> 7][i & 127] = ds[i >> 7][i & 127];
+    __syncthreads();
+    ln_bwd_rows(&t2[0][0], kD + 4, &xh[0][0], kD + 4, a.g2[r], a.rs2[r], row0, N, a.dt2[r]);
+    __syncthreads();
+    colsum16(&t2[0][0], kD + 4, nullptr, 0, kD, part + 256);           // d l2.bias
+    {   // dpre1 = (dt2 W2) * (hdn > 0)
+        constexpr int NT = DFF / 64;
+        f32x4 acc[NT];
+        zero_acc(acc);
+        mm_nn<NT>(&t2[0][0], kD + 4, a.w2[r] + w * (DFF / 4), DFF, kD, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * (DFF / 4) + t * 16 + lr;
+                float v = 0.f;
+                if (row0 + row < N) {
+                    const size_t o = (size_t)(row0 + row) * DFF + col;
+                    v = a.hdn[r][o] > 0.f ? acc[t][i] : 0.f;
+                    a.dpre1[r][o] = v;
+                }
+                wide[row][col] = v;
+            }
+    }
+    load_tile(&xh[0][0], kD + 4, a.xh1[r], kD, kD, row0, N, identity_map());   // xhat2 is dead now
+    __syncthreads();
+    colsum16(&wide[0][0], WW + 4, nullptr, 0, DFF, part + 384);        // d l1.bias
+    {   // dy1 = dt2 + dpre1 W1
+        f32x4 acc[2];
+        zero_acc(acc);
+        mm_nn<2>(&wide[0][0], WW + 4, a.w1[r] + w * 32, kD, DFF, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                ds[row][col] = acc[t][i] + t2[row][col];
+            }
+    }
+    __syncthreads();
+    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF);   // d ln1.weight
+    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 512 + DFF);          // d ln1.bias
+    __syncthreads();
+    ln_bwd_rows(&ds[0][0], kD + 4, &xh[0][0], kD + 4, a.g1[r], a.rs1[r], row0, N, a.dt1[r]);   // ds = dt1
+    __syncthreads();
+    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF);     // d out-proj bias
+    {   // da = dt1 Wo
+        constexpr int NT = DM / 64;
+        f32x4 acc[NT];
+        zero_acc(acc);
+        mm_nn<NT>(&ds[0][0], kD + 4, a.wo[r] + w * (DM / 4), DM, kD, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * (DM / 4) + t * 16 + lr;
+                wide[row][col] = acc[t][i];
+                if (row0 + row < N) a.da[r][(size_t)(row0 + row) * DM + col] = acc[t][i];
+            }
+    }
+    if (VPROJ) {   // dxbar[:, h, e] = sum_d da[:, h*64+d] Wv[h*64+d, e]
+        __syncthreads();
+        const int h = w >> 1, e0 = (w & 1) * 64;
+        f32x4 acc[4];
+        zero_acc(acc);
+        mm_nn<4>(&wide[0][h * 64], WW + 4, a.wv[r] + (size_t)(h * 64) * kD + e0, kD, 64, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i;
+                if (row0 + row < N) a.dxbar[r][(size_t)(row0 + row) * 256 + h * kD + e0 + t * 16 + lr] = acc[t][i];
+            }
+    }
+}
+
+// =======================================================================================
+// Generic Linear forward / input-gradient on 16-row tiles (used where no chain applies:
+// Regulation q|k|v|gate projection, lin_proj_p, the head).
+// =======================================================================================
+struct LinArgs {
+    const float* x[kMaxRes];
+    RowMap xmap;
+    int ldx;
+    const float* w[kMaxRes];     // [Nout, K]
+    const float* b[kMaxRes];     // may be null
+    float* y[kMaxRes];
+    int ldy;
+    int N, K, Nout, relu;
+};
+constexpr int kKChunk = 256;   // reduction columns staged in LDS at a time
+template <int NT>
+__global__ __launch_bounds__(256) void k_linear_fwd(LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[kTile][kKChunk + 4];
+    const int r = blockIdx.z, row0 = blockIdx.x * kTile, K = a.K;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int col0 = blockIdx.y * (64 * NT) + w * (16 * NT);
+    const bool active = col0 < a.Nout;
+    f32x4 acc[NT];
+    zero_acc(acc);
+    for (int kc = 0; kc < K; kc += kKChunk) {
+        const int kl = min(kKChunk, K - kc);
+        if (kc) __syncthreads();
+        load_tile(&xs[0][0], kKChunk + 4, a.x[r] + kc, a.ldx, kl, row0, a.N, a.xmap);
+        __syncthreads();
+        if (active) mm_nt<NT>(&xs[0][0], kKChunk + 4, a.w[r] + (size_t)col0 * K + kc, K, kl, acc);
+    }
+    if (!active) return;
+    const float* bias = a.b[r];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i, col = col0 + t * 16 + lr;
+            if (row0 + row < a.N) {
+                float v = acc[t][i] + (bias ? bias[col] : 0.f);
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.y[r][(size_t)(row0 + row) * a.ldy + col] = v;
+            }
+        }
+}
+
+struct DgradArgs {
+    const float* dy[kMaxRes];    // [N, K]
+    int lddy;
+    const float* w[kMaxRes];     // [K, ldw]  (the Linear weight [out=K, in=Ncols])
+    int ldw;
+    const float* res[kMaxRes];   // optional residual gradient, [.., ldres] through rmap
+    RowMap rmap;
+    int ldres;
+    float* dx[kMaxRes];
+    int lddx;
+    int N, K, Ncols;
+};
+template <int NT>
+__global__ __launch_bounds__(256) void k_dgrad(DgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float ys[kTile][kKChunk + 4];
+    const int r = blockIdx.z, row0 = blockIdx.x * kTile, K = a.K;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int col0 = blockIdx.y * (64 * NT) + w * (16 * NT);
+    const bool active = col0 < a.Ncols;
+    f32x4 acc[NT];
+    zero_acc(acc);
+    for (int kc = 0; kc < K; kc += kKChunk) {
+        const int kl = min(kKChunk, K - kc);
+        if (kc) __syncthreads();
+        load_tile(&ys[0][0], kKChunk + 4, a.dy[r] + kc, a.lddy, kl, row0, a.N, identity_map());
+        __syncthreads();
+        if (active) mm_nn<NT>(&ys[0][0], kKChunk + 4, a.w[r] + (size_t)kc * a.ldw + col0, a.ldw, kl, acc);
+    }
+    if (!active) return;
+    const float* res = a.res[r];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i, col = col0 + t * 16 + lr;
+            if (row0 + row < a.N) {
+                float v = acc[t][i];
+                if (res) v += res[(size_t)map_row(a.rmap, row0 + row) * a.ldres + col];
+                a.dx[r][(size_t)(row0 + row) * a.lddx + col] = v;
+            }
+        }
+}
+
+// =======================================================================================
+// Regulation attention: T <= 17 tokens, 8 heads x 32, gate + frequency bias
+// (modules.py:38-81).  One workgroup per (gene, resolution).
+// =======================================================================================
+constexpr int kRH = 8, kRDh = 32, kRDm = 256, kRW = 1024, kRMaxT = 17;
+struct AttrArgs {
+    const float* qkvg[kMaxRes];      // [B*T, 1024]  q | k | v | gate
+    const uint8_t* mask[kMaxRes];    // [B, T, T]
+    const float* freq;               // [B, T, T]
+    const float* gamma[kMaxRes];     // [8]
+    float* p[kMaxRes];               // [B, 8, T, T]
+    float* a[kMaxRes];               // fwd out [B*T, 256]; bwd in: da
+    float* dqkvg[kMaxRes];           // bwd out
+    float* dgam[kMaxRes];            // bwd out [B, 8] per-gene partials
+    int T;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_attr(AttrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, T = a.T, TT = T * T;
+    float* x_s = smem;                       // [T][1024]
+    float* p_s = x_s + T * kRW;              // [8][T][T]
+    float* ds_s = p_s + kRH * TT;            // [8][T][T]     (bwd)
+    float* do_s = ds_s + (BWD ? kRH * TT : 0);   // [T][256]  (bwd)
+    float* red_s = do_s + (BWD ? T * kRDm : 0);  // 8*T       (bwd)
+    const float inv = 1.0f;                  // division by sqrt(dh) done explicitly below
+    (void)inv;
+    const float scale = sqrtf((float)kRDh);
+    const float* xg = a.qkvg[r] + (size_t)g * T * kRW;
+    for (int i = tid; i < T * kRW / 4; i += 256) reinterpret_cast<float4*>(x_s)[i] = reinterpret_cast<const float4*>(xg)[i];
+    if (BWD) {
+        const float* pg = a.p[r] + (size_t)g * kRH * TT;
+        for (int i = tid; i < kRH * TT; i += 256) p_s[i] = pg[i];
+    }
+    __syncthreads();
+    const uint8_t* mk = a.mask[r] + (size_t)g * TT;
+    const float* fq = a.freq + (size_t)g * TT;
+    if (!BWD) {
+        for (int idx = tid; idx < kRH * TT; idx += 256) {
+            const int h = idx / TT, ij = idx - h * TT, i = ij / T, j = ij - i * T;
+            const float* qp = x_s + i * kRW + h * kRDh;
+            const float* kp = x_s + j * kRW + kRDm + h * kRDh;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < kRDh; ++d) s = fmaf(qp[d], kp[d], s);
+            s = s / scale + a.gamma[r][h] * fq[ij];
+            if (mk[ij]) s = kMaskFill;
+            p_s[idx] = s;
+        }
+        __syncthreads();
+        for (int row = tid; row < kRH * T; row += 256) {
+            float* pr = p_s + row * T;
+            float m = -INFINITY;
+            for (int j = 0; j < T; ++j) m = fmaxf(m, pr[j]);
+            float z = 0.f;
+            for (int j = 0; j < T; ++j) {
+                const float e = expf(pr[j] - m);
+                pr[j] = e;
+                z += e;
+            }
+            for (int j = 0; j < T; ++j) pr[j] = pr[j] / z;
+        }
+        __syncthreads();
+        float* pg = a.p[r] + (size_t)g * kRH * TT;
+        for (int i = tid; i < kRH * TT; i += 256) pg[i] = p_s[i];
+        for (int idx = tid; idx < T * kRDm; idx += 256) {
+            const int i = idx >> 8, c = idx & 255, h = c >> 5;
+            const float* pr = p_s + (h * T + i) * T;
+            float o = 0.f;
+            for (int j = 0; j < T; ++j) o = fmaf(pr[j], x_s[j * kRW + 2 * kRDm + c], o);
+            const float gt = x_s[i * kRW + 3 * kRDm + c];
+            const float sg = 1.0f / (1.0f + expf(-gt));
+            a.a[r][((size_t)g * T + i) * kRDm + c] = o * sg;
+        }
+    } else {
+        float* dx = a.dqkvg[r] + (size_t)g * T * kRW;
+        const float* dag = a.a[r] + (size_t)g * T * kRDm;
+        // gate / value-side: do = da * sigmoid(g); dgate = da * o * s(1-s)
+        for (int idx = tid; idx < T * kRDm; idx += 256) {
+            const int i = idx >> 8, c = idx & 255, h = c >> 5;
+            const float* pr = p_s + (h * T + i) * T;
+            float o = 0.f;
+            for (int j = 0; j < T; ++j) o = fmaf(pr[j], x_s[j * kRW + 2 * kRDm + c], o);
+            const float gt = x_s[i * kRW + 3 * kRDm + c];
+            const float sg = 1.0f / (1.0f + expf(-gt));
+            const float da = dag[idx];
+            do_s[idx] = da * sg;
+            dx[i * kRW + 3 * kRDm + c] = da * o * sg * (1.0f - sg);
+        }
+        __syncthreads();
+        // dp[h][i][j] = do[i][h] . v[j][h]
+        for (int idx = tid; idx < kRH * TT; idx += 256) {
+            const int h = idx / TT, ij = idx - h * TT, i = ij / T, j = ij - i * T;
+            const float* dp = do_s + i * kRDm + h * kRDh;
+            const float* vp = x_s + j * kRW + 2 * kRDm + h * kRDh;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < kRDh; ++d) s = fmaf(dp[d], vp[d], s);
+            ds_s[idx] = s;
+        }
+        __syncthreads();
+        for (int row = tid; row < kRH * T; row += 256) {
+            const float* pr = p_s + row * T;
+            float* dr = ds_s + row * T;
+            const int i = row % T;
+            float dot = 0.f;
+            for (int j = 0; j < T; ++j) dot = fmaf(pr[j], dr[j], dot);
+            float gsum = 0.f;
+            for (int j = 0; j < T; ++j) {
+                const float v = mk[i * T + j] ? 0.f : pr[j] * (dr[j] - dot);
+                gsum = fmaf(v, fq[i * T + j], gsum);
+                dr[j] = v;
+            }
+            red_s[row] = gsum;
+        }
+        __syncthreads();
+        if (tid < kRH) {
+            float s = 0.f;
+            for (int i = 0; i < T; ++i) s += red_s[tid * T + i];
+            a.dgam[r][(size_t)g * kRH + tid] = s;
+        }
+        // dq, dk, dv
+        for (int idx = tid; idx < T * kRDm; idx += 256) {
+            const int i = idx >> 8, c = idx & 255, h = c >> 5;
+            float dq = 0.f, dk = 0.f, dv = 0.f;
+            for (int j = 0; j < T; ++j) {
+                dq = fmaf(ds_s[(h * T + i) * T + j], x_s[j * kRW + kRDm + c], dq);     // ds[i][j] k[j]
+                dk = fmaf(ds_s[(h * T + j) * T + i], x_s[j * kRW + c], dk);            // ds[j][i] q[j]
+                dv = fmaf(p_s[(h * T + j) * T + i], do_s[j * kRDm + c], dv);           // p[j][i] do[j]
+            }
+            dx[i * kRW + c] = dq / scale;
+            dx[i * kRW + kRDm + c] = dk / scale;
+            dx[i * kRW + 2 * kRDm + c] = dv;
+        }
+    }
+}
+
+// =======================================================================================
+// Head  (net.py:377-380; loss train.py:156, 193)
+// =======================================================================================
+struct HeadInArgs {
+    const float* xl[kMaxRes];    // regulation output  [B*T,128]
+    const float* x0[kMaxRes];    // regulation input   [B*T,128]
+    float* hin;                  // [B, 3*128]
+    int T, n_res;
+};
+__global__ __launch_bounds__(128) void k_head_in(HeadInArgs a) {
+    const int g = blockIdx.x, r = blockIdx.y, e = threadIdx.x;
+    const size_t o = (size_t)g * a.T * kD + e;
+    a.hin[(size_t)g * (a.n_res * kD) + r * kD + e] = a.xl[r][o] + a.x0[r][o];
+}
+
+// logits[g][c] = h1[g] . W2[c] + b2[c]        (n_out is 1 or 2: VALU)
+__global__ __launch_bounds__(64) void k_head_out(const float* __restrict__ h1, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, float* logits, int n_out) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    for (int c = 0; c < n_out; ++c) {
+        float s = h1[(size_t)g * kD + lane] * w2[c * kD + lane] + h1[(size_t)g * kD + lane + 64] * w2[c * kD + lane + 64];
+        s = wave_sum(s);
+        if (lane == 0) logits[g * n_out + c] = s + b2[c];
+    }
+}
+
+// CrossEntropyLoss (mean) / MSELoss (mean) and d loss / d logits, one workgroup.
+__global__ __launch_bounds__(256) void k_loss(const float* __restrict__ logits, const void* labels, int B, int n_out,
+                                              float gscale, float* dlogits, float* loss_out) {
+    __shared__ float red[4];
+    float li = 0.f;
+    for (int g = threadIdx.x; g < B; g += 256) {
+        if (n_out == 1) {
+            const float y = reinterpret_cast<const float*>(labels)[g];
+            const float d = logits[g] - y;
+            li += d * d;
+            dlogits[g] = 2.0f * d * gscale / (float)B;
+        } else {
+            const long long y = reinterpret_cast<const long long*>(labels)[g];
+            float m = -INFINITY;
+            for (int c = 0; c < n_out; ++c) m = fmaxf(m, logits[g * n_out + c]);
+            float z = 0.f;
+            for (int c = 0; c < n_out; ++c) z += expf(logits[g * n_out + c] - m);
+            const float lse = m + logf(z);
+            li += lse - logits[g * n_out + (int)y];
+            for (int c = 0; c < n_out; ++c)
+                dlogits[g * n_out + c] = (expf(logits[g * n_out + c] - lse) - (c == (int)y ? 1.f : 0.f)) * gscale / (float)B;
+        }
+    }
+    li = wave_sum(li);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+}
+
+// dh1pre[g][j] = (sum_c dlogits[g][c] W2[c][j]) * (h1 > 0)
+__global__ __launch_bounds__(128) void k_head_bwd1(const float* __restrict__ dlogits, const float* __restrict__ w2,
+                                                   const float* __restrict__ h1, float* dh1, int n_out) {
+    const int g = blockIdx.x, j = threadIdx.x;
+    float s = 0.f;
+    for (int c = 0; c < n_out; ++c) s = fmaf(dlogits[g * n_out + c], w2[c * kD + j], s);
+    dh1[(size_t)g * kD + j] = h1[(size_t)g * kD + j] > 0.f ? s : 0.f;
+}
+
+// scatter d hin onto token 0 of the (pre-zeroed) regulation output gradient
+struct HeadScatterArgs {
+    const float* dhin;
+    float* dxl[kMaxRes];
+    int T, n_res;
+};
+__global__ __launch_bounds__(128) void k_head_scatter(HeadScatterArgs a) {
+    const int g = blockIdx.x, r = blockIdx.y, e = threadIdx.x;
+    a.dxl[r][(size_t)g * a.T * kD + e] = a.dhin[(size_t)g * (a.n_res * kD) + r * kD + e];
+}
+
+// Joins the gradient streams that meet at the promoter embedding e_c of a gene:
+//   dxp0[g] = sum_s dxP[g*S+s]       (lin_proj_p output is broadcast over the S slots)
+//   resid[g] = dX0[g, token 0] + dhin[g, r]   (regulation input + final skip, net.py:378)
+struct JoinArgs {
+    const float* dxp[kMaxRes];   // [B*S,128]
+    const float* dx0[kMaxRes];   // [B*T,128]
+    const float* dhin;           // [B, n_res*128]
+    float* dxp0[kMaxRes];        // [B,128]
+    float* resid[kMaxRes];       // [B,128]
+    int S, T, n_res;
+};
+__global__ __launch_bounds__(128) void k_join(JoinArgs a) {
+    const int g = blockIdx.x, r = blockIdx.y, e = threadIdx.x;
+    float s = 0.f;
+    for (int i = 0; i < a.S; ++i) s += a.dxp[r][((size_t)g * a.S + i) * kD + e];
+    a.dxp0[r][(size_t)g * kD + e] = s;
+    a.resid[r][(size_t)g * kD + e] = a.dx0[r][(size_t)g * a.T * kD + e] + a.dhin[(size_t)g * (a.n_res * kD) + r * kD + e];
+}
+
+// =======================================================================================
+// Deferred weight gradients: one launch, a table of 64x64 output tiles.
+//   C[n][k] = sum over segments, sum_m A[m][n] * Bm[m][k]      (dW = dY^T X)
+// =======================================================================================
+struct WgSeg {
+    const float* A;
+    const float* B;
+    int lda, ldb;
+    int rows_per_gene;    // M = rows_per_gene * batch
+};
+struct WgTile {
+    WgSeg seg[4];
+    int nseg;
+    float* C;
+    int ldc, Nn, Kk;
+    int n0, k0;
+};
+__global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) {
+    const WgTile& t = tiles[blockIdx.x];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int n = t.n0 + w * 16 + lr;
+    const bool nv = n < t.Nn;
+    f32x4 acc[4];
+    zero_acc(acc);
+    int kk[4];
+    bool kv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        kk[c] = t.k0 + c * 16 + lr;
+        kv[c] = kk[c] < t.Kk;
+    }
+    for (int s = 0; s < t.nseg; ++s) {
+        const WgSeg& sg = t.seg[s];
+        const int M = sg.rows_per_gene * batch;
+        const float* Ap = sg.A + n;
+        for (int m0 = 0; m0 < M; m0 += 16) {
+            float av[4], bv[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + i * 4 + lq;
+                const bool mv = m < M;
+                av[i] = (mv && nv) ? Ap[(size_t)m * sg.lda] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bv[i][c] = (mv && kv[c]) ? sg.B[(size_t)m * sg.ldb + kk[c]] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = mfma4(av[i], bv[i][c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = t.n0 + w * 16 + lq * 4 + i;
+            if (row < t.Nn && kv[c]) t.C[(size_t)row * t.ldc + kk[c]] = acc[c][i];
+        }
+}
+
+// Deferred column sums (bias / LayerNorm / gamma gradients): out[c] = sum_m src[m][c]
+struct CsTile {
+    const float* src;
+    float* out;
+    int ld, ncols, c0;
+    int rows_per_gene, div;      // M = ceil(rows_per_gene * batch / div)
+};
+__global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles, int batch) {
+    __shared__ float red[4][64];
+    const CsTile& t = tiles[blockIdx.x];
+    const int M = (t.rows_per_gene * batch + t.div - 1) / t.div;
+    const int c = t.c0 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < t.ncols)
+        for (int m = ph; m < M; m += 4) s += t.src[(size_t)m * t.ld + c];
+    red[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && c < t.ncols) t.out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// =======================================================================================
+// AdamW (torch.optim.AdamW defaults as used at train.py:157): decoupled decay, then the
+// moment updates and the bias-corrected step, in the same operation order as torch.
+// =======================================================================================
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, long long n4, float decay, float one_m_b1, float b2,
+                                               float one_m_b2, float step_size, float bc2_sqrt, float eps) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pa = reinterpret_cast<float*>(&pp);
+        const float* ga = reinterpret_cast<const float*>(&gg);
+        float* ma = reinterpret_cast<float*>(&mm);
+        float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pa[k] = pa[k] * decay;
+            ma[k] = ma[k] + one_m_b1 * (ga[k] - ma[k]);
+            va[k] = va[k] * b2 + one_m_b2 * ga[k] * ga[k];
+            const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
+            pa[k] = pa[k] - step_size * (ma[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+}  // namespace cf

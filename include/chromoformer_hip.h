@@ -1,0 +1,150 @@
+/*
+ * chromoformer_hip.h  --  C ABI of libchromoformer_hip.so (MI355X / gfx950).
+ *
+ * The reference (dohlee/chromoformer) has no native boundary: its hot path is the
+ * Python call  model(promoter_feats, promoter_pad_masks, pcre_feats, pcre_pad_masks,
+ * interaction_masks, interaction_freq)  ->  loss.backward()  ->  optimizer.step()
+ * (chromoformer/train.py:182-196, chromoformer/net.py:332-380).  This header is the
+ * boundary a binding for that path uses: plain pointers and sizes, no torch types.
+ * Every entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers unless a comment says "host";
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
+ *     never allocates (workspace is sized in cf_create for cfg.max_batch genes);
+ *   - return value 0 = ok, negative = error; cf_last_error() gives the message;
+ *   - a handle is thread-compatible (one thread at a time), handles are independent.
+ */
+#ifndef CHROMOFORMER_HIP_H
+#define CHROMOFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_MAX_RES 3
+#define CF_ABI_VERSION 1
+
+/* Model / problem description.  Mirrors the constructor arguments of
+ * ChromoformerBase (net.py:273-299) and the data-processing keys of
+ * configs/default.yaml:9-12 (i_max, w_max / binsizes -> n_bins). */
+typedef struct cf_config {
+    int n_feats;            /* histone marks per bin (7)                          net.py:276  */
+    int d_emb;              /* 128                                                net.py:277  */
+    int d_head;             /* 128                                                net.py:278  */
+    int n_out;              /* 2 = classifier, 1 = regressor                      net.py:329,427 */
+    int n_res;              /* number of resolutions (3)                          net.py:297  */
+    int binsizes[CF_MAX_RES];   /* e.g. 2000, 500, 100 (only used for names)               */
+    int n_bins[CF_MAX_RES];     /* L_b = w_max / binsize, e.g. 20, 80, 400    data.py:140  */
+    int i_max;              /* pCRE slots per gene (8)                            data.py:63  */
+    int embed_layers, embed_heads, embed_dmodel, embed_dff;      /* net.py:279-284 */
+    int pair_layers, pair_heads, pair_dmodel, pair_dff;          /* net.py:285-290 */
+    int reg_layers, reg_heads, reg_dmodel, reg_dff;              /* net.py:291-296 */
+    int max_batch;          /* largest B a call will pass                                     */
+} cf_config;
+
+/* One entry of the parameter table, in the reference's state_dict() order
+ * (net.py:311-330).  `offset` indexes the flat fp32 parameter buffer; the
+ * same offset addresses the gradient and the two AdamW moment buffers.  Tensors that
+ * never receive a gradient in the reference (w_bias, Embedding/Pairwise gamma_f,
+ * Pairwise ln; train.py:157 skips them) have trainable = 0 and live after
+ * cf_layout.n_active so that optimiser and all-reduce run on one contiguous range. */
+typedef struct cf_param_desc {
+    char name[120];
+    int ndim;
+    int shape[2];
+    long long offset;       /* in floats */
+    long long numel;
+    int trainable;
+} cf_param_desc;
+
+typedef struct cf_layout {
+    int n_tensors;
+    long long n_total;      /* floats in the flat buffer (incl. alignment padding)      */
+    long long n_active;     /* floats [0, n_active) hold every trainable tensor          */
+    long long n_elems;      /* sum of numel (5,342,672 for the default config)           */
+} cf_layout;
+
+/* One batch, reference layout (net.py:332-340; produced by data.py:124-212).
+ * Masks are the reference's bool tensors viewed as bytes (non-zero = masked).  Only
+ * the centre query row of the two pad masks is ever consumed, so
+ * they are passed as "row pointers": element (sequence n, key bin j) is read at
+ *     mask[n * stride + j].
+ * For the reference's [B,1,1,L,L] / [B,S,1,L,L] tensors pass  ptr + (L/2)*L  and
+ * stride = L*L (zero-copy); a compact [B(,S),L] row array uses stride = L. */
+typedef struct cf_batch {
+    int B;
+    const float*   promoter_feats[CF_MAX_RES];      /* [B,1,L,F]  fp32                 */
+    const float*   pcre_feats[CF_MAX_RES];          /* [B,S,L,F]  fp32                 */
+    const uint8_t* promoter_mask_row[CF_MAX_RES];   /* see above; n = gene            */
+    long long      promoter_mask_stride[CF_MAX_RES];
+    const uint8_t* pcre_mask_row[CF_MAX_RES];       /* n = gene * S + slot            */
+    long long      pcre_mask_stride[CF_MAX_RES];
+    const uint8_t* interaction_mask[CF_MAX_RES];    /* [B,1,T,T]  T = i_max + 1       */
+    const float*   interaction_freq;                /* [B,T,T]                        */
+} cf_batch;
+
+typedef struct cf_handle cf_handle;
+
+/* ---- host-only helpers (no GPU needed) ------------------------------------------ */
+int         cf_abi_version(void);
+const char* cf_last_error(void);
+/* Parameter table for a config: fills `layout`, writes up to `cap` entries into `table`
+ * (may be NULL to query the count).  Replaces walking model.state_dict(). */
+int cf_param_layout(const cf_config* cfg, cf_layout* layout, cf_param_desc* table, int cap);
+
+/* ---- lifetime --------------------------------------------------------------------- */
+/* Replaces Model(...).cuda() (train.py:142-154): allocates the workspace for
+ * cfg.max_batch genes and the positional tables (net.py:23-29) which the caller supplies
+ * from host memory: pe[r] is float[n_bins[r] * d_emb], row-major, same values the
+ * reference adds at net.py:47-53 / :124-130. */
+int  cf_create(const cf_config* cfg, const float* const* pe_host, cf_handle** out);
+void cf_destroy(cf_handle* h);
+/* Flat fp32 buffers owned by the caller (cf_layout.n_total floats each).  grads / m / v
+ * may be NULL for inference-only use.  Replaces model.parameters() / optimizer state. */
+int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg, float* exp_avg_sq);
+
+/* ---- hot path ------------------------------------------------------------------- */
+/* ChromoformerBase.forward (net.py:332-380).  logits: [B, n_out].  With save_for_backward
+ * = 0 the call is inference only. */
+int cf_forward(cf_handle* h, const cf_batch* batch, float* logits, int save_for_backward, void* stream);
+/* criterion(out, label) + loss.backward() (train.py:156, 193-195).  labels: int64 [B]
+ * (n_out = 2, CrossEntropyLoss) or float [B] (n_out = 1, MSELoss).  `loss_scale`
+ * multiplies the mean-over-B loss gradient (1.0 single GPU; 1/world for an all-reduce SUM).
+ * Writes the scalar loss to loss_out (device, 1 float) and every trainable gradient into
+ * the bound grads buffer (overwrites; nothing accumulates across calls).  Must follow a
+ * cf_forward(..., save_for_backward = 1) on the same batch. */
+int cf_backward(cf_handle* h, const cf_batch* batch, const void* labels, float loss_scale,
+                float* loss_out, void* stream);
+/* Same, but from a caller-supplied d(loss)/d(logits) [B, n_out]. */
+int cf_backward_from(cf_handle* h, const cf_batch* batch, const float* dlogits, void* stream);
+/* torch.optim.AdamW.step (train.py:157, 196): decoupled weight decay, bias correction
+ * from `step` (1-based), over [0, n_active). */
+int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  long long step, void* stream);
+
+/* ---- introspection (tests / profiling) -------------------------------------------- */
+/* Copies a named workspace buffer (e.g. "E0.qt", "dP2.1.xbar") to dst (device);
+ * *n_floats receives its size; dst may be NULL to query. */
+int cf_debug_copy(cf_handle* h, const char* name, float* dst, long long* n_floats, void* stream);
+/* Names of all workspace buffers, '\n' separated (host string owned by the handle). */
+const char* cf_debug_names(cf_handle* h);
+/* Number of kernels one forward / backward / optimiser call launches. */
+int cf_launch_counts(cf_handle* h, int* fwd, int* bwd, int* opt);
+
+/* ---- standalone operators (same kernels, for unit tests and micro-benchmarks) ------ */
+/* C[M,N] = A[M,K] . W[N,K]^T (+ bias[N]) (relu)      -- the Linear of modules.py:20-24 */
+int cf_op_linear(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                 int relu, void* stream);
+/* dW[N,K] = dY[M,N]^T . X[M,K]                       -- its weight gradient           */
+int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, int N, int K, void* stream);
+/* dX[M,K] = dY[M,N] . W[N,K]                         -- its input gradient            */
+int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHROMOFORMER_HIP_H */

@@ -1,0 +1,85 @@
+"""Host-only checks of the C-ABI library: it loads, exports every symbol of
+include/chromoformer_hip.h, and its parameter table equals the reference's state_dict
+layout (golden G3).  No compute call is made (there is no GPU here)."""
+import json
+import os
+import re
+
+import torch
+
+from chromoformer_amd import _lib
+from tests.helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "chromoformer_hip.h")).read()
+    declared = set(re.findall(r"\b(cf_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.cf_abi_version() == 1
+
+
+def _cfg(n_out=2):
+    return _lib.make_config(7, 128, 128, n_out, [2000, 500, 100], [20, 80, 400], 8,
+                            {"n_layers": 1, "n_heads": 2, "d_model": 128, "d_ff": 128},
+                            {"n_layers": 2, "n_heads": 2, "d_model": 128, "d_ff": 256},
+                            {"n_layers": 6, "n_heads": 8, "d_model": 256, "d_ff": 256}, 64)
+
+
+def test_param_table_matches_reference_state_dict():
+    g = json.load(open(os.path.join(GOLDEN, "state_dict.json")))
+    for n_out, key in ((2, "seed42_clf"), (1, "seed42_reg")):
+        lay, tab = _lib.param_layout(_cfg(n_out))
+        assert [t["name"] for t in tab] == g[key]["keys"]
+        assert [list(t["shape"]) for t in tab] == g[key]["shapes"]
+        assert lay.n_tensors == 370
+        assert sum(not t["trainable"] for t in tab) == 36
+        assert sum(t["numel"] for t in tab if not t["trainable"]) == 1086
+        # trainable tensors first, contiguous, 16-byte aligned, non-overlapping
+        spans = sorted((t["offset"], t["offset"] + t["numel"], t["trainable"]) for t in tab)
+        for (a0, a1, _), (b0, _, _) in zip(spans, spans[1:]):
+            assert a1 <= b0
+        assert all(t["offset"] % 4 == 0 for t in tab)
+        assert max(t["offset"] + t["numel"] for t in tab if t["trainable"]) <= lay.n_active
+        assert min(t["offset"] for t in tab if not t["trainable"]) >= lay.n_active
+    assert lay.n_elems + 129 == g["n_params"] == 5342672
+
+
+def test_unsupported_configs_are_rejected_loudly():
+    import ctypes as C
+    cfg = _cfg()
+    cfg.embed_layers = 2
+    lay = _lib.cf_layout()
+    assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
+    assert b"embed.n_layers" in _lib.lib().cf_last_error()
+
+
+def test_model_state_dict_and_seeded_init_match_golden():
+    from chromoformer_amd import ChromoformerClassifier, ChromoformerRegressor
+    from tests.helpers import checksum
+    import numpy as np
+    g = json.load(open(os.path.join(GOLDEN, "state_dict.json")))
+    for cls, tag in ((ChromoformerClassifier, "clf"), (ChromoformerRegressor, "reg")):
+        for seed in (42, 123):
+            ref = g["seed%d_%s" % (seed, tag)]
+            sd = cls(seed=seed).state_dict()
+            assert list(sd.keys()) == ref["keys"]
+            got = np.array([checksum(v) for v in sd.values()])
+            np.testing.assert_allclose(got, np.array(ref["checksums"]), rtol=1e-12, atol=1e-12)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from chromoformer_amd import ChromoformerClassifier
+    if torch.cuda.is_available():
+        return
+    m = ChromoformerClassifier()
+    try:
+        m.cuda()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("expected a RuntimeError without a GPU")
