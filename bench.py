@@ -1,0 +1,133 @@
+"""Headline benchmark: genes/s of Chromoformer training (forward + loss + backward + gradient
+all-reduce + AdamW), default config, bsz = 64 genes per GPU, synthetic 7-mark inputs resident
+in HBM (BASELINE.json: configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for how `roofline` is defined).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+BSZ = 64
+
+
+def cpu_baseline(budget_s=20.0):
+    """The CPU oracle (dense PyTorch restatement of the reference) timed on this host's cores:
+    forward + backward + AdamW on a bounded sample of the same synthetic workload."""
+    from oracle import chromoformer_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = orc.init_params(None, 42, False)
+    for t in P.values():
+        t.requires_grad_(True)
+    opt = orc.make_optimizer(P, 3e-5)
+    warm = orc.synthetic_batch(4, seed=1, regime="dense")
+    orc.train_step(P, opt, warm)
+    b = 16
+    batch = orc.synthetic_batch(b, seed=1234, regime="dense")
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.train_step(P, opt, batch)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    cpu = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n * b / el, 3), "unit": "genes/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps (fwd+bwd+AdamW) of %d genes, dense synthetic default config, %d threads, %s" % (n, b, cores, cpu)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--regime", default="dense", choices=["dense", "realistic"])
+    ap.add_argument("--roofline-kernel", default="k_wgrad")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+        pg = torch.distributed.group.WORLD
+
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    from oracle import chromoformer_oracle as orc  # synthetic workload generator only (inputs, not compute)
+
+    model = ChromoformerClassifier(seed=42, max_batch=BSZ).cuda(local)
+    batch = orc.synthetic_batch(BSZ, seed=1234 + rank, regime=args.regime)
+    trainer = Trainer(model, lr=3e-5, world_size=world, process_group=pg, use_graph=not args.no_graph)
+    slot = trainer.stage(batch)            # inputs resident in HBM before the timed region
+
+    for _ in range(args.warmup):
+        trainer.step(slot)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    trainer.timing(args.roofline_kernel)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(slot)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = t.item()
+    kernel_ms, kernel_n = trainer.timing_read()
+
+    if rank == 0:
+        ms = 1e3 * el / args.steps
+        value = BSZ * world * args.steps / el
+        roof = trainer.roofline(args.roofline_kernel, kernel_ms, kernel_n, BSZ)
+        out = {
+            "metric": "genes/sec training (bsz=64, default config)", "value": round(value, 1), "unit": "genes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "default config (d_emb 128, i_max 8, binsizes 2000/500/100 -> L 20/80/400), bsz 64 genes per GPU, "
+                                   "%s synthetic 7-mark signals, fwd+loss+bwd+allreduce+AdamW" % args.regime,
+                       "parallelism": "dp%d" % world, "global_batch": BSZ * world, "hip_graph": not args.no_graph,
+                       "launches_per_step": sum(model.launch_counts())},
+            "roofline": roof,
+            "loss": round(float(trainer.last_loss()), 6),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,14 @@ SYMBOLS = {
     "cf_bind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_forward": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_int, C.c_void_p]),
     "cf_backward": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "cf_backward_chain": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "cf_backward_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cf_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "cf_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_timing_select": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cf_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "cf_wgrad_flops": (C.c_double, [C.c_void_p, C.c_int]),
     "cf_backward_from": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
     "cf_adamw_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p]),
     "cf_debug_copy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),

@@ -213,8 +213,29 @@ struct cf_handle {
     int n_wg = 0;
     CsTile* cs_tiles = nullptr;
     int n_cs = 0;
+    LpJob* lp_jobs = nullptr;
+    int n_lp = 0;
+    float *lp_part_e[kMaxRes], *lp_part_p[kMaxRes];
     int last_fwd_B = 0;
     int n_fwd = 0, n_bwd = 0, n_opt = 0;
+    double wg_flops_per_gene = 0.0;     // 2*M*N*K summed over the weight-gradient jobs, per gene
+    // optional HIP-event timing of one of the eagerly launched kernels
+    std::string timed;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    // captured launch sequences
+    std::vector<hipGraphExec_t> graphs;
+    bool capturing = false;
+
+    void time_mark(const char* name, hipStream_t st) {
+        if (timed.empty() || capturing || timed != name) return;
+        if (ev_used == ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            ev.push_back(e);
+        }
+        (void)hipEventRecord(ev[ev_used++], st);
+    }
 
     float* ws_get(const std::string& name, size_t n) {
         n = (n + 3) / 4 * 4;
@@ -270,6 +291,8 @@ static void plan_workspace(cf_handle* h) {
         h->pe[r] = h->ws_get(fmt("pe%d", r), (size_t)L * kD);
         h->pet[r] = h->ws_get(fmt("pet%d", r), (size_t)L * kD);
         h->featc[r] = h->ws_get(fmt("E%d.featc", r), NE * 8);
+        h->lp_part_e[r] = h->ws_get(fmt("dE%d.lp_partial", r), ((MB + kLpGenes - 1) / kLpGenes) * kD * 8);
+        h->lp_part_p[r] = h->ws_get(fmt("dP%d.lp_partial", r), ((MB + kLpGenes - 1) / kLpGenes) * kD * 8);
         h->ex0[r] = h->ws_get(fmt("E%d.x0", r), NE * kD);
         plan_centre(h, h->E[r], fmt("E%d.", r), NE, L, c.embed_dff, false, false);
         h->edout[r] = h->ws_get(fmt("dE%d.out", r), NE * kD);
@@ -387,22 +410,22 @@ static int build_tables(cf_handle* h) {
     const int S = c.i_max, T = S + 1, F = c.n_feats;
     std::vector<WgTile> wg;
     std::vector<CsTile> cs;
+    std::vector<LpJob> lpj;
     for (int r = 0; r < c.n_res; ++r) {
         const int bs = c.binsizes[r];
         {   // Embedding
             const std::string pre = fmt("embed.%d.", bs), lp = pre + "transformer.layers.0.";
             const CentreBuf& b = h->E[r];
-            WgJob j;
+            LpJob j;
             memset(&j, 0, sizeof j);
             j.seg[0] = WgSeg{h->edx0[r], h->featc[r], kD, 8, 1};
             j.seg[1] = WgSeg{b.dxbar, b.w, kD, 8, 2};
             j.seg[2] = WgSeg{b.qt, b.du, kD, 8, 2};
             j.nseg = 3;
-            j.C = h->G_(pre + "lin_proj.weight");
-            j.ldc = F;
-            j.Nn = kD;
-            j.Kk = F;
-            push_wg(wg, j);
+            j.partial = h->lp_part_e[r];
+            j.F = F;
+            lpj.push_back(j);
+            push_cs(cs, j.partial, kD * F, kD * F, 1, kLpGenes, h->G_(pre + "lin_proj.weight"));
             float* gatt = h->G_(lp + "self_att.att.weight");
             push_centre_wg(wg, h, b, h->ex0[r], kD, 1, c.embed_dff, gatt, gatt + (size_t)kD * kD, gatt + (size_t)2 * kD * kD,
                            lp + "self_att.", lp + "ff.");
@@ -411,22 +434,19 @@ static int build_tables(cf_handle* h) {
         {   // Pairwise
             const std::string pre = fmt("pairwise_interaction.%d.", bs);
             push_wg(wg, wg1(h->dxp0[r], kD, h->Rx[r][0], T * kD, 1, h->G_(pre + "lin_proj_p.weight"), kD, kD, kD));
-            WgJob j;
+            LpJob j;
             memset(&j, 0, sizeof j);
-            // lin_proj_pcre collects two terms per layer; at most 4 segments per tile, so
-            // layers are grouped in pairs and the second group would need accumulation:
-            // with pair_layers <= 2 a single job suffices (checked below).
+            // lin_proj_pcre collects two terms per layer (pair_layers <= 2 -> <= 4 segments)
             int ns = 0;
-            for (int l = 0; l < c.pair_layers && ns + 2 <= 4; ++l) {
+            for (int l = 0; l < c.pair_layers; ++l) {
                 j.seg[ns++] = WgSeg{h->P[r][l].dxbar, h->P[r][l].w, kD, 8, 2 * S};
                 j.seg[ns++] = WgSeg{h->P[r][l].qt, h->P[r][l].du, kD, 8, 2 * S};
             }
             j.nseg = ns;
-            j.C = h->G_(pre + "lin_proj_pcre.weight");
-            j.ldc = F;
-            j.Nn = kD;
-            j.Kk = F;
-            push_wg(wg, j);
+            j.partial = h->lp_part_p[r];
+            j.F = F;
+            lpj.push_back(j);
+            push_cs(cs, j.partial, kD * F, kD * F, 1, kLpGenes, h->G_(pre + "lin_proj_pcre.weight"));
             for (int l = 0; l < c.pair_layers; ++l) {
                 const std::string lp = pre + fmt("transformer.layers.%d.", l);
                 const CentreBuf& b = h->P[r][l];
@@ -454,6 +474,15 @@ static int build_tables(cf_handle* h) {
     push_cs(cs, h->dh1, kD, kD, 1, 1, h->G_("fc_head.0.bias"));
     push_cs(cs, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
 
+    if (h->lp_jobs) (void)hipFree(h->lp_jobs);
+    h->n_lp = (int)lpj.size();
+    HIP_TRY(hipMalloc(&h->lp_jobs, lpj.size() * sizeof(LpJob)));
+    HIP_TRY(hipMemcpy(h->lp_jobs, lpj.data(), lpj.size() * sizeof(LpJob), hipMemcpyHostToDevice));
+    h->wg_flops_per_gene = 0.0;
+    for (const WgTile& t : wg) {
+        if (t.n0 || t.k0) continue;      // count each job once
+        for (int sgi = 0; sgi < t.nseg; ++sgi) h->wg_flops_per_gene += 2.0 * t.seg[sgi].rows_per_gene * (double)t.Nn * t.Kk;
+    }
     if (h->wg_tiles) (void)hipFree(h->wg_tiles);
     if (h->cs_tiles) (void)hipFree(h->cs_tiles);
     h->n_wg = (int)wg.size();
@@ -534,7 +563,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     // dynamic LDS of the attention kernels
     const cf_config& c = h->cfg;
     h->n_fwd = 1 + 3 + 1 + 3 * c.pair_layers + 3 * c.reg_layers + 3;
-    h->n_bwd = 4 + 3 * c.reg_layers + 3 * c.pair_layers + 2 + 3 + 2;
+    h->n_bwd = 4 + 3 * c.reg_layers + 3 * c.pair_layers + 2 + 3 + 3;
     h->n_opt = 1;
     *out = h;
     return 0;
@@ -545,6 +574,9 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->wg_tiles) (void)hipFree(h->wg_tiles);
     if (h->cs_tiles) (void)hipFree(h->cs_tiles);
+    if (h->lp_jobs) (void)hipFree(h->lp_jobs);
+    for (hipGraphExec_t g : h->graphs) (void)hipGraphExecDestroy(g);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -886,7 +918,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         a.N = B;
         a.K = kD;
         a.Ncols = 3 * kD;
-        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(B), 3, 1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(B), 3 * kD / 32, 1), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_dgrad<head>");
         HeadScatterArgs sc;
         sc.dhin = h->dhin;
@@ -949,7 +981,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         LAUNCH_CHECK("k_post_bwd<reg>");
         hipLaunchKernelGGL((k_attr<true>), dim3(B, nres), dim3(256), attr_smem(T, true), st, at);
         LAUNCH_CHECK("k_attr<bwd>");
-        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(NR), 1, nres), dim3(256), 0, st, dg);
+        hipLaunchKernelGGL((k_dgrad<kRW / 64>), dim3(tiles_of(NR), kD / 32, nres), dim3(256), 0, st, dg);
         LAUNCH_CHECK("k_dgrad<qkvg>");
     }
     // one centre-row layer backward: post chain -> attention -> query chain
@@ -1052,7 +1084,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         a.N = NE;
         a.K = kD;
         a.Ncols = kD;
-        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(NE), 1, nres), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_dgrad<lin_proj_p>");
     }
     {   // Embedding
@@ -1067,10 +1099,20 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
                        c.embed_dff))
             return -1;
     }
-    // deferred weight / bias gradients
+    return 0;
+}
+
+// deferred weight / bias gradients: two launches over the tile tables
+static int reduce_impl(cf_handle* h, int B, hipStream_t st) {
+    hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
+    LAUNCH_CHECK("k_wgrad_lp");
+    h->time_mark("k_wgrad", st);
     hipLaunchKernelGGL(k_wgrad, dim3(h->n_wg), dim3(256), 0, st, (const WgTile*)h->wg_tiles, B);
+    h->time_mark("k_wgrad", st);
     LAUNCH_CHECK("k_wgrad");
+    h->time_mark("k_colsum", st);
     hipLaunchKernelGGL(k_colsum, dim3(h->n_cs), dim3(256), 0, st, (const CsTile*)h->cs_tiles, B);
+    h->time_mark("k_colsum", st);
     LAUNCH_CHECK("k_colsum");
     return 0;
 }
@@ -1082,7 +1124,8 @@ static int check_bwd(cf_handle* h, const cf_batch* bt) {
     return 0;
 }
 
-extern "C" int cf_backward(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out, void* stream) {
+extern "C" int cf_backward_chain(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out,
+                                 void* stream) {
     if (check_bwd(h, bt)) return -1;
     if (!labels) return fail("cf_backward: labels is null");
     hipStream_t st = (hipStream_t)stream;
@@ -1094,13 +1137,82 @@ extern "C" int cf_backward(cf_handle* h, const cf_batch* bt, const void* labels,
     return 0;
 }
 
+extern "C" int cf_backward_reduce(cf_handle* h, int B, void* stream) {
+    if (!h || !h->grads) return fail("cf_backward_reduce: no gradient buffer bound");
+    if (B < 1 || B > h->cfg.max_batch) return fail("cf_backward_reduce: bad batch size %d", B);
+    return reduce_impl(h, B, (hipStream_t)stream);
+}
+
+extern "C" int cf_backward(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out, void* stream) {
+    if (cf_backward_chain(h, bt, labels, loss_scale, loss_out, stream)) return -1;
+    return reduce_impl(h, bt->B, (hipStream_t)stream);
+}
+
 extern "C" int cf_backward_from(cf_handle* h, const cf_batch* bt, const float* dlogits, void* stream) {
     if (check_bwd(h, bt)) return -1;
     if (!dlogits) return fail("cf_backward_from: dlogits is null");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(h->dlogits, dlogits, (size_t)bt->B * h->cfg.n_out * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return backward_impl(h, bt, st);
+    if (backward_impl(h, bt, st)) return -1;
+    return reduce_impl(h, bt->B, st);
 }
+
+// ------------------------------------------------------------------------------------
+// hipGraph capture of launch sequences (the per-step sequence is static)
+// ------------------------------------------------------------------------------------
+extern "C" int cf_capture_begin(cf_handle* h, void* stream) {
+    if (!h) return fail("null handle");
+    if (h->capturing) return fail("cf_capture_begin: already capturing");
+    HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+    h->capturing = true;
+    return 0;
+}
+extern "C" int cf_capture_end(cf_handle* h, void* stream, int* graph_id) {
+    if (!h || !graph_id) return fail("null argument");
+    if (!h->capturing) return fail("cf_capture_end: not capturing");
+    h->capturing = false;
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    h->graphs.push_back(ge);
+    *graph_id = (int)h->graphs.size() - 1;
+    return 0;
+}
+extern "C" int cf_graph_launch(cf_handle* h, int graph_id, void* stream) {
+    if (!h || graph_id < 0 || graph_id >= (int)h->graphs.size()) return fail("cf_graph_launch: bad graph id %d", graph_id);
+    HIP_TRY(hipGraphLaunch(h->graphs[graph_id], (hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// HIP-event timing of one eagerly launched kernel ("k_wgrad", "k_colsum", "k_adamw")
+// ------------------------------------------------------------------------------------
+extern "C" int cf_timing_select(cf_handle* h, const char* kernel) {
+    if (!h) return fail("null handle");
+    h->timed = kernel ? kernel : "";
+    h->ev_used = 0;
+    return 0;
+}
+extern "C" int cf_timing_read(cf_handle* h, float* total_ms, int* count) {
+    if (!h || !total_ms || !count) return fail("null argument");
+    float tot = 0.f;
+    int n = 0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        tot += ms;
+        ++n;
+    }
+    h->ev_used = 0;
+    *total_ms = tot;
+    *count = n;
+    return 0;
+}
+extern "C" double cf_wgrad_flops(cf_handle* h, int B) { return h ? h->wg_flops_per_gene * B : 0.0; }
 
 // ------------------------------------------------------------------------------------
 // optimiser
@@ -1116,8 +1228,10 @@ extern "C" int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, f
     const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
     const long long n4 = h->lay.n_active / 4;
     const int grid = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
+    h->time_mark("k_adamw", (hipStream_t)stream);
     hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params, (const float*)h->grads, h->m, h->v, n4,
                        decay, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps);
+    h->time_mark("k_adamw", (hipStream_t)stream);
     LAUNCH_CHECK("k_adamw");
     return 0;
 }
@@ -1147,7 +1261,7 @@ extern "C" int cf_launch_counts(cf_handle* h, int* fwd, int* bwd, int* opt) {
 // standalone operators
 // ------------------------------------------------------------------------------------
 extern "C" int cf_op_linear(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int relu, void* stream) {
-    if (K % 16 || N % 32) return fail("cf_op_linear: K %% 16 == 0 and N %% 32 == 0 required");
+    if (K % 128 || N % 32) return fail("cf_op_linear: K %% 128 == 0 and N %% 32 == 0 required");
     LinArgs a;
     memset(&a, 0, sizeof a);
     a.x[0] = A;
@@ -1166,7 +1280,7 @@ extern "C" int cf_op_linear(const float* A, const float* W, const float* bias, f
     return 0;
 }
 extern "C" int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream) {
-    if (N % 16 || K % 32) return fail("cf_op_dgrad: N %% 16 == 0 and K %% 32 == 0 required");
+    if ((N != 128 && N != 256 && N != 1024) || K % 32) return fail("cf_op_dgrad: N in {128, 256, 1024} and K %% 32 == 0 required");
     DgradArgs a;
     memset(&a, 0, sizeof a);
     a.dy[0] = dY;
@@ -1179,11 +1293,15 @@ extern "C" int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, in
     a.N = M;
     a.K = N;
     a.Ncols = K;
-    hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(M), (K + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid(tiles_of(M), K / 32, 1);
+    if (N == 128) hipLaunchKernelGGL((k_dgrad<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (N == 256) hipLaunchKernelGGL((k_dgrad<4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_dgrad<16>), grid, dim3(256), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK("cf_op_dgrad");
     return 0;
 }
 extern "C" int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, int N, int K, void* stream) {
+    if (K % 4) return fail("cf_op_wgrad: K %% 4 == 0 required");
     std::vector<WgTile> tiles;
     push_wg(tiles, wg1(dY, N, X, K, M, dW, K, N, K));
     WgTile* d = nullptr;

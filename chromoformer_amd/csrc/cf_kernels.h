@@ -60,57 +60,95 @@ __device__ __forceinline__ float group16_sum(float v) {
 // MFMA tile products.  A is a 16-row tile in LDS (row stride lda floats, 16-byte aligned
 // rows).  Lane l = (r = l & 15, q = l >> 4).  The 16x16x4 instruction wants
 // A[i = r][k = q] and B[k = q][j = r]; the reduction index is assigned to lanes in
-// blocks of four (k = k0 + 4q + i for the i-th of four MFMAs) so that both operands are
-// read 16 bytes at a time.  Result fragment: acc[t][i] = C[row 4q + i][col t*16 + r].
+// blocks of four (k = k0 + 4q + i for the i-th of four MFMAs) so that the A operand is
+// read 16 bytes at a time.  Result fragment: acc[t][i] = C[row 4q + i][col(t, r)].
+//
+// The weights are not shared between the waves of a workgroup (each wave owns its own
+// output columns), so they go straight from L2 into registers: a wave first issues ALL
+// loads of its B fragments for the product (up to 128 VGPRs, fully unrolled, nothing
+// waits), typically before the barrier / LayerNorm that precedes the product, and then
+// runs the MFMAs as the data lands.  With ~100 resident workgroups on 256 CUs this
+// memory-level parallelism is what hides the L2 latency.
 // ---------------------------------------------------------------------------------------
 
-// C[16, NT*16] += A[16, K] . W^T,  W row-major [n][K] (an nn.Linear weight); W points at
-// the first output column of this wave.
-template <int NT>
-__device__ __forceinline__ void mm_nt(const float* As, int lda, const float* __restrict__ W, int ldw, int K,
-                                      f32x4 (&acc)[NT]) {
+// "NT" fragments: W row-major [n][ldw] (an nn.Linear weight), C = A . W^T.
+// Column map: col(t, r) = t*16 + r (contiguous 16-column tiles).
+template <int NT, int KS>
+struct FragNT {
+    float4 b[KS][NT];
+};
+template <int NT, int KS>
+__device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __restrict__ W, int ldw) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* wp = W + (size_t)r * ldw + q * 4;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f.b[ks][t] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * ldw + ks * 16);
+}
+template <int NT, int KS>
+__device__ __forceinline__ void frag_mma_nt(const FragNT<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
-    const float* wp = W + (size_t)r * ldw + q * 4;
-#pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const float4 a = *reinterpret_cast<const float4*>(ap + k0);
-        float4 b[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * ldw + k0);
+    for (int ks = 0; ks < KS; ++ks) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + ks * 16);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            acc[t] = mfma4(a.x, b[t].x, acc[t]);
-            acc[t] = mfma4(a.y, b[t].y, acc[t]);
-            acc[t] = mfma4(a.z, b[t].z, acc[t]);
-            acc[t] = mfma4(a.w, b[t].w, acc[t]);
+            acc[t] = mfma4(a.x, f.b[ks][t].x, acc[t]);
+            acc[t] = mfma4(a.y, f.b[ks][t].y, acc[t]);
+            acc[t] = mfma4(a.z, f.b[ks][t].z, acc[t]);
+            acc[t] = mfma4(a.w, f.b[ks][t].w, acc[t]);
         }
     }
 }
+__device__ __forceinline__ int col_nt(int t, int r) { return t * 16 + r; }
 
-// C[16, NT*16] += A[16, K] . Bm,  Bm row-major [k][ldb]; Bm points at the first output
-// column of this wave.
+// "NN" fragments: Bm row-major [k][ldb], C = A . Bm.  A lane reads NT consecutive floats
+// of one k-row, which feed NT different tiles, so tile t holds the STRIDED columns
+// col(t, r) = NT*r + t of the wave's 16*NT-column range (one 8/16-byte load per NT MFMAs).
 template <int NT>
-__device__ __forceinline__ void mm_nn(const float* As, int lda, const float* __restrict__ Bm, int ldb, int K,
-                                      f32x4 (&acc)[NT]) {
+struct VecN;
+template <>
+struct VecN<2> {
+    typedef float2 type;
+};
+template <>
+struct VecN<4> {
+    typedef float4 type;
+};
+template <int NT, int KS>
+struct FragNN {
+    typename VecN<NT>::type b[KS][4];
+};
+template <int NT, int KS>
+__device__ __forceinline__ void frag_load_nn(FragNN<NT, KS>& f, const float* __restrict__ Bm, int ldb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* bp = Bm + (size_t)(q * 4) * ldb + NT * r;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            f.b[ks][i] = *reinterpret_cast<const typename VecN<NT>::type*>(bp + (size_t)(ks * 16 + i) * ldb);
+}
+template <int NT, int KS>
+__device__ __forceinline__ void frag_mma_nn(const FragNN<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
-    const float* bp = Bm + (size_t)(q * 4) * ldb + r;
-#pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const float4 a = *reinterpret_cast<const float4*>(ap + k0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + ks * 16);
         const float av[4] = {a.x, a.y, a.z, a.w};
-        float b[4][NT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const float* bv = reinterpret_cast<const float*>(&f.b[ks][i]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[i][t] = bp[(size_t)(k0 + i) * ldb + t * 16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma4(av[i], b[i][t], acc[t]);
+            for (int t = 0; t < NT; ++t) acc[t] = mfma4(av[i], bv[t], acc[t]);
+        }
     }
 }
+template <int NT>
+__device__ __forceinline__ int col_nn(int t, int r) { return NT * r + t; }
 
 template <int NT>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NT]) {
@@ -242,6 +280,11 @@ __global__ __launch_bounds__(256) void k_qchain_fwd(QChainArgs a) {
     __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
     const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int h = w >> 1, e0 = (w & 1) * 64;
+    FragNT<2, 8> fq;
+    frag_load_nt(fq, a.wq[r] + (size_t)(w * 32) * kD, kD);
+    FragNN<4, 4> fk;
+    frag_load_nn(fk, a.wk[r] + (size_t)(h * 64) * kD + e0, kD);
     load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, a.N, a.xmap);
     __syncthreads();
     if (a.xcopy[r])
@@ -250,29 +293,28 @@ __global__ __launch_bounds__(256) void k_qchain_fwd(QChainArgs a) {
     {
         f32x4 acc[2];
         zero_acc(acc);
-        mm_nt<2>(&xs[0][0], kD + 4, a.wq[r] + (size_t)(w * 32) * kD, kD, kD, acc);
+        frag_mma_nt(fq, &xs[0][0], kD + 4, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
                 qs[row][col] = acc[t][i];
                 if (row0 + row < a.N) a.q[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
             }
     }
     __syncthreads();
     {
-        const int h = w >> 1, e0 = (w & 1) * 64;
         f32x4 acc[4];
         zero_acc(acc);
-        mm_nn<4>(&qs[0][h * 64], kD + 4, a.wk[r] + (size_t)(h * 64) * kD + e0, kD, 64, acc);
+        frag_mma_nn(fk, &qs[0][h * 64], kD + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i;
-                if (row0 + row < a.N) a.qt[r][(size_t)(row0 + row) * 256 + h * kD + e0 + t * 16 + lr] = acc[t][i];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i;
+            if (row0 + row < a.N)
+                *reinterpret_cast<float4*>(a.qt[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + 4 * lr) =
+                    make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+        }
     }
 }
 
@@ -290,18 +332,22 @@ __global__ __launch_bounds__(256) void k_qchain_bwd(QBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
     const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int h = w >> 1;
+    FragNT<2, 8> fk;
+    frag_load_nt(fk, a.wk[r] + (size_t)(w * 32) * kD, kD);
+    FragNN<2, 8> fq;
+    frag_load_nn(fq, a.wq[r] + w * 32, kD);
     load_tile(&ds[0][0], 260, a.dqt[r], 256, 256, row0, a.N, identity_map());
     __syncthreads();
     {   // dq[:, h*64+d] = sum_e dqt[:, h, e] Wk[h*64+d, e]
-        const int h = w >> 1;
         f32x4 acc[2];
         zero_acc(acc);
-        mm_nt<2>(&ds[0][h * kD], 260, a.wk[r] + (size_t)(w * 32) * kD, kD, kD, acc);
+        frag_mma_nt(fk, &ds[0][h * kD], 260, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
                 qs[row][col] = acc[t][i];
                 if (row0 + row < a.N) a.dq[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
             }
@@ -310,17 +356,16 @@ __global__ __launch_bounds__(256) void k_qchain_bwd(QBwdArgs a) {
     {   // dx = dres + dq Wq
         f32x4 acc[2];
         zero_acc(acc);
-        mm_nn<2>(&qs[0][0], kD + 4, a.wq[r] + w * 32, kD, kD, acc);
+        frag_mma_nn(fq, &qs[0][0], kD + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
-                if (row0 + row < a.N) {
-                    const size_t o = (size_t)(row0 + row) * kD + col;
-                    a.dx[r][o] = acc[t][i] + a.dres[r][o];
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i;
+            if (row0 + row < a.N) {
+                const size_t o = (size_t)(row0 + row) * kD + w * 32 + 2 * lr;
+                const float2 dr = *reinterpret_cast<const float2*>(a.dres[r] + o);
+                *reinterpret_cast<float2*>(a.dx[r] + o) = make_float2(acc[0][i] + dr.x, acc[1][i] + dr.y);
             }
+        }
     }
 }
 
@@ -566,19 +611,23 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
     __shared__ __attribute__((aligned(16))) float hs[kTile][HW + 4];
     const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    FragNT<2, DM / 16> fo;
+    frag_load_nt(fo, a.wo[r] + (size_t)(w * 32) * DM, DM);
     load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, N, a.xmap);
     if (VPROJ) {
+        FragNT<2, 8> fv;
+        frag_load_nt(fv, a.wv[r] + (size_t)(w * 32) * kD, kD);
         load_tile(&hs[0][0], HW + 4, a.ain[r], 256, 256, row0, N, identity_map());
         __syncthreads();
         const int h = w >> 1;
         f32x4 acc[2];
         zero_acc(acc);
-        mm_nt<2>(&hs[0][h * kD], HW + 4, a.wv[r] + (size_t)(w * 32) * kD, kD, kD, acc);
+        frag_mma_nt(fv, &hs[0][h * kD], HW + 4, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
                 as_[row][col] = acc[t][i];
                 if (a.save && row0 + row < N) a.a_out[r][(size_t)(row0 + row) * DM + col] = acc[t][i];
             }
@@ -589,44 +638,48 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
     {   // t1 = x + a Wo^T + bo
         f32x4 acc[2];
         zero_acc(acc);
-        mm_nt<2>(&as_[0][0], DM + 4, a.wo[r] + (size_t)(w * 32) * DM, DM, DM, acc);
+        frag_mma_nt(fo, &as_[0][0], DM + 4, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
                 ts[row][col] = acc[t][i] + a.bo[r][col] + xs[row][col];
             }
     }
+    constexpr int NT1 = DFF / 64;
+    FragNT<NT1, 8> f1;      // issued before the LayerNorm so the L2 latency hides behind it
+    frag_load_nt(f1, a.w1[r] + (size_t)(w * (DFF / 4)) * kD, kD);
     __syncthreads();
     ln_fwd_rows(&ts[0][0], kD + 4, a.g1[r], a.be1[r], row0, N, a.save ? a.xh1[r] : nullptr, a.rs1[r],
                 a.save ? a.y1[r] : nullptr, identity_map());
     __syncthreads();
     {   // hdn = relu(y1 W1^T + b1)
-        constexpr int NT = DFF / 64;
-        f32x4 acc[NT];
+        f32x4 acc[NT1];
         zero_acc(acc);
-        mm_nt<NT>(&ts[0][0], kD + 4, a.w1[r] + (size_t)(w * (DFF / 4)) * kD, kD, kD, acc);
+        frag_mma_nt(f1, &ts[0][0], kD + 4, acc);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT1; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * (DFF / 4) + t * 16 + lr;
+                const int row = lq * 4 + i, col = w * (DFF / 4) + col_nt(t, lr);
                 const float v = fmaxf(acc[t][i] + a.b1[r][col], 0.f);
                 hs[row][col] = v;
                 if (a.save && row0 + row < N) a.hdn[r][(size_t)(row0 + row) * DFF + col] = v;
             }
     }
+    FragNT<2, DFF / 16> f2;
+    frag_load_nt(f2, a.w2[r] + (size_t)(w * 32) * DFF, DFF);
     __syncthreads();
     {   // t2 = y1 + hdn W2^T + b2
         f32x4 acc[2];
         zero_acc(acc);
-        mm_nt<2>(&hs[0][0], HW + 4, a.w2[r] + (size_t)(w * 32) * DFF, DFF, DFF, acc);
+        frag_mma_nt(f2, &hs[0][0], HW + 4, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
+                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
                 xs[row][col] = acc[t][i] + a.b2[r][col] + ts[row][col];
             }
     }
@@ -663,58 +716,65 @@ __host__ __device__ constexpr int post_partial_width(int dff) { return 768 + dff
 template <bool VPROJ, int DM, int DFF>
 __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
     constexpr int WW = (DFF > DM ? DFF : DM);
-    __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1
+    constexpr int NT2 = DFF / 64, NTO = DM / 64;
+    __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1 -> dt1
     __shared__ __attribute__((aligned(16))) float xh[kTile][kD + 4];    // xhat2 -> xhat1
-    __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2 -> dt1
+    __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2
     __shared__ __attribute__((aligned(16))) float wide[kTile][WW + 4];  // dpre1 -> da
     const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     float* part = a.partial[r] + (size_t)blockIdx.x * post_partial_width(DFF);
+    FragNN<NT2, 8> fw2;
+    frag_load_nn(fw2, a.w2[r] + w * (DFF / 4), DFF);
     load_tile(&ds[0][0], kD + 4, a.dout[r], kD, kD, row0, N, a.dmap);
     load_tile(&xh[0][0], kD + 4, a.xh2[r], kD, kD, row0, N, identity_map());
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0);      // d ln2.weight
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128);           // d ln2.bias
-    __syncthreads();
-    // LN2 backward -> dt2  (kept in t2; ds keeps dout*... no longer needed)
     for (int i = threadIdx.x; i < kTile * kD; i += 256) t2[i >> 7][i & 127] = ds[i >> 7][i & 127];
     __syncthreads();
-    ln_bwd_rows(&t2[0][0], kD + 4, &xh[0][0], kD + 4, a.g2[r], a.rs2[r], row0, N, a.dt2[r]);
+    ln_bwd_rows(&t2[0][0], kD + 4, &xh[0][0], kD + 4, a.g2[r], a.rs2[r], row0, N, a.dt2[r]);   // t2 = dt2
+    FragNN<2, DFF / 16> fw1;
+    frag_load_nn(fw1, a.w1[r] + w * 32, kD);
     __syncthreads();
     colsum16(&t2[0][0], kD + 4, nullptr, 0, kD, part + 256);           // d l2.bias
     {   // dpre1 = (dt2 W2) * (hdn > 0)
-        constexpr int NT = DFF / 64;
-        f32x4 acc[NT];
+        f32x4 acc[NT2];
         zero_acc(acc);
-        mm_nn<NT>(&t2[0][0], kD + 4, a.w2[r] + w * (DFF / 4), DFF, kD, acc);
+        frag_mma_nn(fw2, &t2[0][0], kD + 4, acc);
+        typedef typename VecN<NT2>::type vec_t;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i, col = w * (DFF / 4) + NT2 * lr;
+            float v[NT2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * (DFF / 4) + t * 16 + lr;
-                float v = 0.f;
-                if (row0 + row < N) {
-                    const size_t o = (size_t)(row0 + row) * DFF + col;
-                    v = a.hdn[r][o] > 0.f ? acc[t][i] : 0.f;
-                    a.dpre1[r][o] = v;
-                }
-                wide[row][col] = v;
+            for (int t = 0; t < NT2; ++t) v[t] = 0.f;
+            if (row0 + row < N) {
+                const size_t o = (size_t)(row0 + row) * DFF + col;
+                const vec_t hv = *reinterpret_cast<const vec_t*>(a.hdn[r] + o);
+                const float* hp = reinterpret_cast<const float*>(&hv);
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) v[t] = hp[t] > 0.f ? acc[t][i] : 0.f;
+                *reinterpret_cast<vec_t*>(a.dpre1[r] + o) = *reinterpret_cast<const vec_t*>(v);
             }
+            *reinterpret_cast<vec_t*>(&wide[row][col]) = *reinterpret_cast<const vec_t*>(v);
+        }
     }
     load_tile(&xh[0][0], kD + 4, a.xh1[r], kD, kD, row0, N, identity_map());   // xhat2 is dead now
+    FragNN<NTO, 8> fwo;
+    frag_load_nn(fwo, a.wo[r] + w * (DM / 4), DM);
     __syncthreads();
     colsum16(&wide[0][0], WW + 4, nullptr, 0, DFF, part + 384);        // d l1.bias
     {   // dy1 = dt2 + dpre1 W1
         f32x4 acc[2];
         zero_acc(acc);
-        mm_nn<2>(&wide[0][0], WW + 4, a.w1[r] + w * 32, kD, DFF, acc);
+        frag_mma_nn(fw1, &wide[0][0], WW + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + t * 16 + lr;
-                ds[row][col] = acc[t][i] + t2[row][col];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i, col = w * 32 + 2 * lr;
+            ds[row][col] = acc[0][i] + t2[row][col];
+            ds[row][col + 1] = acc[1][i] + t2[row][col + 1];
+        }
     }
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF);   // d ln1.weight
@@ -724,32 +784,35 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF);     // d out-proj bias
     {   // da = dt1 Wo
-        constexpr int NT = DM / 64;
-        f32x4 acc[NT];
+        f32x4 acc[NTO];
         zero_acc(acc);
-        mm_nn<NT>(&ds[0][0], kD + 4, a.wo[r] + w * (DM / 4), DM, kD, acc);
+        frag_mma_nn(fwo, &ds[0][0], kD + 4, acc);
+        typedef typename VecN<NTO>::type vec_t;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i, col = w * (DM / 4) + NTO * lr;
+            float v[NTO];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * (DM / 4) + t * 16 + lr;
-                wide[row][col] = acc[t][i];
-                if (row0 + row < N) a.da[r][(size_t)(row0 + row) * DM + col] = acc[t][i];
-            }
+            for (int t = 0; t < NTO; ++t) v[t] = acc[t][i];
+            *reinterpret_cast<vec_t*>(&wide[row][col]) = *reinterpret_cast<const vec_t*>(v);
+            if (row0 + row < N) *reinterpret_cast<vec_t*>(a.da[r] + (size_t)(row0 + row) * DM + col) = *reinterpret_cast<const vec_t*>(v);
+        }
     }
     if (VPROJ) {   // dxbar[:, h, e] = sum_d da[:, h*64+d] Wv[h*64+d, e]
-        __syncthreads();
         const int h = w >> 1, e0 = (w & 1) * 64;
+        FragNN<4, 4> fwv;
+        frag_load_nn(fwv, a.wv[r] + (size_t)(h * 64) * kD + e0, kD);
+        __syncthreads();
         f32x4 acc[4];
         zero_acc(acc);
-        mm_nn<4>(&wide[0][h * 64], WW + 4, a.wv[r] + (size_t)(h * 64) * kD + e0, kD, 64, acc);
+        frag_mma_nn(fwv, &wide[0][h * 64], WW + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i;
-                if (row0 + row < N) a.dxbar[r][(size_t)(row0 + row) * 256 + h * kD + e0 + t * 16 + lr] = acc[t][i];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i;
+            if (row0 + row < N)
+                *reinterpret_cast<float4*>(a.dxbar[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + 4 * lr) =
+                    make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+        }
     }
 }
 
@@ -767,22 +830,24 @@ struct LinArgs {
     int ldy;
     int N, K, Nout, relu;
 };
-constexpr int kKChunk = 256;   // reduction columns staged in LDS at a time
+constexpr int kKChunk = 128;   // reduction columns per fragment set / LDS stage
 template <int NT>
 __global__ __launch_bounds__(256) void k_linear_fwd(LinArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[kTile][kKChunk + 4];
+    __shared__ __attribute__((aligned(16))) float xs[2][kTile][kKChunk + 4];
     const int r = blockIdx.z, row0 = blockIdx.x * kTile, K = a.K;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int col0 = blockIdx.y * (64 * NT) + w * (16 * NT);
     const bool active = col0 < a.Nout;
+    const float* wp = a.w[r] + (size_t)(active ? col0 : 0) * K;
     f32x4 acc[NT];
     zero_acc(acc);
-    for (int kc = 0; kc < K; kc += kKChunk) {
-        const int kl = min(kKChunk, K - kc);
-        if (kc) __syncthreads();
-        load_tile(&xs[0][0], kKChunk + 4, a.x[r] + kc, a.ldx, kl, row0, a.N, a.xmap);
+    int buf = 0;
+    for (int kc = 0; kc < K; kc += kKChunk, buf ^= 1) {
+        FragNT<NT, 8> f;
+        frag_load_nt(f, wp + kc, K);
+        load_tile(&xs[buf][0][0], kKChunk + 4, a.x[r] + kc, a.ldx, kKChunk, row0, a.N, a.xmap);
         __syncthreads();
-        if (active) mm_nt<NT>(&xs[0][0], kKChunk + 4, a.w[r] + (size_t)col0 * K + kc, K, kl, acc);
+        frag_mma_nt(f, &xs[buf][0][0], kKChunk + 4, acc);
     }
     if (!active) return;
     const float* bias = a.b[r];
@@ -790,7 +855,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(LinArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = lq * 4 + i, col = col0 + t * 16 + lr;
+            const int row = lq * 4 + i, col = col0 + col_nt(t, lr);
             if (row0 + row < a.N) {
                 float v = acc[t][i] + (bias ? bias[col] : 0.f);
                 if (a.relu) v = fmaxf(v, 0.f);
@@ -811,35 +876,46 @@ struct DgradArgs {
     int lddx;
     int N, K, Ncols;
 };
-template <int NT>
+// One workgroup = 16 rows x 32 output columns; the reduction dimension K is split over the
+// four waves (K/4 each, operands straight from L2 into registers, no LDS staging because
+// nothing is shared), partial tiles are summed through LDS.  K % 64 == 0, KS = K/64.
+template <int KS>
 __global__ __launch_bounds__(256) void k_dgrad(DgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float ys[kTile][kKChunk + 4];
-    const int r = blockIdx.z, row0 = blockIdx.x * kTile, K = a.K;
+    __shared__ __attribute__((aligned(16))) float red[4][kTile][32 + 1];
+    const int r = blockIdx.z, row0 = blockIdx.x * kTile, col0 = blockIdx.y * 32;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int col0 = blockIdx.y * (64 * NT) + w * (16 * NT);
-    const bool active = col0 < a.Ncols;
-    f32x4 acc[NT];
-    zero_acc(acc);
-    for (int kc = 0; kc < K; kc += kKChunk) {
-        const int kl = min(kKChunk, K - kc);
-        if (kc) __syncthreads();
-        load_tile(&ys[0][0], kKChunk + 4, a.dy[r] + kc, a.lddy, kl, row0, a.N, identity_map());
-        __syncthreads();
-        if (active) mm_nn<NT>(&ys[0][0], kKChunk + 4, a.w[r] + (size_t)kc * a.ldw + col0, a.ldw, kl, acc);
-    }
-    if (!active) return;
-    const float* res = a.res[r];
+    const int kw = w * KS * 16;                       // this wave's slice of K
+    FragNN<2, KS> f;
+    frag_load_nn(f, a.w[r] + (size_t)kw * a.ldw + col0, a.ldw);
+    float4 av[KS];
+    const bool rv = row0 + lr < a.N;
+    const float* ap = a.dy[r] + (size_t)(rv ? row0 + lr : 0) * a.lddy + kw + lq * 4;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int ks = 0; ks < KS; ++ks) av[ks] = rv ? *reinterpret_cast<const float4*>(ap + ks * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc[2];
+    zero_acc(acc);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const float a4[4] = {av[ks].x, av[ks].y, av[ks].z, av[ks].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = lq * 4 + i, col = col0 + t * 16 + lr;
-            if (row0 + row < a.N) {
-                float v = acc[t][i];
-                if (res) v += res[(size_t)map_row(a.rmap, row0 + row) * a.ldres + col];
-                a.dx[r][(size_t)(row0 + row) * a.lddx + col] = v;
-            }
+            acc[0] = mfma4(a4[i], f.b[ks][i].x, acc[0]);
+            acc[1] = mfma4(a4[i], f.b[ks][i].y, acc[1]);
         }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[w][lq * 4 + i][2 * lr + t] = acc[t][i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kTile * 32; idx += 256) {
+        const int row = idx >> 5, c = idx & 31, col = col0 + c;
+        if (row0 + row < a.N && col < a.Ncols) {
+            float v = (red[0][row][c] + red[1][row][c]) + (red[2][row][c] + red[3][row][c]);
+            if (a.res[r]) v += a.res[r][(size_t)map_row(a.rmap, row0 + row) * a.ldres + col];
+            a.dx[r][(size_t)(row0 + row) * a.lddx + col] = v;
+        }
+    }
 }
 
 // =======================================================================================
@@ -1092,46 +1168,93 @@ struct WgTile {
     int n0, k0;
 };
 __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) {
+    // 64 x 64 output tile; wave w owns rows n0+16w..+15.  B is read 16 bytes per lane, so
+    // accumulator c holds the strided columns k0 + 4r + c (Kk % 4 == 0).
     const WgTile& t = tiles[blockIdx.x];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int n = t.n0 + w * 16 + lr;
     const bool nv = n < t.Nn;
+    const int kc = t.k0 + 4 * lr;
+    const bool kv = kc < t.Kk;
     f32x4 acc[4];
     zero_acc(acc);
-    int kk[4];
-    bool kv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        kk[c] = t.k0 + c * 16 + lr;
-        kv[c] = kk[c] < t.Kk;
-    }
     for (int s = 0; s < t.nseg; ++s) {
         const WgSeg& sg = t.seg[s];
         const int M = sg.rows_per_gene * batch;
-        const float* Ap = sg.A + n;
-        for (int m0 = 0; m0 < M; m0 += 16) {
-            float av[4], bv[4][4];
+        const float* Ap = sg.A + (nv ? n : 0) + (size_t)lq * sg.lda;
+        const float* Bp = sg.B + (kv ? kc : 0) + (size_t)lq * sg.ldb;
+        int m0 = 0;
+#pragma unroll 2
+        for (; m0 + 16 <= M; m0 += 16) {
+            float av[4];
+            float4 bv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = m0 + i * 4 + lq;
-                const bool mv = m < M;
-                av[i] = (mv && nv) ? Ap[(size_t)m * sg.lda] : 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) bv[i][c] = (mv && kv[c]) ? sg.B[(size_t)m * sg.ldb + kk[c]] : 0.f;
+                av[i] = Ap[(size_t)(m0 + 4 * i) * sg.lda];
+                bv[i] = *reinterpret_cast<const float4*>(Bp + (size_t)(m0 + 4 * i) * sg.ldb);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                acc[0] = mfma4(av[i], bv[i].x, acc[0]);
+                acc[1] = mfma4(av[i], bv[i].y, acc[1]);
+                acc[2] = mfma4(av[i], bv[i].z, acc[2]);
+                acc[3] = mfma4(av[i], bv[i].w, acc[3]);
+            }
+        }
+        if (m0 < M) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = mfma4(av[i], bv[i][c], acc[c]);
+            for (int i = 0; i < 4; ++i) {
+                const bool mv = m0 + 4 * i + lq < M;
+                const float av = mv ? Ap[(size_t)(m0 + 4 * i) * sg.lda] : 0.f;
+                const float4 bv = mv ? *reinterpret_cast<const float4*>(Bp + (size_t)(m0 + 4 * i) * sg.ldb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc[0] = mfma4(av, bv.x, acc[0]);
+                acc[1] = mfma4(av, bv.y, acc[1]);
+                acc[2] = mfma4(av, bv.z, acc[2]);
+                acc[3] = mfma4(av, bv.w, acc[3]);
+            }
         }
     }
+    if (!kv) return;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = t.n0 + w * 16 + lq * 4 + i;
-            if (row < t.Nn && kv[c]) t.C[(size_t)row * t.ldc + kk[c]] = acc[c][i];
+    for (int i = 0; i < 4; ++i) {
+        const int row = t.n0 + w * 16 + lq * 4 + i;
+        if (row < t.Nn) *reinterpret_cast<float4*>(t.C + (size_t)row * t.ldc + kc) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+    }
+}
+
+// Weight gradient of the 7-mark projections (lin_proj / lin_proj_pcre, [128, F]): too narrow
+// for an MFMA tile.  One workgroup sums a chunk of 8 genes into partial[chunk][128*F]; the
+// chunks are added by k_colsum.   dW[e][f] = sum over segments, sum_m A[m][e] * B[m][f]
+struct LpJob {
+    WgSeg seg[4];
+    int nseg;
+    float* partial;
+    int F;
+};
+constexpr int kLpGenes = 8;
+__global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs, int batch) {
+    const LpJob& j = jobs[blockIdx.y];
+    const int g0 = blockIdx.x * kLpGenes, g1 = min(batch, g0 + kLpGenes);
+    if (g0 >= batch) return;
+    const int e = threadIdx.x & 127, fh = threadIdx.x >> 7;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < j.nseg; ++s) {
+        const WgSeg& sg = j.seg[s];
+        const int m1 = g1 * sg.rows_per_gene;
+#pragma unroll 4
+        for (int m = g0 * sg.rows_per_gene; m < m1; ++m) {
+            const float av = sg.A[(size_t)m * sg.lda + e];
+            const float4 bv = *reinterpret_cast<const float4*>(sg.B + (size_t)m * sg.ldb + fh * 4);
+            acc[0] = fmaf(av, bv.x, acc[0]);
+            acc[1] = fmaf(av, bv.y, acc[1]);
+            acc[2] = fmaf(av, bv.z, acc[2]);
+            acc[3] = fmaf(av, bv.w, acc[3]);
         }
+    }
+    float* out = j.partial + (size_t)blockIdx.x * (kD * j.F) + e * j.F;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (fh * 4 + k < j.F) out[fh * 4 + k] = acc[k];
 }
 
 // Deferred column sums (bias / LayerNorm / gamma gradients): out[c] = sum_m src[m][c]

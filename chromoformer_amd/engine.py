@@ -1,0 +1,155 @@
+"""Step engine: device-resident batch slots, hipGraph replay of the static launch sequence,
+data-parallel gradient all-reduce (RCCL through torch.distributed), AdamW + StepLR.
+
+Replaces the body of the reference's training loop (chromoformer/train.py:171-196):
+per-tensor ``.cuda()`` copies, ``zero_grad``/``forward``/``backward``/``step`` and the
+per-step host synchronisations.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class Slot:
+    """One batch resident in HBM at fixed addresses (what a captured graph reads)."""
+
+    def __init__(self, model, B):
+        dev = model._device
+        S, T, F = model.i_max, model.i_max + 1, model.n_feats
+        self.B = B
+        self.pf = [torch.zeros(B, 1, L, F, device=dev) for L in model.n_bins]
+        self.cf = [torch.zeros(B, S, L, F, device=dev) for L in model.n_bins]
+        self.pm = [torch.zeros(B, L, dtype=torch.uint8, device=dev) for L in model.n_bins]      # centre query row only
+        self.cm = [torch.zeros(B, S, L, dtype=torch.uint8, device=dev) for L in model.n_bins]
+        self.im = [torch.zeros(B, T, T, dtype=torch.uint8, device=dev) for _ in model.n_bins]
+        self.freq = torch.zeros(B, T, T, device=dev)
+        self.label = torch.zeros(B, dtype=torch.float32 if model.n_out == 1 else torch.int64, device=dev)
+        self.logits = torch.zeros(B, model.n_out, device=dev)
+        self.loss = torch.zeros(1, device=dev)
+        bs = _lib.cf_batch()
+        bs.B = B
+        for r, L in enumerate(model.n_bins):
+            bs.promoter_feats[r], bs.pcre_feats[r] = self.pf[r].data_ptr(), self.cf[r].data_ptr()
+            bs.promoter_mask_row[r], bs.promoter_mask_stride[r] = self.pm[r].data_ptr(), L
+            bs.pcre_mask_row[r], bs.pcre_mask_stride[r] = self.cm[r].data_ptr(), L
+            bs.interaction_mask[r] = self.im[r].data_ptr()
+        bs.interaction_freq = self.freq.data_ptr()
+        self.struct = bs
+        self.graph = None
+
+    def fill(self, model, d, non_blocking=True):
+        """Copy a reference-layout batch dict (host or device) into the slot."""
+        for r, b in enumerate(model.binsizes):
+            L = model.n_bins[r]
+            self.pf[r].copy_(d["promoter_feats"][b].reshape(self.pf[r].shape), non_blocking=non_blocking)
+            self.cf[r].copy_(d["pcre_feats"][b].reshape(self.cf[r].shape), non_blocking=non_blocking)
+            pm, cm = d["promoter_pad_masks"][b], d["pcre_pad_masks"][b]
+            if pm.dim() == 5:
+                pm, cm = pm[:, 0, 0, L // 2, :], cm[:, :, 0, L // 2, :]
+            self.pm[r].copy_(pm.reshape(self.pm[r].shape), non_blocking=non_blocking)
+            self.cm[r].copy_(cm.reshape(self.cm[r].shape), non_blocking=non_blocking)
+            self.im[r].copy_(d["interaction_masks"][b].reshape(self.im[r].shape), non_blocking=non_blocking)
+        self.freq.copy_(d["interaction_freq"], non_blocking=non_blocking)
+        if "label" in d:
+            self.label.copy_(d["label"].reshape(-1), non_blocking=non_blocking)
+        return self
+
+
+class Trainer:
+    def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.model, self.lr, self.gamma = model, float(lr), gamma
+        self.world, self.pg, self.use_graph = world_size, process_group, use_graph
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self._L = _lib.lib()
+        self._last = None
+        # hipGraph capture needs a non-default stream; all work of the trainer runs on it
+        self.stream = torch.cuda.Stream(device=model._device)
+
+    def stage(self, batch, slot=None):
+        slot = slot or Slot(self.model, batch["interaction_freq"].shape[0])
+        with torch.cuda.stream(self.stream):
+            return slot.fill(self.model, batch)
+
+    def _stream(self):
+        return self.stream.cuda_stream
+
+    def _fwd_bwd_chain(self, slot, st):
+        m, L = self.model, self._L
+        _lib.check(L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 1, st), "cf_forward")
+        _lib.check(L.cf_backward_chain(m._handle, C.byref(slot.struct), slot.label.data_ptr(), 1.0 / self.world,
+                                       slot.loss.data_ptr(), st), "cf_backward_chain")
+
+    def step(self, slot):
+        """One optimisation step on a staged batch (train.py:182-196)."""
+        with torch.cuda.stream(self.stream):
+            return self._step(slot)
+
+    def _step(self, slot):
+        m, L = self.model, self._L
+        st = self._stream()
+        if not self.use_graph:
+            self._fwd_bwd_chain(slot, st)
+        else:
+            if slot.graph is None:
+                self._fwd_bwd_chain(slot, st)          # eager once (also validates the arguments)
+                torch.cuda.synchronize()
+                gid = C.c_int()
+                _lib.check(L.cf_capture_begin(m._handle, st), "cf_capture_begin")
+                try:
+                    self._fwd_bwd_chain(slot, st)
+                finally:
+                    _lib.check(L.cf_capture_end(m._handle, st, C.byref(gid)), "cf_capture_end")
+                slot.graph = gid.value
+            _lib.check(L.cf_graph_launch(m._handle, slot.graph, st), "cf_graph_launch")
+        _lib.check(L.cf_backward_reduce(m._handle, slot.B, st), "cf_backward_reduce")
+        if self.world > 1:
+            torch.distributed.all_reduce(m.active_grads(), group=self.pg)
+        m.adamw_step(self.lr, self.betas, self.eps, self.wd)
+        self._last = slot
+        return slot.logits, slot.loss
+
+    def evaluate(self, slot):
+        m = self.model
+        with torch.cuda.stream(self.stream):
+            _lib.check(self._L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 0, self._stream()), "cf_forward")
+        return slot.logits
+
+    def scheduler_step(self):
+        """StepLR(step_size=1, gamma) (train.py:158, 344)."""
+        self.lr *= self.gamma
+
+    def last_loss(self):
+        return self._last.loss.item() if self._last is not None else float("nan")
+
+    # ------------------------------------------------------------------ measurement
+    def timing(self, kernel):
+        _lib.check(self._L.cf_timing_select(self.model._handle, kernel.encode() if kernel else None), "cf_timing_select")
+
+    def timing_read(self):
+        ms, n = C.c_float(), C.c_int()
+        _lib.check(self._L.cf_timing_read(self.model._handle, C.byref(ms), C.byref(n)), "cf_timing_read")
+        return ms.value, n.value
+
+    def roofline(self, kernel, total_ms, launches, B):
+        """Roofline entry of bench.py for the kernel timed with HIP events."""
+        if not launches:
+            return None
+        avg_s = total_ms / launches * 1e-3
+        if kernel == "k_wgrad":
+            flops = self._L.cf_wgrad_flops(self.model._handle, B)
+            ach = flops / avg_s / 1e12
+            return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": round(ach / 157.3, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "algorithmic_gflop_per_launch": round(flops / 1e9, 4)}
+        if kernel == "k_adamw":
+            nbytes = 7.0 * 4.0 * self.model._layout.n_active
+            ach = nbytes / avg_s / 1e9
+            return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(ach / 8000.0, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "algorithmic_mb_per_launch": round(nbytes / 1e6, 3)}
+        return {"kernel": kernel, "avg_launch_us": round(avg_s * 1e6, 2)}

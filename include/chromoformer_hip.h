@@ -119,6 +119,16 @@ int cf_forward(cf_handle* h, const cf_batch* batch, float* logits, int save_for_
  * cf_forward(..., save_for_backward = 1) on the same batch. */
 int cf_backward(cf_handle* h, const cf_batch* batch, const void* labels, float loss_scale,
                 float* loss_out, void* stream);
+/* The two halves of cf_backward, for callers that replay the first as a hipGraph:
+ *   cf_backward_chain  -- loss + the activation-gradient chain (head -> Regulation ->
+ *                         Pairwise -> Embedding); every dY a weight gradient needs is left
+ *                         in the workspace;
+ *   cf_backward_reduce -- the deferred reductions: all weight gradients (dW = dY^T X, one
+ *                         launch over a tile table) and all bias / LayerNorm / gamma_f
+ *                         gradients (one launch). */
+int cf_backward_chain(cf_handle* h, const cf_batch* batch, const void* labels, float loss_scale,
+                      float* loss_out, void* stream);
+int cf_backward_reduce(cf_handle* h, int B, void* stream);
 /* Same, but from a caller-supplied d(loss)/d(logits) [B, n_out]. */
 int cf_backward_from(cf_handle* h, const cf_batch* batch, const float* dlogits, void* stream);
 /* torch.optim.AdamW.step (train.py:157, 196): decoupled weight decay, bias correction
@@ -126,7 +136,23 @@ int cf_backward_from(cf_handle* h, const cf_batch* batch, const float* dlogits, 
 int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
                   long long step, void* stream);
 
+/* ---- hipGraph capture ---------------------------------------------------------------- */
+/* The launch sequence of a step is static, so it can be captured once and replayed: every
+ * library call issued on `stream` between begin and end is recorded (nothing executes);
+ * cf_graph_launch replays it.  Pointers are baked in: replay reads the same device buffers,
+ * so callers refill those buffers (hipMemcpyAsync) instead of passing new ones. */
+int cf_capture_begin(cf_handle* h, void* stream);
+int cf_capture_end(cf_handle* h, void* stream, int* graph_id);
+int cf_graph_launch(cf_handle* h, int graph_id, void* stream);
+
 /* ---- introspection (tests / profiling) -------------------------------------------- */
+/* HIP-event timing of one eagerly launched kernel ("k_wgrad", "k_colsum", "k_adamw"; NULL
+ * = off): events are recorded on the launch stream around every launch of that kernel;
+ * cf_timing_read waits for them and returns the summed duration and the launch count. */
+int cf_timing_select(cf_handle* h, const char* kernel);
+int cf_timing_read(cf_handle* h, float* total_ms, int* count);
+/* Executed flops (2*M*N*K summed over the tile table) of one k_wgrad launch at batch B. */
+double cf_wgrad_flops(cf_handle* h, int B);
 /* Copies a named workspace buffer (e.g. "E0.qt", "dP2.1.xbar") to dst (device);
  * *n_floats receives its size; dst may be NULL to query. */
 int cf_debug_copy(cf_handle* h, const char* name, float* dst, long long* n_floats, void* stream);

