@@ -1,0 +1,271 @@
+"""`python -m chromoformer_amd.train` -- drop-in for the reference's training entrypoint.
+
+Same command line (-o -c --exp-id -m -d --fold [--binsizes ...] [--regression] [--use-wandb]),
+same config.yaml schema and same .pt checkpoint layout as
+/root/reference/chromoformer/train.py:26-37, 45-68, 322-343.  What changed underneath:
+
+  * the model runs on the HIP path (chromoformer_amd.net) and a step is one library sequence
+    (forward, loss, backward, [RCCL all-reduce], AdamW) replayed from a hipGraph;
+  * genes are binned once into a pinned host store instead of per step in 8 loader processes;
+  * launched under torch.distributed.run it trains data-parallel, one process per GPU
+    (`bsz` is then the per-GPU batch and the gradients are averaged over ranks);
+  * `--binsizes` given on the command line are parsed as ints (the reference crashes on them).
+
+Behaviour that is kept on purpose: `for epoch in range(1, num_epoch)` (num_epoch - 1 epochs),
+the model constructor reseeding torch with 42, the checkpoint written BEFORE the scheduler step,
+metrics scaled by 100, validation loss computed on the host over the concatenated outputs, and the
+DataLoader's consumption of the global torch RNG (so the shuffled batch order is the reference's).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+import torch
+import torch.nn as nn
+import yaml
+
+from .data import ChromoformerDataset, GeneStore, shard_indices
+from .engine import Slot, Trainer
+from .net import ChromoformerClassifier, ChromoformerRegressor
+from .util import seed_everything
+
+
+def _wandb(enabled):
+    try:
+        import wandb
+        return wandb
+    except ImportError:
+        if enabled:
+            raise SystemExit("--use-wandb given but wandb is not installed")
+        stub = types.SimpleNamespace(init=lambda *a, **k: None, log=lambda *a, **k: None,
+                                     config=types.SimpleNamespace(update=lambda *a, **k: None),
+                                     summary=types.SimpleNamespace(update=lambda *a, **k: None))
+        return stub
+
+
+def _draw_loader_seed():
+    """One int64 draw from the global torch RNG, as DataLoader / RandomSampler do."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def epoch_permutation(n):
+    """Index order of DataLoader(shuffle=True): the iterator draws its base seed, then the
+    RandomSampler seeds a private generator from the global RNG and takes a randperm."""
+    _draw_loader_seed()
+    g = torch.Generator()
+    g.manual_seed(_draw_loader_seed())
+    return torch.randperm(n, generator=g).tolist()
+
+
+def optimizer_state_dict(model, lr):
+    """torch.optim.AdamW.state_dict() layout: entries only for parameters that ever had a gradient,
+    `step` as a 0-dim float32 tensor (train.py:325, 336)."""
+    named = list(model.named_parameters())
+    ref = torch.optim.AdamW([nn.Parameter(torch.zeros(1)) for _ in named], lr=float(lr))
+    sd = ref.state_dict()
+    sd["param_groups"][0]["lr"] = float(lr)
+    state = {}
+    if model._step > 0:
+        for i, e in enumerate(model._table):
+            if not e["trainable"]:
+                continue
+            sl = slice(e["offset"], e["offset"] + e["numel"])
+            state[i] = {"step": torch.tensor(float(model._step)),
+                        "exp_avg": model._mflat[sl].view(e["shape"]).detach().cpu().clone(),
+                        "exp_avg_sq": model._vflat[sl].view(e["shape"]).detach().cpu().clone()}
+    sd["state"] = state
+    return sd
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-o", "--output", required=True)
+    parser.add_argument("-c", "--config", required=True)
+    parser.add_argument("--exp-id", required=True)
+    parser.add_argument("-m", "--meta", required=True)
+    parser.add_argument("-d", "--npy-dir", required=True)
+    parser.add_argument("--fold", type=int, required=True)
+    parser.add_argument("--binsizes", nargs="+", type=int, default=[2000, 500, 100])
+    parser.add_argument("--regression", action="store_true", default=False)
+    parser.add_argument("--use-wandb", action="store_true", default=False)
+    args = parser.parse_args(argv)
+
+    if args.use_wandb is False:
+        os.environ["WANDB_MODE"] = "disabled"
+    wandb = _wandb(args.use_wandb)
+    with open(args.config) as f:
+        config = yaml.safe_load(f)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        pg = torch.distributed.group.WORLD
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say(config)
+
+    config["exp_id"] = args.exp_id
+    seed, num_epoch, bsz, gamma = config["seed"], config["num_epoch"], config["bsz"], config["gamma"]
+    i_max, w_prom, w_max, n_feats = config["i_max"], config["w_prom"], config["w_max"], config["n_feats"]
+    d_emb = config["embed"]["d_model"]
+
+    seed_everything(seed)
+    wandb.init(project="chromoformer-refactoring", entity="dohlee", group=args.exp_id)
+    wandb.config.update(args)
+    wandb.config.update(config)
+
+    meta = pd.read_csv(args.meta).sample(frac=1, random_state=seed).reset_index(drop=True)
+    if args.regression and "expression" not in meta.columns:
+        raise ValueError("`expression` column is required for training ChromoformerRegression model.")
+    say("Target genes:", len(set(meta.gene_id.unique())))
+    qs = [meta[meta.split == k].gene_id.tolist() for k in (1, 2, 3, 4)]
+    train_genes = qs[(args.fold + 0) % 4] + qs[(args.fold + 1) % 4] + qs[(args.fold + 2) % 4]
+    val_genes = qs[(args.fold + 3) % 4]
+    say(len(train_genes), len(val_genes))
+
+    def store_of(genes):
+        ds = ChromoformerDataset(args.meta, args.npy_dir, genes, n_feats, i_max, args.binsizes, w_prom, w_max,
+                                 regression=args.regression)
+        return GeneStore(ds, progress=(rank == 0))
+
+    train_store, val_store = store_of(train_genes), store_of(val_genes)
+
+    Model = ChromoformerRegressor if args.regression else ChromoformerClassifier
+    model = Model(n_feats, d_emb, config["d_head"], config["embed"], config["pairwise_interaction"], config["regulation"],
+                  binsizes=args.binsizes, seed=42, i_max=i_max, w_max=w_max, max_batch=bsz)
+    model.cuda(local)
+    criterion = nn.MSELoss() if args.regression else nn.CrossEntropyLoss()
+    trainer = Trainer(model, lr=float(config["lr"]), gamma=gamma, world_size=world, process_group=pg)
+    slots = [Slot(model, bsz), Slot(model, bsz)]       # double-buffered device batches
+    copy_stream = torch.cuda.Stream()
+
+    val_score = val_label = val_loss = None
+    for epoch in range(1, num_epoch):
+        perm = epoch_permutation(len(train_store))
+        batches = shard_indices(perm, rank, world, bsz, drop_last=True)
+        running, outs, labels, losses = 0.0, [], [], []
+        pending = None
+        if batches:
+            with torch.cuda.stream(copy_stream):
+                slots[0].fill(model, train_store.batch(batches[0]))
+            pending = copy_stream.record_event()
+        for k, idx in enumerate(batches, 1):
+            slot = slots[(k - 1) % 2]
+            trainer.stream.wait_event(pending)
+            logits, loss = trainer.step(slot)
+            done = trainer.stream.record_event()
+            if k < len(batches):                                   # prefetch the next batch while this one computes
+                with torch.cuda.stream(copy_stream):
+                    if k >= 2:
+                        copy_stream.wait_event(prev_done)          # the other slot's previous step has finished
+                    slots[k % 2].fill(model, train_store.batch(batches[k]))
+                pending = copy_stream.record_event()
+            prev_done = done
+            with torch.cuda.stream(trainer.stream):
+                outs.append(logits.detach().clone())
+                labels.append(slot.label.clone())
+                losses.append(loss.clone())
+                if k % 10 == 0:                                     # the only host synchronisation of the loop
+                    lo, la = torch.cat(outs).cpu(), torch.cat(labels).cpu()
+                    running = float(torch.cat(losses).mean().item())
+                    _report_train(say, wandb, epoch, running, trainer.lr, lo, la, args.regression)
+                    outs, labels, losses = [], [], []
+
+        # validation (sharded over ranks, gathered on every rank)
+        _draw_loader_seed()                                         # the val DataLoader's base seed draw
+        val_out, val_lab = _validate(model, trainer, val_store, bsz, rank, world)
+        val_loss = criterion(val_out, val_lab.view(-1, 1) if args.regression else val_lab)
+        val_label = val_lab.numpy()
+        from scipy import stats
+        from sklearn import metrics
+        if args.regression:
+            val_score = val_out.flatten().numpy()
+            val_r2 = metrics.r2_score(val_label, val_score) * 100
+            val_r = stats.pearsonr(val_label, val_score)[0] * 100
+            say(f"Validation loss={val_loss:.4f}, r2={val_r2:.4f}, r={val_r:.4f}")
+            wandb.log({"val/loss": val_loss, "val/r2": val_r2, "val/r": val_r})
+            ckpt = {"net": None, "optimizer": None, "epoch": epoch, "last_val_loss": val_loss, "last_val_r2": val_r2,
+                    "val_score": val_score, "val_label": val_label}
+        else:
+            val_score = val_out.softmax(axis=1)[:, 1].numpy()
+            val_pred = val_out.argmax(axis=1).numpy()
+            val_acc = metrics.accuracy_score(val_label, val_pred) * 100
+            val_auc = metrics.roc_auc_score(val_label, val_score) * 100
+            val_ap = metrics.average_precision_score(val_label, val_score) * 100
+            say(f"Validation loss={val_loss:.4f}, acc={val_acc:.4f}, auc={val_auc:.4f}, ap={val_ap:.4f}")
+            wandb.log({"val/loss": val_loss, "val/acc": val_acc, "val/auc": val_auc, "val/ap": val_ap, "val/epoch": epoch})
+            ckpt = {"net": None, "optimizer": None, "epoch": epoch, "last_val_loss": val_loss, "last_val_auc": val_auc,
+                    "val_score": val_score, "val_label": val_label}
+        if rank == 0:
+            torch.cuda.synchronize()
+            ckpt["net"] = type(model.state_dict())((k, v.detach().cpu().clone()) for k, v in model.state_dict().items())
+            ckpt["optimizer"] = optimizer_state_dict(model, trainer.lr)
+            torch.save(ckpt, args.output)
+        trainer.scheduler_step()
+
+    if val_loss is not None:
+        key = "last_val_r2" if args.regression else "last_val_auc"
+        wandb.summary.update({"last_val_loss": val_loss, key: ckpt[key]})
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+def _report_train(say, wandb, epoch, batch_loss, lr, out, label, regression):
+    from scipy import stats
+    from sklearn import metrics
+    if regression:
+        pred, lab = out.flatten(), label.flatten()
+        r2 = metrics.r2_score(lab, pred) * 100
+        r = stats.pearsonr(lab, pred)[0] * 100
+        say(f"E{epoch} {batch_loss:.4f}, lr={lr}, r2={r2:.4f}, r={r:.4f}")
+        wandb.log({"train/loss": batch_loss, "train/r2": r2, "train/r": r})
+    else:
+        score, pred = out.softmax(axis=1)[:, 1], out.argmax(axis=1)
+        acc = metrics.accuracy_score(label, pred) * 100
+        try:
+            auc = metrics.roc_auc_score(label, score) * 100
+            ap = metrics.average_precision_score(label, score) * 100
+        except ValueError:          # a window with a single class
+            auc = ap = float("nan")
+        say(f"E{epoch} {batch_loss:.4f}, lr={lr}, acc={acc:.4f}, auc={auc:.4f}, ap={ap:.4f}")
+        wandb.log({"train/loss": batch_loss, "train/acc": acc, "train/auc": auc, "train/ap": ap})
+
+
+def _validate(model, trainer, store, bsz, rank, world):
+    """Forward over the validation genes (the tail batch is kept, train.py:140); returns CPU
+    (logits [n, n_out], labels [n]) in dataset order on every rank."""
+    n = len(store)
+    per = (n + world - 1) // world
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    outs = []
+    slot_cache = {}
+    for s in range(lo, hi, bsz):
+        idx = list(range(s, min(hi, s + bsz)))
+        slot = slot_cache.get(len(idx)) or Slot(model, len(idx))
+        slot_cache[len(idx)] = slot
+        with torch.cuda.stream(trainer.stream):
+            slot.fill(model, store.batch(idx))
+        outs.append(trainer.evaluate(slot).clone())
+    torch.cuda.synchronize()
+    mine = torch.cat(outs) if outs else torch.zeros(0, model.n_out, device=model._device)
+    if world > 1:
+        pad = torch.zeros(per, model.n_out, device=model._device)
+        pad[: mine.shape[0]] = mine
+        parts = [torch.zeros_like(pad) for _ in range(world)]
+        torch.distributed.all_gather(parts, pad)
+        mine = torch.cat([p[: max(0, min(n, (r + 1) * per) - min(n, r * per))] for r, p in enumerate(parts)])
+    return mine.cpu(), store.label.clone()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -369,8 +369,71 @@ def g5_dataset():
     print("G5 ok; wrote dataset.npz %.1f KB" % (os.path.getsize(os.path.join(HERE, "dataset.npz")) / 1024))
 
 
+def g6_training_run():
+    """Run the reference's own `python -m chromoformer.train` (CPU, wandb / .cuda() stubbed) on the
+    deterministic synthetic dataset of tests/synth_data.py and keep what its checkpoint holds."""
+    import runpy
+    import yaml
+    from tests.synth_data import make_dataset
+    tmp = tempfile.mkdtemp()
+    meta = make_dataset(os.path.join(tmp, "npy"), n_genes=48, seed=2024)
+    cfg = yaml.safe_load(open(os.path.join(REF, "chromoformer/configs/default.yaml")))
+    cfg["bsz"] = 8
+    cfg["num_epoch"] = 3
+    cfg_path = os.path.join(tmp, "cfg.yaml")
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    wb = sys.modules["wandb"]
+    wb.init = lambda *a, **k: None
+    wb.log = lambda *a, **k: None
+    wb.config = types.SimpleNamespace(update=lambda *a, **k: None)
+    wb.summary = types.SimpleNamespace(update=lambda *a, **k: None)
+    import torch.utils.data as tud
+    real_loader = tud.DataLoader
+
+    def single_process_loader(*a, **k):      # same sampling / RNG consumption, no worker processes
+        k["num_workers"] = 0
+        return real_loader(*a, **k)
+
+    torch.utils.data.DataLoader = single_process_loader
+    torch.autograd.set_detect_anomaly(False)
+    out = {}
+    for reg in (False, True):
+        ck = os.path.join(tmp, "ck_%d.pt" % reg)
+        argv = ["train", "-o", ck, "-c", cfg_path, "--exp-id", "g6", "-m", meta, "-d", os.path.join(tmp, "npy"), "--fold", "0"]
+        if reg:
+            argv.append("--regression")
+        old = sys.argv
+        sys.argv = argv
+        try:
+            runpy.run_module("chromoformer.train", run_name="__main__")
+        finally:
+            sys.argv = old
+            torch.autograd.set_detect_anomaly(False)
+        c = torch.load(ck, map_location="cpu", weights_only=False)
+        tag = "reg" if reg else "clf"
+        out[tag + ".epoch"] = np.int64(c["epoch"])
+        out[tag + ".last_val_loss"] = np.float64(float(c["last_val_loss"]))
+        out[tag + ".last_val_metric"] = np.float64(c["last_val_r2" if reg else "last_val_auc"])
+        out[tag + ".val_score"] = np.asarray(c["val_score"])
+        out[tag + ".val_label"] = np.asarray(c["val_label"])
+        out[tag + ".lr"] = np.float64(c["optimizer"]["param_groups"][0]["lr"])
+        out[tag + ".opt_n_state"] = np.int64(len(c["optimizer"]["state"]))
+        out[tag + ".opt_step"] = np.float64(float(next(iter(c["optimizer"]["state"].values()))["step"]))
+        out[tag + ".ckpt_keys"] = np.array(list(c.keys()))
+        out[tag + ".param_checksums"] = np.array([checksum(v) for v in c["net"].values()])
+        out[tag + ".val_score_dtype"] = np.array(str(np.asarray(c["val_score"]).dtype))
+        out[tag + ".val_label_dtype"] = np.array(str(np.asarray(c["val_label"]).dtype))
+        print("G6 [%s] epoch %d val_loss %.5f metric %.4f lr %.4e" % (tag, c["epoch"], float(c["last_val_loss"]),
+              out[tag + ".last_val_metric"], out[tag + ".lr"]))
+    torch.utils.data.DataLoader = real_loader
+    np.savez_compressed(os.path.join(HERE, "train_run.npz"), **out)
+    print("wrote train_run.npz")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g3", "g2", "g1", "g5"]
+    which = sys.argv[1:] or ["g3", "g2", "g1", "g5", "g6"]
+    if "g6" in which:
+        g6_training_run()
     if "g3" in which:
         g3_state_dict()
     if "g2" in which:

@@ -1,0 +1,53 @@
+"""End-to-end drop-in check of `python -m chromoformer_amd.train` against golden G6: the
+reference's own train.py run (CPU, in the build container) on the deterministic synthetic dataset
+of tests/synth_data.py -- same shuffling, same 2 epochs x 4 steps, same checkpoint."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from tests.helpers import GOLDEN, checksum
+from tests.synth_data import make_dataset
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("reg", [False, True])
+def test_training_run_matches_reference_checkpoint(tmp_path, reg):
+    from chromoformer_amd import train
+    z = np.load(os.path.join(GOLDEN, "train_run.npz"))
+    tag = "reg" if reg else "clf"
+    meta = make_dataset(str(tmp_path / "npy"), n_genes=48, seed=2024)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "chromoformer_amd", "configs", "default.yaml")))
+    cfg["bsz"], cfg["num_epoch"] = 8, 3
+    cfg_path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    out = str(tmp_path / "ck.pt")
+    argv = ["-o", out, "-c", cfg_path, "--exp-id", "g6", "-m", meta, "-d", str(tmp_path / "npy"), "--fold", "0",
+            "--binsizes", "2000", "500", "100"]
+    if reg:
+        argv.append("--regression")
+    assert train.main(argv) == 0
+    c = torch.load(out, map_location="cpu", weights_only=False)
+    assert list(c.keys()) == list(z[tag + ".ckpt_keys"])
+    assert c["epoch"] == int(z[tag + ".epoch"])
+    assert abs(c["optimizer"]["param_groups"][0]["lr"] - float(z[tag + ".lr"])) < 1e-12
+    assert len(c["optimizer"]["state"]) == int(z[tag + ".opt_n_state"]) == 334
+    st = next(iter(c["optimizer"]["state"].values()))
+    assert float(st["step"]) == float(z[tag + ".opt_step"]) and st["step"].dtype == torch.float32 and st["step"].dim() == 0
+    assert str(np.asarray(c["val_score"]).dtype) == str(z[tag + ".val_score_dtype"])
+    assert str(np.asarray(c["val_label"]).dtype) == str(z[tag + ".val_label_dtype"])
+    assert np.array_equal(np.asarray(c["val_label"]), z[tag + ".val_label"])
+    # 8 AdamW steps from identical weights, identical batches: the validation outputs agree closely
+    assert np.abs(np.asarray(c["val_score"]) - z[tag + ".val_score"]).max() < (5e-3 if reg else 1e-3)
+    assert abs(float(c["last_val_loss"]) - float(z[tag + ".last_val_loss"])) < 2e-3 * max(1.0, float(z[tag + ".last_val_loss"]))
+    got = np.array([checksum(v) for v in c["net"].values()])
+    ref = z[tag + ".param_checksums"]
+    assert np.abs(got[:, 2] - ref[:, 2]).max() <= 1e-4 * ref[:, 2].max()
+    # the checkpoint loads back into both model classes' load_state_dict
+    from chromoformer_amd import ChromoformerClassifier, ChromoformerRegressor
+    m = (ChromoformerRegressor if reg else ChromoformerClassifier)()
+    m.load_state_dict(c["net"])
