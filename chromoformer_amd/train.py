@@ -183,7 +183,12 @@ def main(argv=None):
         # validation (sharded over ranks, gathered on every rank)
         _draw_loader_seed()                                         # the val DataLoader's base seed draw
         val_out, val_lab = _validate(model, trainer, val_store, bsz, rank, world)
-        val_loss = criterion(val_out, val_lab.view(-1, 1) if args.regression else val_lab)
+        # NB: for the regressor the reference compares [n,1] outputs with [n] labels here (train.py:280-283),
+        # i.e. a broadcast [n,n] MSE; `last_val_loss` in the checkpoint is that number, so it is kept.
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            val_loss = criterion(val_out, val_lab)
         val_label = val_lab.numpy()
         from scipy import stats
         from sklearn import metrics
@@ -255,7 +260,7 @@ def _validate(model, trainer, store, bsz, rank, world):
         slot_cache[len(idx)] = slot
         with torch.cuda.stream(trainer.stream):
             slot.fill(model, store.batch(idx))
-        outs.append(trainer.evaluate(slot).clone())
+            outs.append(trainer.evaluate(slot).clone())
     torch.cuda.synchronize()
     mine = torch.cat(outs) if outs else torch.zeros(0, model.n_out, device=model._device)
     if world > 1:
