@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -207,7 +208,7 @@ struct cf_handle {
     std::vector<CentreBuf> P[kMaxRes];
     std::vector<float*> Rx[kMaxRes], dRx[kMaxRes];
     std::vector<RegBuf> R[kMaxRes];
-    float *hin, *h1, *logits, *dlogits, *dh1, *dhin, *loss;
+    float *hin, *h1, *logits, *dlogits, *dh1, *dhin, *loss, *tdbg;
     // deferred-gradient tile tables
     WgTile* wg_tiles = nullptr;
     int n_wg = 0;
@@ -215,6 +216,8 @@ struct cf_handle {
     int n_cs = 0;
     LpJob* lp_jobs = nullptr;
     int n_lp = 0;
+    RegLayerDev* reg_tab = nullptr;      // fused Regulation stack (one workgroup per gene), when it fits in LDS
+    bool reg_fused = false;
     float *lp_part_e[kMaxRes], *lp_part_p[kMaxRes];
     int last_fwd_B = 0;
     int n_fwd = 0, n_bwd = 0, n_opt = 0;
@@ -327,7 +330,7 @@ static void plan_workspace(cf_handle* h) {
             b.dt1 = h->ws_get(d + "t1", NR * kD);
             b.da = h->ws_get(d + "a", NR * kRDm);
             b.dqkvg = h->ws_get(d + "qkvg", NR * kRW);
-            b.partial = h->ws_get(d + "partial", ((NR + kTile - 1) / kTile) * post_partial_width(dff));
+            b.partial = h->ws_get(d + "partial", std::max((NR + kTile - 1) / kTile, MB) * post_partial_width(dff));
             b.dgam = h->ws_get(d + "gam", MB * kRH);
         }
     }
@@ -338,6 +341,7 @@ static void plan_workspace(cf_handle* h) {
     h->dh1 = h->ws_get("dH.h1", MB * kD);
     h->dhin = h->ws_get("dH.in", MB * 3 * kD);
     h->loss = h->ws_get("H.loss", 4);
+    h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 40);      // shader-clock stamps (uint64) of the fused Regulation kernels
 }
 
 // ------------------------------------------------------------------------------------
@@ -405,6 +409,56 @@ static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const C
     push_wg(out, wg1(b.dt2, kD, b.hdn, dff, rpg, h->G_(ff_pre + "l2.weight"), dff, kD, dff));
 }
 
+static int build_reg_table(cf_handle* h) {
+    const cf_config& c = h->cfg;
+    if (h->reg_fused) {
+        std::vector<RegLayerDev> rt;
+        for (int r = 0; r < c.n_res; ++r)
+            for (int l = 0; l < c.reg_layers; ++l) {
+                const std::string lp = fmt("regulation.%d.transformer.layers.%d.", c.binsizes[r], l);
+                const RegBuf& b = h->R[r][l];
+                RegLayerDev d;
+                d.watt = h->P_(lp + "self_att.att.weight");
+                d.gamma = h->P_(lp + "self_att.gamma_f");
+                d.wo = h->P_(lp + "self_att.ff.weight");
+                d.bo = h->P_(lp + "self_att.ff.bias");
+                d.g1 = h->P_(lp + "self_att.ln.weight");
+                d.be1 = h->P_(lp + "self_att.ln.bias");
+                d.w1 = h->P_(lp + "ff.l1.weight");
+                d.b1 = h->P_(lp + "ff.l1.bias");
+                d.w2 = h->P_(lp + "ff.l2.weight");
+                d.b2 = h->P_(lp + "ff.l2.bias");
+                d.g2 = h->P_(lp + "ff.ln.weight");
+                d.be2 = h->P_(lp + "ff.ln.bias");
+                d.xin = h->Rx[r][l];
+                d.qkvg = b.qkvg;
+                d.p = b.p;
+                d.a = b.a;
+                d.xh1 = b.xh1;
+                d.rs1 = b.rs1;
+                d.y1 = b.y1;
+                d.hdn = b.hdn;
+                d.xh2 = b.xh2;
+                d.rs2 = b.rs2;
+                d.xout = h->Rx[r][l + 1];
+                d.dxout = h->dRx[r][l + 1];
+                d.dt2 = b.dt2;
+                d.dpre1 = b.dpre1;
+                d.dt1 = b.dt1;
+                d.da = b.da;
+                d.dqkvg = b.dqkvg;
+                d.dxin = h->dRx[r][l];
+                d.partial = b.partial;
+                d.dgam = b.dgam;
+                rt.push_back(d);
+            }
+        if (h->reg_tab) (void)hipFree(h->reg_tab);
+        HIP_TRY(hipMalloc(&h->reg_tab, rt.size() * sizeof(RegLayerDev)));
+        HIP_TRY(hipMemcpy(h->reg_tab, rt.data(), rt.size() * sizeof(RegLayerDev), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
 static int build_tables(cf_handle* h) {
     const cf_config& c = h->cfg;
     const int S = c.i_max, T = S + 1, F = c.n_feats;
@@ -465,7 +519,19 @@ static int build_tables(cf_handle* h) {
             push_wg(wg, wg1(b.dt1, kD, b.a, kRDm, T, h->G_(lp + "self_att.ff.weight"), kRDm, kD, kRDm));
             push_wg(wg, wg1(b.dpre1, dff, b.y1, kD, T, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
             push_wg(wg, wg1(b.dt2, kD, b.hdn, dff, T, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
-            push_post_cs(cs, h, b.partial, dff, T, lp + "self_att.", lp + "ff.");
+            if (h->reg_fused) {       // one partial row per gene instead of per 16-row tile
+                const int pw = post_partial_width(dff);
+                const std::string ap = lp + "self_att.", fp = lp + "ff.";
+                push_cs(cs, b.partial + 0, pw, kD, 1, 1, h->G_(fp + "ln.weight"));
+                push_cs(cs, b.partial + 128, pw, kD, 1, 1, h->G_(fp + "ln.bias"));
+                push_cs(cs, b.partial + 256, pw, kD, 1, 1, h->G_(fp + "l2.bias"));
+                push_cs(cs, b.partial + 384, pw, dff, 1, 1, h->G_(fp + "l1.bias"));
+                push_cs(cs, b.partial + 384 + dff, pw, kD, 1, 1, h->G_(ap + "ln.weight"));
+                push_cs(cs, b.partial + 512 + dff, pw, kD, 1, 1, h->G_(ap + "ln.bias"));
+                push_cs(cs, b.partial + 640 + dff, pw, kD, 1, 1, h->G_(ap + "ff.bias"));
+            } else {
+                push_post_cs(cs, h, b.partial, dff, T, lp + "self_att.", lp + "ff.");
+            }
             push_cs(cs, b.dgam, kRH, kRH, 1, 1, h->G_(lp + "self_att.gamma_f"));
         }
     }
@@ -560,10 +626,22 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             return fail("cf_create: positional table upload failed");
         }
     }
-    // dynamic LDS of the attention kernels
     const cf_config& c = h->cfg;
-    h->n_fwd = 1 + 3 + 1 + 3 * c.pair_layers + 3 * c.reg_layers + 3;
-    h->n_bwd = 4 + 3 * c.reg_layers + 3 * c.pair_layers + 2 + 3 + 3;
+    {   // the fused Regulation kernels need up to ~150 KB of dynamic LDS
+        const int T = c.i_max + 1;
+        const size_t need = std::max(reg_fwd_smem(T), reg_bwd_smem(T));
+        h->reg_fused = T <= kTile && need <= 160 * 1024;
+        if (h->reg_fused) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)k_reg_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_fwd_smem(T));
+            hipError_t e2 = hipFuncSetAttribute((const void*)k_reg_fwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_fwd_smem(T));
+            hipError_t e3 = hipFuncSetAttribute((const void*)k_reg_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_bwd_smem(T));
+            hipError_t e4 = hipFuncSetAttribute((const void*)k_reg_bwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_bwd_smem(T));
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) h->reg_fused = false;
+        }
+    }
+    const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
+    h->n_fwd = 1 + 3 + 1 + 3 * c.pair_layers + reg_launches + 3;
+    h->n_bwd = 4 + reg_launches + 3 * c.pair_layers + 2 + 3 + 3;
     h->n_opt = 1;
     *out = h;
     return 0;
@@ -575,6 +653,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (h->wg_tiles) (void)hipFree(h->wg_tiles);
     if (h->cs_tiles) (void)hipFree(h->cs_tiles);
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
+    if (h->reg_tab) (void)hipFree(h->reg_tab);
     for (hipGraphExec_t g : h->graphs) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
@@ -586,6 +665,7 @@ extern "C" int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg
     h->grads = grads;
     h->m = exp_avg;
     h->v = exp_avg_sq;
+    if (build_reg_table(h)) return -1;
     if (grads) return build_tables(h);
     return 0;
 }
@@ -798,7 +878,20 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
                          l == 0))
             return -1;
     }
-    for (int l = 0; l < c.reg_layers; ++l) {   // Regulation layers
+    if (h->reg_fused) {   // Regulation: all layers in one launch, one workgroup per (gene, resolution)
+        RegArgs ra;
+        ra.tab = h->reg_tab;
+        ra.n_layers = c.reg_layers;
+        ra.T = T;
+        for (int r = 0; r < nres; ++r) ra.mask[r] = bt->interaction_mask[r];
+        ra.freq = bt->interaction_freq;
+        ra.save = save;
+        ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
+        if (c.reg_dff == 128) hipLaunchKernelGGL((k_reg_fwd<128>), dim3(B, nres), dim3(256), reg_fwd_smem(T), st, ra);
+        else hipLaunchKernelGGL((k_reg_fwd<256>), dim3(B, nres), dim3(256), reg_fwd_smem(T), st, ra);
+        LAUNCH_CHECK("k_reg_fwd");
+    }
+    for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
         LinArgs la;
         AttrArgs at;
         PostArgs po;
@@ -928,7 +1021,20 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         hipLaunchKernelGGL(k_head_scatter, dim3(B, nres), dim3(128), 0, st, sc);
         LAUNCH_CHECK("k_head_scatter");
     }
-    for (int l = c.reg_layers - 1; l >= 0; --l) {   // Regulation
+    if (h->reg_fused) {
+        RegArgs ra;
+        ra.tab = h->reg_tab;
+        ra.n_layers = c.reg_layers;
+        ra.T = T;
+        for (int r = 0; r < nres; ++r) ra.mask[r] = bt->interaction_mask[r];
+        ra.freq = bt->interaction_freq;
+        ra.save = 1;
+        ra.tdbg = nullptr;
+        if (c.reg_dff == 128) hipLaunchKernelGGL((k_reg_bwd<128>), dim3(B, nres), dim3(256), reg_bwd_smem(T), st, ra);
+        else hipLaunchKernelGGL((k_reg_bwd<256>), dim3(B, nres), dim3(256), reg_bwd_smem(T), st, ra);
+        LAUNCH_CHECK("k_reg_bwd");
+    }
+    for (int l = (h->reg_fused ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback
         PostBwdArgs pb;
         AttrArgs at;
         DgradArgs dg;

@@ -71,34 +71,57 @@ __device__ __forceinline__ float group16_sum(float v) {
 // memory-level parallelism is what hides the L2 latency.
 // ---------------------------------------------------------------------------------------
 
+// Operand streaming.  A product walks K in chunks of 32 (two MFMA k-steps); the B operand of
+// chunk c+2 is requested from L2 while chunk c is multiplied (3-slot register ring, at most
+// 2*NT*2 sixteen-byte loads outstanding, well inside the 6-bit vmcnt counter so the compiler
+// can emit counted waits instead of draining the queue).  frag_load_*() issues the first two
+// chunks -- typically before the barrier / LayerNorm that precedes the product -- and
+// frag_mma_*() runs the pipeline.
+
 // "NT" fragments: W row-major [n][ldw] (an nn.Linear weight), C = A . W^T.
-// Column map: col(t, r) = t*16 + r (contiguous 16-column tiles).
+// Column map: col(t, r) = t*16 + r (contiguous 16-column tiles).  KS = K / 16.
 template <int NT, int KS>
 struct FragNT {
-    float4 b[KS][NT];
+    float4 ring[3][2][NT];
+    const float* wp;
+    int ldw;
 };
 template <int NT, int KS>
-__device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __restrict__ W, int ldw) {
-    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const float* wp = W + (size_t)r * ldw + q * 4;
+__device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS>& f, int slot, int chunk) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) f.b[ks][t] = *reinterpret_cast<const float4*>(wp + (size_t)t * 16 * ldw + ks * 16);
+        for (int t = 0; t < NT; ++t)
+            f.ring[slot][k][t] = *reinterpret_cast<const float4*>(f.wp + (size_t)t * 16 * f.ldw + (chunk * 2 + k) * 16);
 }
 template <int NT, int KS>
-__device__ __forceinline__ void frag_mma_nt(const FragNT<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __restrict__ W, int ldw) {
+    static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    f.wp = W + (size_t)r * ldw + q * 4;
+    f.ldw = ldw;
+    frag_chunk_nt(f, 0, 0);
+    frag_chunk_nt(f, 1, 1);
+}
+template <int NT, int KS>
+__device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
+    constexpr int NC = KS / 2;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const float4 a = *reinterpret_cast<const float4*>(ap + ks * 16);
+    for (int c = 0; c < NC; ++c) {
+        if (c + 2 < NC) frag_chunk_nt(f, (c + 2) % 3, c + 2);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = mfma4(a.x, f.b[ks][t].x, acc[t]);
-            acc[t] = mfma4(a.y, f.b[ks][t].y, acc[t]);
-            acc[t] = mfma4(a.z, f.b[ks][t].z, acc[t]);
-            acc[t] = mfma4(a.w, f.b[ks][t].w, acc[t]);
+        for (int k = 0; k < 2; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 b = f.ring[c % 3][k][t];
+                acc[t] = mfma4(a.x, b.x, acc[t]);
+                acc[t] = mfma4(a.y, b.y, acc[t]);
+                acc[t] = mfma4(a.z, b.z, acc[t]);
+                acc[t] = mfma4(a.w, b.w, acc[t]);
+            }
         }
     }
 }
@@ -119,31 +142,45 @@ struct VecN<4> {
 };
 template <int NT, int KS>
 struct FragNN {
-    typename VecN<NT>::type b[KS][4];
+    typename VecN<NT>::type ring[3][2][4];
+    const float* bp;
+    int ldb;
 };
 template <int NT, int KS>
-__device__ __forceinline__ void frag_load_nn(FragNN<NT, KS>& f, const float* __restrict__ Bm, int ldb) {
-    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const float* bp = Bm + (size_t)(q * 4) * ldb + NT * r;
+__device__ __forceinline__ void frag_chunk_nn(FragNN<NT, KS>& f, int slot, int chunk) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            f.b[ks][i] = *reinterpret_cast<const typename VecN<NT>::type*>(bp + (size_t)(ks * 16 + i) * ldb);
+            f.ring[slot][k][i] = *reinterpret_cast<const typename VecN<NT>::type*>(f.bp + (size_t)((chunk * 2 + k) * 16 + i) * f.ldb);
 }
 template <int NT, int KS>
-__device__ __forceinline__ void frag_mma_nn(const FragNN<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void frag_load_nn(FragNN<NT, KS>& f, const float* __restrict__ Bm, int ldb) {
+    static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    f.bp = Bm + (size_t)(q * 4) * ldb + NT * r;
+    f.ldb = ldb;
+    frag_chunk_nn(f, 0, 0);
+    frag_chunk_nn(f, 1, 1);
+}
+template <int NT, int KS>
+__device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
+    constexpr int NC = KS / 2;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const float4 a = *reinterpret_cast<const float4*>(ap + ks * 16);
-        const float av[4] = {a.x, a.y, a.z, a.w};
+    for (int c = 0; c < NC; ++c) {
+        if (c + 2 < NC) frag_chunk_nn(f, (c + 2) % 3, c + 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float* bv = reinterpret_cast<const float*>(&f.b[ks][i]);
+        for (int k = 0; k < 2; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+            const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma4(av[i], bv[t], acc[t]);
+            for (int i = 0; i < 4; ++i) {
+                const float* bv = reinterpret_cast<const float*>(&f.ring[c % 3][k][i]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma4(av[i], bv[t], acc[t]);
+            }
         }
     }
 }
@@ -172,7 +209,7 @@ __device__ __forceinline__ void load_tile(float* dst, int ldd, const float* __re
 // an LDS tile).  y = xhat * g + b is written back into the tile; xhat / rstd / y go to
 // global (row-major [N,128]) when the pointers are non-null.
 __device__ __forceinline__ void ln_fwd_rows(float* ts, int ld, const float* __restrict__ g, const float* __restrict__ b,
-                                            int row0, int nrows, float* xhat_g, float* rstd_g, float* y_g,
+                                            int row0, int nvalid, float* xhat_g, float* rstd_g, float* y_g,
                                             const RowMap& ymap) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float g0 = g[lane], g1 = g[lane + 64], b0 = b[lane], b1 = b[lane + 64];
@@ -189,7 +226,7 @@ __device__ __forceinline__ void ln_fwd_rows(float* ts, int ld, const float* __re
         ts[row * ld + lane] = y0;
         ts[row * ld + lane + 64] = y1;
         const int n = row0 + row;
-        if (n < nrows) {
+        if (row < nvalid) {
             if (xhat_g) {
                 xhat_g[(size_t)n * kD + lane] = x0;
                 xhat_g[(size_t)n * kD + lane + 64] = x1;
@@ -207,7 +244,7 @@ __device__ __forceinline__ void ln_fwd_rows(float* ts, int ld, const float* __re
 // LayerNorm backward for the wave's 4 rows: dys holds dL/dy (LDS), xh the saved xhat
 // (LDS); dL/dx overwrites dys and is stored to dx_g.
 __device__ __forceinline__ void ln_bwd_rows(float* dys, int ld, const float* xh, int ldx, const float* __restrict__ g,
-                                            const float* __restrict__ rstd_g, int row0, int nrows, float* dx_g) {
+                                            const float* __restrict__ rstd_g, int row0, int nvalid, float* dx_g) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float g0 = g[lane], g1 = g[lane + 64];
 #pragma unroll
@@ -217,11 +254,11 @@ __device__ __forceinline__ void ln_bwd_rows(float* dys, int ld, const float* xh,
         const float x0 = xh[row * ldx + lane], x1 = xh[row * ldx + lane + 64];
         const float m1 = wave_sum(a0 + a1) * (1.0f / kD);
         const float m2 = wave_sum(a0 * x0 + a1 * x1) * (1.0f / kD);
-        const float rs = (n < nrows) ? rstd_g[n] : 0.f;
+        const float rs = (row < nvalid) ? rstd_g[n] : 0.f;
         const float o0 = rs * (a0 - m1 - x0 * m2), o1 = rs * (a1 - m1 - x1 * m2);
         dys[row * ld + lane] = o0;
         dys[row * ld + lane + 64] = o1;
-        if (n < nrows) {
+        if (row < nvalid) {
             dx_g[(size_t)n * kD + lane] = o0;
             dx_g[(size_t)n * kD + lane + 64] = o1;
         }
@@ -651,7 +688,7 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
     FragNT<NT1, 8> f1;      // issued before the LayerNorm so the L2 latency hides behind it
     frag_load_nt(f1, a.w1[r] + (size_t)(w * (DFF / 4)) * kD, kD);
     __syncthreads();
-    ln_fwd_rows(&ts[0][0], kD + 4, a.g1[r], a.be1[r], row0, N, a.save ? a.xh1[r] : nullptr, a.rs1[r],
+    ln_fwd_rows(&ts[0][0], kD + 4, a.g1[r], a.be1[r], row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r],
                 a.save ? a.y1[r] : nullptr, identity_map());
     __syncthreads();
     {   // hdn = relu(y1 W1^T + b1)
@@ -684,7 +721,7 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
             }
     }
     __syncthreads();
-    ln_fwd_rows(&xs[0][0], kD + 4, a.g2[r], a.be2[r], row0, N, a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+    ln_fwd_rows(&xs[0][0], kD + 4, a.g2[r], a.be2[r], row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
 }
 
 // backward of the chain.  Per tile it also emits the column sums that make up the
@@ -733,7 +770,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128);           // d ln2.bias
     for (int i = threadIdx.x; i < kTile * kD; i += 256) t2[i >> 7][i & 127] = ds[i >> 7][i & 127];
     __syncthreads();
-    ln_bwd_rows(&t2[0][0], kD + 4, &xh[0][0], kD + 4, a.g2[r], a.rs2[r], row0, N, a.dt2[r]);   // t2 = dt2
+    ln_bwd_rows(&t2[0][0], kD + 4, &xh[0][0], kD + 4, a.g2[r], a.rs2[r], row0, min(kTile, N - row0), a.dt2[r]);   // t2 = dt2
     FragNN<2, DFF / 16> fw1;
     frag_load_nn(fw1, a.w1[r] + w * 32, kD);
     __syncthreads();
@@ -780,7 +817,7 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF);   // d ln1.weight
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 512 + DFF);          // d ln1.bias
     __syncthreads();
-    ln_bwd_rows(&ds[0][0], kD + 4, &xh[0][0], kD + 4, a.g1[r], a.rs1[r], row0, N, a.dt1[r]);   // ds = dt1
+    ln_bwd_rows(&ds[0][0], kD + 4, &xh[0][0], kD + 4, a.g1[r], a.rs1[r], row0, min(kTile, N - row0), a.dt1[r]);   // ds = dt1
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF);     // d out-proj bias
     {   // da = dt1 Wo
@@ -885,22 +922,37 @@ __global__ __launch_bounds__(256) void k_dgrad(DgradArgs a) {
     const int r = blockIdx.z, row0 = blockIdx.x * kTile, col0 = blockIdx.y * 32;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int kw = w * KS * 16;                       // this wave's slice of K
-    FragNN<2, KS> f;
-    frag_load_nn(f, a.w[r] + (size_t)kw * a.ldw + col0, a.ldw);
-    float4 av[KS];
     const bool rv = row0 + lr < a.N;
     const float* ap = a.dy[r] + (size_t)(rv ? row0 + lr : 0) * a.lddy + kw + lq * 4;
+    const float* bp = a.w[r] + (size_t)(kw + lq * 4) * a.ldw + col0 + 2 * lr;
+    float4 ra[3][2];
+    float2 rb[3][2][4];
+    auto fetch = [&](int slot, int chunk) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) av[ks] = rv ? *reinterpret_cast<const float4*>(ap + ks * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 2; ++k) {
+            ra[slot][k] = *reinterpret_cast<const float4*>(ap + (chunk * 2 + k) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rb[slot][k][i] = *reinterpret_cast<const float2*>(bp + (size_t)((chunk * 2 + k) * 16 + i) * a.ldw);
+        }
+    };
+    constexpr int NC = KS / 2;
+    fetch(0, 0);
+    if (NC > 1) fetch(1, 1);
     f32x4 acc[2];
     zero_acc(acc);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const float a4[4] = {av[ks].x, av[ks].y, av[ks].z, av[ks].w};
+    for (int c = 0; c < NC; ++c) {
+        if (c + 2 < NC) fetch((c + 2) % 3, c + 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[0] = mfma4(a4[i], f.b[ks][i].x, acc[0]);
-            acc[1] = mfma4(a4[i], f.b[ks][i].y, acc[1]);
+        for (int k = 0; k < 2; ++k) {
+            const float4 av = ra[c % 3][k];
+            const float a4[4] = {rv ? av.x : 0.f, rv ? av.y : 0.f, rv ? av.z : 0.f, rv ? av.w : 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0] = mfma4(a4[i], rb[c % 3][k][i].x, acc[0]);
+                acc[1] = mfma4(a4[i], rb[c % 3][k][i].y, acc[1]);
+            }
         }
     }
 #pragma unroll
@@ -1184,23 +1236,34 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
         const float* Ap = sg.A + (nv ? n : 0) + (size_t)lq * sg.lda;
         const float* Bp = sg.B + (kv ? kc : 0) + (size_t)lq * sg.ldb;
         int m0 = 0;
-#pragma unroll 2
-        for (; m0 + 16 <= M; m0 += 16) {
-            float av[4];
-            float4 bv[4];
+        float ra[3][4];
+        float4 rb[3][4];
+        auto fetch = [&](int slot, int mm) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                av[i] = Ap[(size_t)(m0 + 4 * i) * sg.lda];
-                bv[i] = *reinterpret_cast<const float4*>(Bp + (size_t)(m0 + 4 * i) * sg.ldb);
+                ra[slot][i] = Ap[(size_t)(mm + 4 * i) * sg.lda];
+                rb[slot][i] = *reinterpret_cast<const float4*>(Bp + (size_t)(mm + 4 * i) * sg.ldb);
             }
+        };
+        const int nfull = M / 16;
+        if (nfull > 0) fetch(0, 0);
+        if (nfull > 1) fetch(1, 16);
+        for (int it = 0; it < nfull; it += 3) {      // three iterations per trip: static ring slots
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[0] = mfma4(av[i], bv[i].x, acc[0]);
-                acc[1] = mfma4(av[i], bv[i].y, acc[1]);
-                acc[2] = mfma4(av[i], bv[i].z, acc[2]);
-                acc[3] = mfma4(av[i], bv[i].w, acc[3]);
+            for (int u = 0; u < 3; ++u) {
+                if (it + u < nfull) {
+                    if (it + u + 2 < nfull) fetch((u + 2) % 3, (it + u + 2) * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[0] = mfma4(ra[u][i], rb[u][i].x, acc[0]);
+                        acc[1] = mfma4(ra[u][i], rb[u][i].y, acc[1]);
+                        acc[2] = mfma4(ra[u][i], rb[u][i].z, acc[2]);
+                        acc[3] = mfma4(ra[u][i], rb[u][i].w, acc[3]);
+                    }
+                }
             }
         }
+        m0 = nfull * 16;
         if (m0 < M) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1231,7 +1294,7 @@ struct LpJob {
     float* partial;
     int F;
 };
-constexpr int kLpGenes = 8;
+constexpr int kLpGenes = 1;
 __global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs, int batch) {
     const LpJob& j = jobs[blockIdx.y];
     const int g0 = blockIdx.x * kLpGenes, g1 = min(batch, g0 + kLpGenes);
@@ -1309,3 +1372,5 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
 }
 
 }  // namespace cf
+
+#include "cf_reg_fused.h"
