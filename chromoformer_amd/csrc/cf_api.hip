@@ -193,6 +193,9 @@ struct cf_handle {
     std::map<std::string, int> index;
     cf_layout lay;
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+    float* tiled = nullptr;              // tiled copy of the Linear weights (forward products), same offsets
+    RetileUnit* retile_units = nullptr;
+    int n_retile = 0;
     // workspace
     float* arena = nullptr;
     size_t arena_floats = 0;
@@ -252,6 +255,7 @@ struct cf_handle {
         return arena + e.off;
     }
     const float* P_(const std::string& name, long long extra = 0) const { return params + table[index.at(name)].offset + extra; }
+    const float* T_(const std::string& name, long long extra = 0) const { return tiled + table[index.at(name)].offset + extra; }
     float* G_(const std::string& name, long long extra = 0) const { return grads + table[index.at(name)].offset + extra; }
 };
 
@@ -419,6 +423,10 @@ static int build_reg_table(cf_handle* h) {
                 const RegBuf& b = h->R[r][l];
                 RegLayerDev d;
                 d.watt = h->P_(lp + "self_att.att.weight");
+                d.watt_t = h->T_(lp + "self_att.att.weight");
+                d.wo_t = h->T_(lp + "self_att.ff.weight");
+                d.w1_t = h->T_(lp + "ff.l1.weight");
+                d.w2_t = h->T_(lp + "ff.l2.weight");
                 d.gamma = h->P_(lp + "self_att.gamma_f");
                 d.wo = h->P_(lp + "self_att.ff.weight");
                 d.bo = h->P_(lp + "self_att.ff.bias");
@@ -602,6 +610,19 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         return -1;
     }
     for (size_t i = 0; i < h->table.size(); ++i) h->index[h->table[i].name] = (int)i;
+    {
+        std::vector<RetileUnit> units;
+        for (const PDesc& p : h->table)
+            if (p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable)
+                for (int n0 = 0; n0 < p.shape[0]; n0 += 16) units.push_back(RetileUnit{p.offset + (long long)n0 * p.shape[1], p.shape[1]});
+        h->n_retile = (int)units.size();
+        if (hipMalloc(&h->tiled, h->lay.n_total * sizeof(float)) != hipSuccess ||
+            hipMalloc(&h->retile_units, units.size() * sizeof(RetileUnit)) != hipSuccess ||
+            hipMemcpy(h->retile_units, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice) != hipSuccess) {
+            delete h;
+            return fail("cf_create: allocation of the tiled weight copy failed");
+        }
+    }
     h->planning = true;
     plan_workspace(h);
     hipError_t e = hipMalloc(&h->arena, h->arena_floats * sizeof(float));
@@ -640,7 +661,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         }
     }
     const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
-    h->n_fwd = 1 + 3 + 1 + 3 * c.pair_layers + reg_launches + 3;
+    h->n_fwd = 2 + 3 + 1 + 3 * c.pair_layers + reg_launches + 3;
     h->n_bwd = 4 + reg_launches + 3 * c.pair_layers + 2 + 3 + 3;
     h->n_opt = 1;
     *out = h;
@@ -654,6 +675,8 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (h->cs_tiles) (void)hipFree(h->cs_tiles);
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
     if (h->reg_tab) (void)hipFree(h->reg_tab);
+    if (h->tiled) (void)hipFree(h->tiled);
+    if (h->retile_units) (void)hipFree(h->retile_units);
     for (hipGraphExec_t g : h->graphs) (void)hipGraphExecDestroy(g);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
@@ -690,8 +713,9 @@ static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArg
     else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256>), grid, dim3(256), 0, st, a);
 }
 
-struct CentreParams {   // weights of one centre-row layer
+struct CentreParams {   // weights of one centre-row layer (_t: tiled copies for the forward products)
     const float *wq, *wk, *wv, *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2, *wlp;
+    const float *wq_t, *wk_t, *wv_t, *wo_t, *w1_t, *w2_t;
 };
 static CentreParams centre_params(const cf_handle* h, const std::string& att_pre, const std::string& ff_pre, const float* wq,
                                   const float* wk, const float* wv, const float* wlp) {
@@ -700,13 +724,20 @@ static CentreParams centre_params(const cf_handle* h, const std::string& att_pre
     p.wk = wk;
     p.wv = wv;
     p.wlp = wlp;
+    const long long td = h->tiled - h->params;     // same offsets in both buffers
+    p.wq_t = wq + td;
+    p.wk_t = wk + td;
+    p.wv_t = wv + td;
     p.wo = h->P_(att_pre + "ff.weight");
+    p.wo_t = p.wo + td;
     p.bo = h->P_(att_pre + "ff.bias");
     p.g1 = h->P_(att_pre + "ln.weight");
     p.be1 = h->P_(att_pre + "ln.bias");
     p.w1 = h->P_(ff_pre + "l1.weight");
+    p.w1_t = p.w1 + td;
     p.b1 = h->P_(ff_pre + "l1.bias");
     p.w2 = h->P_(ff_pre + "l2.weight");
+    p.w2_t = p.w2 + td;
     p.b2 = h->P_(ff_pre + "l2.bias");
     p.g2 = h->P_(ff_pre + "ln.weight");
     p.be2 = h->P_(ff_pre + "ln.bias");
@@ -748,6 +779,9 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
     const float scale_c = sqrtf(64.f);
     CentreParams ep[kMaxRes], pp[kMaxRes];
     for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
+    // refresh the tiled weight copy (the parameters may have been changed by anyone since the last call)
+    hipLaunchKernelGGL(k_retile, dim3(h->n_retile), dim3(256), 0, st, (const float*)h->params, h->tiled, (const RetileUnit*)h->retile_units);
+    LAUNCH_CHECK("k_retile");
 
     {   // Embedding centre-row input
         X0Args a;
@@ -774,8 +808,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         for (int r = 0; r < nres; ++r) {
             CentreBuf& b = *bufs[r];
             q.x[r] = xin[r];
-            q.wq[r] = prm[r].wq;
-            q.wk[r] = prm[r].wk;
+            q.wq[r] = prm[r].wq_t;      // NT product: tiled copy
+            q.wk[r] = prm[r].wk;        // NN product: row-major
             q.q[r] = b.q;
             q.qt[r] = b.qt;
             q.xcopy[r] = copy_x ? b.xin : nullptr;
@@ -793,14 +827,14 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             smem = std::max(smem, attc_smem(c.n_bins[r], F, false));
             po.x[r] = xin[r];
             po.ain[r] = b.xbar;
-            po.wv[r] = prm[r].wv;
-            po.wo[r] = prm[r].wo;
+            po.wv[r] = prm[r].wv_t;
+            po.wo[r] = prm[r].wo_t;
             po.bo[r] = prm[r].bo;
             po.g1[r] = prm[r].g1;
             po.be1[r] = prm[r].be1;
-            po.w1[r] = prm[r].w1;
+            po.w1[r] = prm[r].w1_t;
             po.b1[r] = prm[r].b1;
-            po.w2[r] = prm[r].w2;
+            po.w2[r] = prm[r].w2_t;
             po.b2[r] = prm[r].b2;
             po.g2[r] = prm[r].g2;
             po.be2[r] = prm[r].be2;
@@ -847,7 +881,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         LinArgs a;
         for (int r = 0; r < nres; ++r) {
             a.x[r] = h->Rx[r][0];
-            a.w[r] = h->P_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
+            a.w[r] = h->T_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
             a.b[r] = nullptr;
             a.y[r] = h->xp0[r];
         }
@@ -899,7 +933,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             const std::string lp = fmt("regulation.%d.transformer.layers.%d.", c.binsizes[r], l);
             RegBuf& b = h->R[r][l];
             la.x[r] = h->Rx[r][l];
-            la.w[r] = h->P_(lp + "self_att.att.weight");
+            la.w[r] = h->T_(lp + "self_att.att.weight");
             la.b[r] = nullptr;
             la.y[r] = b.qkvg;
             at.qkvg[r] = b.qkvg;
@@ -912,13 +946,13 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             po.x[r] = h->Rx[r][l];
             po.ain[r] = b.a;
             po.wv[r] = nullptr;
-            po.wo[r] = h->P_(lp + "self_att.ff.weight");
+            po.wo[r] = h->T_(lp + "self_att.ff.weight");
             po.bo[r] = h->P_(lp + "self_att.ff.bias");
             po.g1[r] = h->P_(lp + "self_att.ln.weight");
             po.be1[r] = h->P_(lp + "self_att.ln.bias");
-            po.w1[r] = h->P_(lp + "ff.l1.weight");
+            po.w1[r] = h->T_(lp + "ff.l1.weight");
             po.b1[r] = h->P_(lp + "ff.l1.bias");
-            po.w2[r] = h->P_(lp + "ff.l2.weight");
+            po.w2[r] = h->T_(lp + "ff.l2.weight");
             po.b2[r] = h->P_(lp + "ff.l2.bias");
             po.g2[r] = h->P_(lp + "ff.ln.weight");
             po.be2[r] = h->P_(lp + "ff.ln.bias");
@@ -965,7 +999,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         LinArgs a;
         memset(&a, 0, sizeof a);
         a.x[0] = h->hin;
-        a.w[0] = h->P_("fc_head.0.weight");
+        a.w[0] = h->T_("fc_head.0.weight");
         a.b[0] = h->P_("fc_head.0.bias");
         a.y[0] = h->h1;
         a.xmap = identity_map();
@@ -1131,7 +1165,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
             smem = std::max(smem, attc_smem(c.n_bins[r], F, true));
             qb.dqt[r] = b.dqt;
             qb.dres[r] = b.dt1;
-            qb.wk[r] = prm[r].wk;
+            qb.wk[r] = prm[r].wk_t;     // NT product in the backward: tiled copy
             qb.wq[r] = prm[r].wq;
             qb.dq[r] = b.dq;
             qb.dx[r] = b.dx;
@@ -1368,10 +1402,19 @@ extern "C" int cf_launch_counts(cf_handle* h, int* fwd, int* bwd, int* opt) {
 // ------------------------------------------------------------------------------------
 extern "C" int cf_op_linear(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int relu, void* stream) {
     if (K % 128 || N % 32) return fail("cf_op_linear: K %% 128 == 0 and N %% 32 == 0 required");
+    // standalone use: build the tiled copy of W on the fly (test / micro-benchmark helper, synchronous)
+    std::vector<RetileUnit> units;
+    for (int n0 = 0; n0 < N; n0 += 16) units.push_back(RetileUnit{(long long)n0 * K, K});
+    float* Wt = nullptr;
+    RetileUnit* du = nullptr;
+    HIP_TRY(hipMalloc(&Wt, (size_t)N * K * sizeof(float)));
+    HIP_TRY(hipMalloc(&du, units.size() * sizeof(RetileUnit)));
+    HIP_TRY(hipMemcpy(du, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_retile, dim3((int)units.size()), dim3(256), 0, (hipStream_t)stream, W, Wt, (const RetileUnit*)du);
     LinArgs a;
     memset(&a, 0, sizeof a);
     a.x[0] = A;
-    a.w[0] = W;
+    a.w[0] = Wt;
     a.b[0] = bias;
     a.y[0] = C;
     a.xmap = identity_map();
@@ -1383,6 +1426,9 @@ extern "C" int cf_op_linear(const float* A, const float* W, const float* bias, f
     a.relu = relu;
     hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of(M), (N + 127) / 128, 1), dim3(256), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK("cf_op_linear");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipFree(Wt));
+    HIP_TRY(hipFree(du));
     return 0;
 }
 extern "C" int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream) {

@@ -78,13 +78,19 @@ __device__ __forceinline__ float group16_sum(float v) {
 // chunks -- typically before the barrier / LayerNorm that precedes the product -- and
 // frag_mma_*() runs the pipeline.
 
-// "NT" fragments: W row-major [n][ldw] (an nn.Linear weight), C = A . W^T.
-// Column map: col(t, r) = t*16 + r (contiguous 16-column tiles).  KS = K / 16.
+// "NT" fragments: C = A . W^T for an nn.Linear weight W[n][K].  Reading W row-major for the MFMA
+// B operand puts 16 different rows (cache lines) into every quarter-wave of a load, which the
+// texture addresser serialises: 15 B/clk/CU measured, half of what the matrix pipes consume
+// (tools/l2_stream_bench.hip).  The forward products therefore read a TILED copy of the weights
+// (k_retile, refreshed at the start of every forward): each 16(n) x 16(k) block is stored as 256
+// contiguous floats in fragment order [q][r][4], so a wave's load is one contiguous 1 KB
+// (55-60 B/clk/CU measured).  A sub-matrix starting at a row multiple of 16 has the same offset in
+// both layouts.  Column map: col(t, r) = t*16 + r.  KS = K / 16, ldw = K of the full tensor.
 template <int NT, int KS>
 struct FragNT {
     float4 ring[3][2][NT];
     const float* wp;
-    int ldw;
+    int tstride;      // floats between consecutive 16-row tiles: (ldw / 16) * 256
 };
 template <int NT, int KS>
 __device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS>& f, int slot, int chunk) {
@@ -92,14 +98,15 @@ __device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS>& f, int slot, int c
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            f.ring[slot][k][t] = *reinterpret_cast<const float4*>(f.wp + (size_t)t * 16 * f.ldw + (chunk * 2 + k) * 16);
+            f.ring[slot][k][t] = *reinterpret_cast<const float4*>(f.wp + (size_t)t * f.tstride + (chunk * 2 + k) * 256);
 }
+// Wt: TILED address of the first output row of this wave (row index a multiple of 16), plus
+// (k0 / 16) * 256 for a reduction offset k0; ldw: K of the full tensor.
 template <int NT, int KS>
-__device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __restrict__ W, int ldw) {
+__device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __restrict__ Wt, int ldw) {
     static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
-    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    f.wp = W + (size_t)r * ldw + q * 4;
-    f.ldw = ldw;
+    f.wp = Wt + (threadIdx.x & 63) * 4;
+    f.tstride = ldw * 16;
     frag_chunk_nt(f, 0, 0);
     frag_chunk_nt(f, 1, 1);
 }
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(LinArgs a) {
     int buf = 0;
     for (int kc = 0; kc < K; kc += kKChunk, buf ^= 1) {
         FragNT<NT, 8> f;
-        frag_load_nt(f, wp + kc, K);
+        frag_load_nt(f, wp + (size_t)kc * 16, K);     // tiled layout: reduction offset kc -> (kc/16)*256 floats
         load_tile(&xs[buf][0][0], kKChunk + 4, a.x[r] + kc, a.ldx, kKChunk, row0, a.N, a.xmap);
         __syncthreads();
         frag_mma_nt(f, &xs[buf][0][0], kKChunk + 4, acc);
@@ -1371,6 +1378,24 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     }
 }
 
+
+// =======================================================================================
+// Tiled copy of the Linear weights for the forward ("NT") products -- see FragNT.
+// One workgroup per 16-row unit of a tensor.
+// =======================================================================================
+struct RetileUnit {
+    long long off;     // float offset of the unit's first row in the flat parameter buffer
+    int K;             // row length of the tensor
+};
+__global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params, float* __restrict__ tiled,
+                                                const RetileUnit* __restrict__ units) {
+    const RetileUnit u = units[blockIdx.x];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* src = params + u.off + (size_t)r * u.K + q * 4;
+    float* dst = tiled + u.off + lane * 4;
+    for (int kt = w; kt < u.K / 16; kt += 4)
+        *reinterpret_cast<float4*>(dst + (size_t)kt * 256) = *reinterpret_cast<const float4*>(src + kt * 16);
+}
 }  // namespace cf
 
 #include "cf_reg_fused.h"

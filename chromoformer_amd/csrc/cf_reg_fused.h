@@ -11,6 +11,7 @@ namespace cf {
 
 struct RegLayerDev {
     const float *watt, *gamma, *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
+    const float *watt_t, *wo_t, *w1_t, *w2_t;      // tiled copies (forward products)
     float *xin, *qkvg, *p, *a, *xh1, *rs1, *y1, *hdn, *xh2, *rs2, *xout;
     float *dxout, *dt2, *dpre1, *dt1, *da, *dqkvg, *dxin, *partial, *dgam;
 };
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         }
     }
     FragNT<4, 8> fa, fb;
-    frag_load_nt(fa, tab[0].watt + (size_t)(w * 256) * kD, kD);
+    frag_load_nt(fa, tab[0].watt_t + (size_t)(w * 256) * kD, kD);
     __syncthreads();
     for (int l = 0; l < a.n_layers; ++l) {
         const RegLayerDev P = tab[l];      // by value: the pointers live in SGPRs (no reload after every store)
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         for (int c = 0; c < 4; ++c) {
             FragNT<4, 8>& cur = (c & 1) ? fb : fa;
             FragNT<4, 8>& nxt = (c & 1) ? fa : fb;
-            if (c < 3) frag_load_nt(nxt, P.watt + (size_t)(w * 256 + (c + 1) * 64) * kD, kD);
+            if (c < 3) frag_load_nt(nxt, P.watt_t + (size_t)(w * 256 + (c + 1) * 64) * kD, kD);
             f32x4 acc[4];
             zero_acc(acc);
             frag_mma_nt(cur, xs, LD, acc);
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
                 }
         }
         FragNT<2, kRDm / 16> fo;       // out-projection weights: in flight during the attention
-        frag_load_nt(fo, P.wo + (size_t)(w * 32) * kRDm, kRDm);
+        frag_load_nt(fo, P.wo_t + (size_t)(w * 32) * kRDm, kRDm);
         CF_STAMP(1);
         __syncthreads();
         CF_STAMP(2);
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         }
         constexpr int NT1 = DFF / 64;
         FragNT<NT1, 8> f1;
-        frag_load_nt(f1, P.w1 + (size_t)(w * (DFF / 4)) * kD, kD);
+        frag_load_nt(f1, P.w1_t + (size_t)(w * (DFF / 4)) * kD, kD);
         CF_STAMP(7);
         __syncthreads();
         ln_fwd_rows(ts, LD, P.g1, P.be1, row0, T, a.save ? P.xh1 : nullptr, P.rs1, a.save ? P.y1 : nullptr, identity_map());
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
                 }
         }
         FragNT<2, DFF / 16> f2;
-        frag_load_nt(f2, P.w2 + (size_t)(w * 32) * DFF, DFF);
+        frag_load_nt(f2, P.w2_t + (size_t)(w * 32) * DFF, DFF);
         CF_STAMP(9);
         __syncthreads();
         {
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
                     xs[row * LD + col] = acc[t][i] + P.b2[col] + ts[row * LD + col];
                 }
         }
-        if (l + 1 < a.n_layers) frag_load_nt(fa, tab[l + 1].watt + (size_t)(w * 256) * kD, kD);   // next layer, chunk 0
+        if (l + 1 < a.n_layers) frag_load_nt(fa, tab[l + 1].watt_t + (size_t)(w * 256) * kD, kD);   // next layer, chunk 0
         CF_STAMP(10);
         __syncthreads();
         ln_fwd_rows(xs, LD, P.g2, P.be2, row0, T, a.save ? P.xh2 : nullptr, P.rs2, P.xout, identity_map());
