@@ -1063,7 +1063,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         for (int r = 0; r < nres; ++r) ra.mask[r] = bt->interaction_mask[r];
         ra.freq = bt->interaction_freq;
         ra.save = 1;
-        ra.tdbg = nullptr;
+        ra.tdbg = getenv("CF_STAMP_BWD") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
         if (c.reg_dff == 128) hipLaunchKernelGGL((k_reg_bwd<128>), dim3(B, nres), dim3(256), reg_bwd_smem(T), st, ra);
         else hipLaunchKernelGGL((k_reg_bwd<256>), dim3(B, nres), dim3(256), reg_bwd_smem(T), st, ra);
         LAUNCH_CHECK("k_reg_bwd");

@@ -86,9 +86,10 @@ __device__ __forceinline__ float group16_sum(float v) {
 // contiguous floats in fragment order [q][r][4], so a wave's load is one contiguous 1 KB
 // (55-60 B/clk/CU measured).  A sub-matrix starting at a row multiple of 16 has the same offset in
 // both layouts.  Column map: col(t, r) = t*16 + r.  KS = K / 16, ldw = K of the full tensor.
+constexpr int kRing = 4;      // register ring slots: chunks c+1 .. c+kRing-1 are in flight while chunk c is multiplied
 template <int NT, int KS>
 struct FragNT {
-    float4 ring[3][2][NT];
+    float4 ring[kRing][2][NT];
     const float* wp;
     int tstride;      // floats between consecutive 16-row tiles: (ldw / 16) * 256
 };
@@ -107,8 +108,9 @@ __device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __r
     static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
     f.wp = Wt + (threadIdx.x & 63) * 4;
     f.tstride = ldw * 16;
-    frag_chunk_nt(f, 0, 0);
-    frag_chunk_nt(f, 1, 1);
+#pragma unroll
+    for (int c = 0; c < kRing - 1; ++c)
+        if (c < KS / 2) frag_chunk_nt(f, c, c);
 }
 template <int NT, int KS>
 __device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
@@ -117,13 +119,13 @@ __device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, 
     constexpr int NC = KS / 2;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (c + 2 < NC) frag_chunk_nt(f, (c + 2) % 3, c + 2);
+        if (c + kRing - 1 < NC) frag_chunk_nt(f, (c + kRing - 1) % kRing, c + kRing - 1);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float4 b = f.ring[c % 3][k][t];
+                const float4 b = f.ring[c % kRing][k][t];
                 acc[t] = mfma4(a.x, b.x, acc[t]);
                 acc[t] = mfma4(a.y, b.y, acc[t]);
                 acc[t] = mfma4(a.z, b.z, acc[t]);
@@ -149,7 +151,7 @@ struct VecN<4> {
 };
 template <int NT, int KS>
 struct FragNN {
-    typename VecN<NT>::type ring[3][2][4];
+    typename VecN<NT>::type ring[kRing][2][4];
     const float* bp;
     int ldb;
 };
@@ -167,8 +169,9 @@ __device__ __forceinline__ void frag_load_nn(FragNN<NT, KS>& f, const float* __r
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     f.bp = Bm + (size_t)(q * 4) * ldb + NT * r;
     f.ldb = ldb;
-    frag_chunk_nn(f, 0, 0);
-    frag_chunk_nn(f, 1, 1);
+#pragma unroll
+    for (int c = 0; c < kRing - 1; ++c)
+        if (c < KS / 2) frag_chunk_nn(f, c, c);
 }
 template <int NT, int KS>
 __device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
@@ -177,14 +180,14 @@ __device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, 
     constexpr int NC = KS / 2;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (c + 2 < NC) frag_chunk_nn(f, (c + 2) % 3, c + 2);
+        if (c + kRing - 1 < NC) frag_chunk_nn(f, (c + kRing - 1) % kRing, c + kRing - 1);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float* bv = reinterpret_cast<const float*>(&f.ring[c % 3][k][i]);
+                const float* bv = reinterpret_cast<const float*>(&f.ring[c % kRing][k][i]);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = mfma4(av[i], bv[t], acc[t]);
             }
@@ -230,6 +233,38 @@ __device__ __forceinline__ void ln_fwd_rows(float* ts, int ld, const float* __re
         const float rstd = 1.0f / sqrtf(var + kLnEps);
         const float x0 = d0 * rstd, x1 = d1 * rstd;
         const float y0 = x0 * g0 + b0, y1 = x1 * g1 + b1;
+        ts[row * ld + lane] = y0;
+        ts[row * ld + lane + 64] = y1;
+        const int n = row0 + row;
+        if (row < nvalid) {
+            if (xhat_g) {
+                xhat_g[(size_t)n * kD + lane] = x0;
+                xhat_g[(size_t)n * kD + lane + 64] = x1;
+                if (lane == 0) rstd_g[n] = rstd;
+            }
+            if (y_g) {
+                const size_t o = (size_t)map_row(ymap, n) * kD;
+                y_g[o + lane] = y0;
+                y_g[o + lane + 64] = y1;
+            }
+        }
+    }
+}
+
+// same, with the lane's four LayerNorm parameters {g[lane], g[lane+64], b[lane], b[lane+64]} already in registers
+__device__ __forceinline__ void ln_fwd_rows_r(float* ts, int ld, const float (&gb)[4], int row0, int nvalid, float* xhat_g,
+                                              float* rstd_g, float* y_g, const RowMap& ymap) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = w * 4 + rr;
+        const float v0 = ts[row * ld + lane], v1 = ts[row * ld + lane + 64];
+        const float mean = wave_sum(v0 + v1) * (1.0f / kD);
+        const float d0 = v0 - mean, d1 = v1 - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / kD);
+        const float rstd = 1.0f / sqrtf(var + kLnEps);
+        const float x0 = d0 * rstd, x1 = d1 * rstd;
+        const float y0 = x0 * gb[0] + gb[2], y1 = x1 * gb[1] + gb[3];
         ts[row * ld + lane] = y0;
         ts[row * ld + lane + 64] = y1;
         const int n = row0 + row;

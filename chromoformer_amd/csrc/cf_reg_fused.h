@@ -67,28 +67,62 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
             mk_s[i] = a.mask[r][(size_t)g * TT + i] ? 1.f : 0.f;
         }
     }
-    FragNT<4, 8> fa, fb;
-    frag_load_nt(fa, tab[0].watt_t + (size_t)(w * 256) * kD, kD);
+    for (int i = tid; i < (kTile - T) * LW; i += 256) as_[T * LW + i] = 0.f;      // dead rows of the attention output
+    // q|k|v|gate projection: one operand ring for the whole [16 x 1024] product.  Step i = (column
+    // chunk i/4 of 64 columns, K-chunk i%4 of 32); the ring runs 3 steps ahead and across layers.
+    float4 qring[kRing][2][4];
+    auto qfetch = [&](int slot, int step, const float* watt_t) {
+        const float* base = watt_t + (size_t)(w * 256 + (step >> 2) * 64) * kD + (step & 3) * 512 + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) qring[slot][k][t] = *reinterpret_cast<const float4*>(base + (size_t)t * (kD * 16) + k * 256);
+    };
+#pragma unroll
+    for (int i = 0; i < kRing - 1; ++i) qfetch(i, i, tab[0].watt_t);
     __syncthreads();
     for (int l = 0; l < a.n_layers; ++l) {
         const RegLayerDev P = tab[l];      // by value: the pointers live in SGPRs (no reload after every store)
         CF_STAMP(0);
-        // ---- q|k|v|gate projection: wave w owns columns [w*256, w*256+256) in 4 chunks of 64
+        // per-lane copies of the small vectors of this layer (their latency hides behind the projection)
+        const float bo0 = P.bo[w * 32 + lr], bo1 = P.bo[w * 32 + 16 + lr];
+        const float b20 = P.b2[w * 32 + lr], b21 = P.b2[w * 32 + 16 + lr];
+        float b1v[DFF / 64];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            FragNT<4, 8>& cur = (c & 1) ? fb : fa;
-            FragNT<4, 8>& nxt = (c & 1) ? fa : fb;
-            if (c < 3) frag_load_nt(nxt, P.watt_t + (size_t)(w * 256 + (c + 1) * 64) * kD, kD);
+        for (int t = 0; t < DFF / 64; ++t) b1v[t] = P.b1[w * (DFF / 4) + t * 16 + lr];
+        const float ln1[4] = {P.g1[lane], P.g1[lane + 64], P.be1[lane], P.be1[lane + 64]};
+        const float ln2[4] = {P.g2[lane], P.g2[lane + 64], P.be2[lane], P.be2[lane + 64]};
+        float gam = 0.f;
+        if (lane < kRH) gam = P.gamma[lane];
+        {
             f32x4 acc[4];
-            zero_acc(acc);
-            frag_mma_nt(cur, xs, LD, acc);
+            const float* ap = xs + lr * LD + lq * 4;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int i = 0; i < 16; ++i) {
+                if (i + kRing - 1 < 16) qfetch((i + kRing - 1) % kRing, i + kRing - 1, P.watt_t);
+                if ((i & 3) == 0) zero_acc(acc);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = lq * 4 + i, col = w * 256 + c * 64 + col_nt(t, lr);
-                    if (row < T) qk[row * kQkLd + col] = acc[t][i];
+                for (int k = 0; k < 2; ++k) {
+                    const float4 av = *reinterpret_cast<const float4*>(ap + ((i & 3) * 2 + k) * 16);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 b = qring[i % kRing][k][t];
+                        acc[t] = mfma4(av.x, b.x, acc[t]);
+                        acc[t] = mfma4(av.y, b.y, acc[t]);
+                        acc[t] = mfma4(av.z, b.z, acc[t]);
+                        acc[t] = mfma4(av.w, b.w, acc[t]);
+                    }
                 }
+                if ((i & 3) == 3) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const int row = lq * 4 + ii, col = w * 256 + (i >> 2) * 64 + col_nt(t, lr);
+                            if (row < T) qk[row * kQkLd + col] = acc[t][ii];
+                        }
+                }
+            }
         }
         FragNT<2, kRDm / 16> fo;       // out-projection weights: in flight during the attention
         frag_load_nt(fo, P.wo_t + (size_t)(w * 32) * kRDm, kRDm);
@@ -102,55 +136,49 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
                 *reinterpret_cast<float4*>(qg + (size_t)row * kRW + c4 * 4) = *reinterpret_cast<const float4*>(qk + row * kQkLd + c4 * 4);
             }
         }
-        // ---- attention (modules.py:58-81)
-        for (int idx = tid; idx < kRH * TT; idx += 256) {
-            const int h = idx / TT, ij = idx - h * TT, i = ij / T, j = ij - i * T;
-            const float4* qp = reinterpret_cast<const float4*>(qk + i * kQkLd + h * kRDh);
-            const float4* kp = reinterpret_cast<const float4*>(qk + j * kQkLd + kRDm + h * kRDh);
-            float sc = 0.f;
+        // ---- attention (modules.py:58-81): 16 lanes per (head, query) row, lane j = key
+        for (int row = tid >> 4; row < kRH * T; row += 16) {
+            const int h = row / T, i = row - h * T, j = tid & 15;
+            float sc = -INFINITY;
+            if (j < T) {
+                const float4* qp = reinterpret_cast<const float4*>(qk + i * kQkLd + h * kRDh);
+                const float4* kp = reinterpret_cast<const float4*>(qk + j * kQkLd + kRDm + h * kRDh);
+                float d = 0.f;
 #pragma unroll
-            for (int d = 0; d < kRDh / 4; ++d) {
-                const float4 qv = qp[d], kv = kp[d];
-                sc = fmaf(qv.x, kv.x, sc);
-                sc = fmaf(qv.y, kv.y, sc);
-                sc = fmaf(qv.z, kv.z, sc);
-                sc = fmaf(qv.w, kv.w, sc);
+                for (int e = 0; e < kRDh / 4; ++e) {
+                    const float4 qv = qp[e], kv = kp[e];
+                    d = fmaf(qv.x, kv.x, d);
+                    d = fmaf(qv.y, kv.y, d);
+                    d = fmaf(qv.z, kv.z, d);
+                    d = fmaf(qv.w, kv.w, d);
+                }
+                sc = d / scale + __shfl(gam, h, 64) * fq_s[i * T + j];
+                if (mk_s[i * T + j] != 0.f) sc = kMaskFill;
+            } else {
+                (void)__shfl(gam, h, 64);
             }
-            sc = sc / scale + P.gamma[h] * fq_s[ij];
-            if (mk_s[ij] != 0.f) sc = kMaskFill;
-            p_s[idx] = sc;
+            float m = sc;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float e = j < T ? expf(sc - m) : 0.f;
+            const float z = group16_sum(e);
+            if (j < T) p_s[row * T + j] = e / z;
         }
         CF_STAMP(3);
-        __syncthreads();
-        for (int row = tid; row < kRH * T; row += 256) {
-            float* pr = p_s + row * T;
-            float m = -INFINITY;
-            for (int j = 0; j < T; ++j) m = fmaxf(m, pr[j]);
-            float z = 0.f;
-            for (int j = 0; j < T; ++j) {
-                const float e = expf(pr[j] - m);
-                pr[j] = e;
-                z += e;
-            }
-            for (int j = 0; j < T; ++j) pr[j] = pr[j] / z;
-        }
         CF_STAMP(4);
         __syncthreads();
         if (a.save) {
             float* pg = P.p + (size_t)g * kRH * TT;
             for (int i = tid; i < kRH * TT; i += 256) pg[i] = p_s[i];
         }
-        for (int idx = tid; idx < kTile * kRDm; idx += 256) {
+        for (int idx = tid; idx < T * kRDm; idx += 256) {
             const int i = idx >> 8, c = idx & 255, h = c >> 5;
-            float v = 0.f;
-            if (i < T) {
-                const float* pr = p_s + (h * T + i) * T;
-                float o = 0.f;
-                for (int j = 0; j < T; ++j) o = fmaf(pr[j], qk[j * kQkLd + 2 * kRDm + c], o);
-                const float gt = qk[i * kQkLd + 3 * kRDm + c];
-                v = o * (1.0f / (1.0f + expf(-gt)));
-                if (a.save) P.a[(size_t)(row0 + i) * kRDm + c] = v;
-            }
+            const float* pr = p_s + (h * T + i) * T;
+            float o = 0.f;
+            for (int j = 0; j < T; ++j) o = fmaf(pr[j], qk[j * kQkLd + 2 * kRDm + c], o);
+            const float gt = qk[i * kQkLd + 3 * kRDm + c];
+            const float v = o * (1.0f / (1.0f + expf(-gt)));
+            if (a.save) P.a[(size_t)(row0 + i) * kRDm + c] = v;
             as_[i * LW + c] = v;
         }
         CF_STAMP(5);
@@ -166,7 +194,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
-                    ts[row * LD + col] = acc[t][i] + P.bo[col] + xs[row * LD + col];
+                    ts[row * LD + col] = acc[t][i] + (t ? bo1 : bo0) + xs[row * LD + col];
                 }
         }
         constexpr int NT1 = DFF / 64;
@@ -174,7 +202,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         frag_load_nt(f1, P.w1_t + (size_t)(w * (DFF / 4)) * kD, kD);
         CF_STAMP(7);
         __syncthreads();
-        ln_fwd_rows(ts, LD, P.g1, P.be1, row0, T, a.save ? P.xh1 : nullptr, P.rs1, a.save ? P.y1 : nullptr, identity_map());
+        ln_fwd_rows_r(ts, LD, ln1, row0, T, a.save ? P.xh1 : nullptr, P.rs1, a.save ? P.y1 : nullptr, identity_map());
         CF_STAMP(8);
         __syncthreads();
         {
@@ -186,7 +214,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = lq * 4 + i, col = w * (DFF / 4) + col_nt(t, lr);
-                    const float v = fmaxf(acc[t][i] + P.b1[col], 0.f);
+                    const float v = fmaxf(acc[t][i] + b1v[t], 0.f);
                     hs[row * LW + col] = v;
                     if (a.save && row < T) P.hdn[(size_t)(row0 + row) * DFF + col] = v;
                 }
@@ -204,13 +232,16 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
-                    xs[row * LD + col] = acc[t][i] + P.b2[col] + ts[row * LD + col];
+                    xs[row * LD + col] = acc[t][i] + (t ? b21 : b20) + ts[row * LD + col];
                 }
         }
-        if (l + 1 < a.n_layers) frag_load_nt(fa, tab[l + 1].watt_t + (size_t)(w * 256) * kD, kD);   // next layer, chunk 0
+        if (l + 1 < a.n_layers) {                 // first operand chunks of the next layer's projection
+#pragma unroll
+            for (int i = 0; i < kRing - 1; ++i) qfetch(i, i, tab[l + 1].watt_t);
+        }
         CF_STAMP(10);
         __syncthreads();
-        ln_fwd_rows(xs, LD, P.g2, P.be2, row0, T, a.save ? P.xh2 : nullptr, P.rs2, P.xout, identity_map());
+        ln_fwd_rows_r(xs, LD, ln2, row0, T, a.save ? P.xh2 : nullptr, P.rs2, P.xout, identity_map());
         CF_STAMP(11);
         __syncthreads();
     }
@@ -253,6 +284,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
     for (int l = a.n_layers - 1; l >= 0; --l) {
         const RegLayerDev P = tab[l];
         float* part = P.partial + (size_t)g * PW;
+        CF_STAMP(0);
         FragNN<NT2, 8> fw2;
         frag_load_nn(fw2, P.w2 + w * (DFF / 4), DFF);
         load_rows(xh, P.xh2);
@@ -261,7 +293,9 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         colsum16(ds, LD, nullptr, 0, kD, part + 128);
         for (int i = tid; i < kTile * kD; i += 256) t2[(i >> 7) * LD + (i & 127)] = ds[(i >> 7) * LD + (i & 127)];
         __syncthreads();
+        CF_STAMP(1);
         ln_bwd_rows(t2, LD, xh, LD, P.g2, P.rs2, row0, T, P.dt2);
+        CF_STAMP(2);
         FragNN<2, DFF / 16> fw1;
         frag_load_nn(fw1, P.w1 + w * 32, kD);
         __syncthreads();
@@ -288,6 +322,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
                 *reinterpret_cast<vec_t*>(wide + row * LW + col) = *reinterpret_cast<const vec_t*>(v);
             }
         }
+        CF_STAMP(3);
         load_rows(xh, P.xh1);
         FragNN<4, 8> fwo;
         frag_load_nn(fwo, P.wo + w * (kRDm / 4), kRDm);
@@ -305,10 +340,12 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
             }
         }
         __syncthreads();
+        CF_STAMP(4);
         colsum16(ds, LD, xh, LD, kD, part + 384 + DFF);
         colsum16(ds, LD, nullptr, 0, kD, part + 512 + DFF);
         __syncthreads();
         ln_bwd_rows(ds, LD, xh, LD, P.g1, P.rs1, row0, T, P.dt1);       // ds = dt1
+        CF_STAMP(5);
         // operands of the attention backward: in flight during the out-projection product
         {
             const float* qg = P.qkvg + (size_t)row0 * kRW;
@@ -333,9 +370,11 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
                 if (row < T) *reinterpret_cast<float4*>(P.da + (size_t)(row0 + row) * kRDm + col) = v;
             }
         }
+        CF_STAMP(6);
         FragNN<2, 16> fda, fdb;           // first K-chunk of the input-gradient product
         frag_load_nn(fda, P.watt + w * 32, kD);
         __syncthreads();
+        CF_STAMP(7);
         // ---- attention backward (gate, value, softmax, score sides)
         for (int idx = tid; idx < T * kRDm; idx += 256) {
             const int i = idx >> 8, c = idx & 255, h = c >> 5;
@@ -349,6 +388,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
             dqk[i * kQkLd + 3 * kRDm + c] = da * o * sg * (1.0f - sg);
         }
         __syncthreads();
+        CF_STAMP(8);
         for (int idx = tid; idx < kRH * TT; idx += 256) {
             const int h = idx / TT, ij = idx - h * TT, i = ij / T, j = ij - i * T;
             const float4* dp = reinterpret_cast<const float4*>(do_s + i * kRDm + h * kRDh);
@@ -365,6 +405,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
             s_s[idx] = sc;
         }
         __syncthreads();
+        CF_STAMP(9);
         for (int row = tid; row < kRH * T; row += 256) {
             const float* pr = p_s + row * T;
             float* dr = s_s + row * T;
@@ -380,6 +421,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
             red_s[row] = gsum;
         }
         __syncthreads();
+        CF_STAMP(10);
         if (tid < kRH) {
             float sm = 0.f;
             for (int i = 0; i < T; ++i) sm += red_s[tid * T + i];
@@ -405,6 +447,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
                 *reinterpret_cast<float4*>(dg + (size_t)row * kRW + c4 * 4) = *reinterpret_cast<const float4*>(dqk + row * kQkLd + c4 * 4);
             }
         }
+        CF_STAMP(11);
         // ---- d(layer input) = dt1 + dqkvg Watt   (K = 1024 in four chunks)
         {
             f32x4 acc[2];
@@ -425,6 +468,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
                 if (row < T) *reinterpret_cast<float2*>(P.dxin + (size_t)(row0 + row) * kD + col) = make_float2(v0, v1);
             }
         }
+        CF_STAMP(12);
         __syncthreads();
     }
 }
