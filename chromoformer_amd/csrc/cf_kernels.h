@@ -40,6 +40,39 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Explicit global-address-space accesses.  A pointer that was itself loaded from memory (a table
+// entry, a by-value struct copied through registers) is "generic" to the compiler, which then emits
+// flat_load/flat_store: those tick BOTH vmcnt and lgkmcnt, so every wait around them degenerates to
+// vmcnt(0) lgkmcnt(0) and no load can stay in flight across an LDS access.  These helpers pin the
+// address space so that global_load/global_store are emitted.
+#define CF_GLOBAL __attribute__((address_space(1)))
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ldg(const float* p) { return *(const CF_GLOBAL float*)(p); }
+__device__ __forceinline__ float2 ldg2(const float* p) {
+    const v2f v = *(const CF_GLOBAL v2f*)(p);
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    const v4f v = *(const CF_GLOBAL v4f*)(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stg(float* p, float v) { *(CF_GLOBAL float*)(p) = v; }
+__device__ __forceinline__ void stg2(float* p, float2 v) { *(CF_GLOBAL v2f*)(p) = v2f{v.x, v.y}; }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *(CF_GLOBAL v4f*)(p) = v4f{v.x, v.y, v.z, v.w}; }
+template <int NT>
+struct LdgN;
+template <>
+struct LdgN<2> {
+    static __device__ __forceinline__ float2 ld(const float* p) { return ldg2(p); }
+    static __device__ __forceinline__ void st(float* p, float2 v) { stg2(p, v); }
+};
+template <>
+struct LdgN<4> {
+    static __device__ __forceinline__ float4 ld(const float* p) { return ldg4(p); }
+    static __device__ __forceinline__ void st(float* p, float4 v) { stg4(p, v); }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -99,7 +132,7 @@ __device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS>& f, int slot, int c
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            f.ring[slot][k][t] = *reinterpret_cast<const float4*>(f.wp + (size_t)t * f.tstride + (chunk * 2 + k) * 256);
+            f.ring[slot][k][t] = ldg4(f.wp + (size_t)t * f.tstride + (chunk * 2 + k) * 256);
 }
 // Wt: TILED address of the first output row of this wave (row index a multiple of 16), plus
 // (k0 / 16) * 256 for a reduction offset k0; ldw: K of the full tensor.
@@ -111,6 +144,7 @@ __device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __r
 #pragma unroll
     for (int c = 0; c < kRing - 1; ++c)
         if (c < KS / 2) frag_chunk_nt(f, c, c);
+    __builtin_amdgcn_sched_barrier(0);
 }
 template <int NT, int KS>
 __device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
@@ -120,6 +154,7 @@ __device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, 
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c + kRing - 1 < NC) frag_chunk_nt(f, (c + kRing - 1) % kRing, c + kRing - 1);
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
@@ -161,7 +196,7 @@ __device__ __forceinline__ void frag_chunk_nn(FragNN<NT, KS>& f, int slot, int c
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            f.ring[slot][k][i] = *reinterpret_cast<const typename VecN<NT>::type*>(f.bp + (size_t)((chunk * 2 + k) * 16 + i) * f.ldb);
+            f.ring[slot][k][i] = LdgN<NT>::ld(f.bp + (size_t)((chunk * 2 + k) * 16 + i) * f.ldb);
 }
 template <int NT, int KS>
 __device__ __forceinline__ void frag_load_nn(FragNN<NT, KS>& f, const float* __restrict__ Bm, int ldb) {
@@ -172,6 +207,7 @@ __device__ __forceinline__ void frag_load_nn(FragNN<NT, KS>& f, const float* __r
 #pragma unroll
     for (int c = 0; c < kRing - 1; ++c)
         if (c < KS / 2) frag_chunk_nn(f, c, c);
+    __builtin_amdgcn_sched_barrier(0);
 }
 template <int NT, int KS>
 __device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
@@ -181,6 +217,7 @@ __device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, 
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c + kRing - 1 < NC) frag_chunk_nn(f, (c + kRing - 1) % kRing, c + kRing - 1);
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
@@ -210,7 +247,7 @@ __device__ __forceinline__ void load_tile(float* dst, int ldd, const float* __re
     for (int i = threadIdx.x; i < kTile * c4n; i += blockDim.x) {
         const int rr = i / c4n, c4 = i - rr * c4n;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + rr < nrows) v = *reinterpret_cast<const float4*>(src + (size_t)map_row(map, row0 + rr) * lds_ + c4 * 4);
+        if (row0 + rr < nrows) v = ldg4(src + (size_t)map_row(map, row0 + rr) * lds_ + c4 * 4);
         *reinterpret_cast<float4*>(dst + rr * ldd + c4 * 4) = v;
     }
 }
@@ -222,7 +259,7 @@ __device__ __forceinline__ void ln_fwd_rows(float* ts, int ld, const float* __re
                                             int row0, int nvalid, float* xhat_g, float* rstd_g, float* y_g,
                                             const RowMap& ymap) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float g0 = g[lane], g1 = g[lane + 64], b0 = b[lane], b1 = b[lane + 64];
+    const float g0 = ldg(g + lane), g1 = ldg(g + lane + 64), b0 = ldg(b + lane), b1 = ldg(b + lane + 64);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int row = w * 4 + rr;
@@ -238,14 +275,14 @@ __device__ __forceinline__ void ln_fwd_rows(float* ts, int ld, const float* __re
         const int n = row0 + row;
         if (row < nvalid) {
             if (xhat_g) {
-                xhat_g[(size_t)n * kD + lane] = x0;
-                xhat_g[(size_t)n * kD + lane + 64] = x1;
-                if (lane == 0) rstd_g[n] = rstd;
+                stg(xhat_g + (size_t)n * kD + lane, x0);
+                stg(xhat_g + (size_t)n * kD + lane + 64, x1);
+                if (lane == 0) stg(rstd_g + n, rstd);
             }
             if (y_g) {
                 const size_t o = (size_t)map_row(ymap, n) * kD;
-                y_g[o + lane] = y0;
-                y_g[o + lane + 64] = y1;
+                stg(y_g + o + lane, y0);
+                stg(y_g + o + lane + 64, y1);
             }
         }
     }
@@ -270,14 +307,14 @@ __device__ __forceinline__ void ln_fwd_rows_r(float* ts, int ld, const float (&g
         const int n = row0 + row;
         if (row < nvalid) {
             if (xhat_g) {
-                xhat_g[(size_t)n * kD + lane] = x0;
-                xhat_g[(size_t)n * kD + lane + 64] = x1;
-                if (lane == 0) rstd_g[n] = rstd;
+                stg(xhat_g + (size_t)n * kD + lane, x0);
+                stg(xhat_g + (size_t)n * kD + lane + 64, x1);
+                if (lane == 0) stg(rstd_g + n, rstd);
             }
             if (y_g) {
                 const size_t o = (size_t)map_row(ymap, n) * kD;
-                y_g[o + lane] = y0;
-                y_g[o + lane + 64] = y1;
+                stg(y_g + o + lane, y0);
+                stg(y_g + o + lane + 64, y1);
             }
         }
     }
@@ -288,7 +325,7 @@ __device__ __forceinline__ void ln_fwd_rows_r(float* ts, int ld, const float (&g
 __device__ __forceinline__ void ln_bwd_rows(float* dys, int ld, const float* xh, int ldx, const float* __restrict__ g,
                                             const float* __restrict__ rstd_g, int row0, int nvalid, float* dx_g) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float g0 = g[lane], g1 = g[lane + 64];
+    const float g0 = ldg(g + lane), g1 = ldg(g + lane + 64);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int row = w * 4 + rr, n = row0 + row;
@@ -296,13 +333,13 @@ __device__ __forceinline__ void ln_bwd_rows(float* dys, int ld, const float* xh,
         const float x0 = xh[row * ldx + lane], x1 = xh[row * ldx + lane + 64];
         const float m1 = wave_sum(a0 + a1) * (1.0f / kD);
         const float m2 = wave_sum(a0 * x0 + a1 * x1) * (1.0f / kD);
-        const float rs = (row < nvalid) ? rstd_g[n] : 0.f;
+        const float rs = (row < nvalid) ? ldg(rstd_g + n) : 0.f;
         const float o0 = rs * (a0 - m1 - x0 * m2), o1 = rs * (a1 - m1 - x1 * m2);
         dys[row * ld + lane] = o0;
         dys[row * ld + lane + 64] = o1;
         if (row < nvalid) {
-            dx_g[(size_t)n * kD + lane] = o0;
-            dx_g[(size_t)n * kD + lane + 64] = o1;
+            stg(dx_g + (size_t)n * kD + lane, o0);
+            stg(dx_g + (size_t)n * kD + lane + 64, o1);
         }
     }
 }
@@ -313,7 +350,7 @@ __device__ __forceinline__ void colsum16(const float* A, int lda, const float* B
         float s = 0.f;
 #pragma unroll
         for (int rr = 0; rr < kTile; ++rr) s += Bt ? A[rr * lda + c] * Bt[rr * ldb + c] : A[rr * lda + c];
-        out[c] = s;
+        stg(out + c, s);
     }
 }
 

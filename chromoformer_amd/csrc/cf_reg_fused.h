@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         for (int i = tid; i < kTile * (kD / 4); i += 256) {
             const int row = i >> 5, c4 = i & 31;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < T) v = *reinterpret_cast<const float4*>(x0 + row * kD + c4 * 4);
+            if (row < T) v = ldg4(x0 + row * kD + c4 * 4);
             *reinterpret_cast<float4*>(xs + row * LD + c4 * 4) = v;
         }
         for (int i = tid; i < TT; i += 256) {
-            fq_s[i] = a.freq[(size_t)g * TT + i];
-            mk_s[i] = a.mask[r][(size_t)g * TT + i] ? 1.f : 0.f;
+            fq_s[i] = ldg(a.freq + (size_t)g * TT + i);
+            mk_s[i] = *(const CF_GLOBAL uint8_t*)(a.mask[r] + (size_t)g * TT + i) ? 1.f : 0.f;
         }
     }
     for (int i = tid; i < (kTile - T) * LW; i += 256) as_[T * LW + i] = 0.f;      // dead rows of the attention output
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) qring[slot][k][t] = *reinterpret_cast<const float4*>(base + (size_t)t * (kD * 16) + k * 256);
+            for (int t = 0; t < 4; ++t) qring[slot][k][t] = ldg4(base + (size_t)t * (kD * 16) + k * 256);
     };
 #pragma unroll
     for (int i = 0; i < kRing - 1; ++i) qfetch(i, i, tab[0].watt_t);
@@ -85,21 +85,22 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         const RegLayerDev P = tab[l];      // by value: the pointers live in SGPRs (no reload after every store)
         CF_STAMP(0);
         // per-lane copies of the small vectors of this layer (their latency hides behind the projection)
-        const float bo0 = P.bo[w * 32 + lr], bo1 = P.bo[w * 32 + 16 + lr];
-        const float b20 = P.b2[w * 32 + lr], b21 = P.b2[w * 32 + 16 + lr];
+        const float bo0 = ldg(P.bo + w * 32 + lr), bo1 = ldg(P.bo + w * 32 + 16 + lr);
+        const float b20 = ldg(P.b2 + w * 32 + lr), b21 = ldg(P.b2 + w * 32 + 16 + lr);
         float b1v[DFF / 64];
 #pragma unroll
-        for (int t = 0; t < DFF / 64; ++t) b1v[t] = P.b1[w * (DFF / 4) + t * 16 + lr];
-        const float ln1[4] = {P.g1[lane], P.g1[lane + 64], P.be1[lane], P.be1[lane + 64]};
-        const float ln2[4] = {P.g2[lane], P.g2[lane + 64], P.be2[lane], P.be2[lane + 64]};
+        for (int t = 0; t < DFF / 64; ++t) b1v[t] = ldg(P.b1 + w * (DFF / 4) + t * 16 + lr);
+        const float ln1[4] = {ldg(P.g1 + lane), ldg(P.g1 + lane + 64), ldg(P.be1 + lane), ldg(P.be1 + lane + 64)};
+        const float ln2[4] = {ldg(P.g2 + lane), ldg(P.g2 + lane + 64), ldg(P.be2 + lane), ldg(P.be2 + lane + 64)};
         float gam = 0.f;
-        if (lane < kRH) gam = P.gamma[lane];
+        if (lane < kRH) gam = ldg(P.gamma + lane);
         {
             f32x4 acc[4];
             const float* ap = xs + lr * LD + lq * 4;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (i + kRing - 1 < 16) qfetch((i + kRing - 1) % kRing, i + kRing - 1, P.watt_t);
+                __builtin_amdgcn_sched_barrier(0);
                 if ((i & 3) == 0) zero_acc(acc);
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
             float* qg = P.qkvg + (size_t)row0 * kRW;
             for (int i = tid; i < T * (kRW / 4); i += 256) {
                 const int row = i >> 8, c4 = i & 255;
-                *reinterpret_cast<float4*>(qg + (size_t)row * kRW + c4 * 4) = *reinterpret_cast<const float4*>(qk + row * kQkLd + c4 * 4);
+                stg4(qg + (size_t)row * kRW + c4 * 4, *reinterpret_cast<const float4*>(qk + row * kQkLd + c4 * 4));
             }
         }
         // ---- attention (modules.py:58-81): 16 lanes per (head, query) row, lane j = key
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         __syncthreads();
         if (a.save) {
             float* pg = P.p + (size_t)g * kRH * TT;
-            for (int i = tid; i < kRH * TT; i += 256) pg[i] = p_s[i];
+            for (int i = tid; i < kRH * TT; i += 256) stg(pg + i, p_s[i]);
         }
         for (int idx = tid; idx < T * kRDm; idx += 256) {
             const int i = idx >> 8, c = idx & 255, h = c >> 5;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
             for (int j = 0; j < T; ++j) o = fmaf(pr[j], qk[j * kQkLd + 2 * kRDm + c], o);
             const float gt = qk[i * kQkLd + 3 * kRDm + c];
             const float v = o * (1.0f / (1.0f + expf(-gt)));
-            if (a.save) P.a[(size_t)(row0 + i) * kRDm + c] = v;
+            if (a.save) stg(P.a + (size_t)(row0 + i) * kRDm + c, v);
             as_[i * LW + c] = v;
         }
         CF_STAMP(5);
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
                     const int row = lq * 4 + i, col = w * (DFF / 4) + col_nt(t, lr);
                     const float v = fmaxf(acc[t][i] + b1v[t], 0.f);
                     hs[row * LW + col] = v;
-                    if (a.save && row < T) P.hdn[(size_t)(row0 + row) * DFF + col] = v;
+                    if (a.save && row < T) stg(P.hdn + (size_t)(row0 + row) * DFF + col, v);
                 }
         }
         FragNT<2, DFF / 16> f2;
@@ -271,14 +272,14 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         for (int i = tid; i < kTile * (kD / 4); i += 256) {
             const int row = i >> 5, c4 = i & 31;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < T) v = *reinterpret_cast<const float4*>(src + (size_t)(row0 + row) * kD + c4 * 4);
+            if (row < T) v = ldg4(src + (size_t)(row0 + row) * kD + c4 * 4);
             *reinterpret_cast<float4*>(dst + row * LD + c4 * 4) = v;
         }
     };
     for (int i = tid; i < (kTile - T) * kQkLd; i += 256) dqk[T * kQkLd + i] = 0.f;      // dead rows of the MFMA operand
     for (int i = tid; i < TT; i += 256) {
-        fq_s[i] = a.freq[(size_t)g * TT + i];
-        mk_s[i] = a.mask[r][(size_t)g * TT + i] ? 1.f : 0.f;
+        fq_s[i] = ldg(a.freq + (size_t)g * TT + i);
+        mk_s[i] = *(const CF_GLOBAL uint8_t*)(a.mask[r] + (size_t)g * TT + i) ? 1.f : 0.f;
     }
     load_rows(ds, tab[a.n_layers - 1].dxout);
     for (int l = a.n_layers - 1; l >= 0; --l) {
@@ -296,8 +297,9 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         CF_STAMP(1);
         ln_bwd_rows(t2, LD, xh, LD, P.g2, P.rs2, row0, T, P.dt2);
         CF_STAMP(2);
-        FragNN<2, DFF / 16> fw1;
-        frag_load_nn(fw1, P.w1 + w * 32, kD);
+        const int cg = w & 1, kh = w >> 1;      // products with 128 output columns: 2 column groups x 2 K halves
+        FragNN<4, DFF / 32> fw1;
+        frag_load_nn(fw1, P.w1 + (size_t)(kh * (DFF / 2)) * kD + cg * 64, kD);
         __syncthreads();
         colsum16(t2, LD, nullptr, 0, kD, part + 256);
         {
@@ -313,11 +315,11 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
                 for (int t = 0; t < NT2; ++t) v[t] = 0.f;
                 if (row < T) {
                     const size_t o = (size_t)(row0 + row) * DFF + col;
-                    const vec_t hv = *reinterpret_cast<const vec_t*>(P.hdn + o);
+                    const vec_t hv = LdgN<NT2>::ld(P.hdn + o);
                     const float* hp = reinterpret_cast<const float*>(&hv);
 #pragma unroll
                     for (int t = 0; t < NT2; ++t) v[t] = hp[t] > 0.f ? acc[t][i] : 0.f;
-                    *reinterpret_cast<vec_t*>(P.dpre1 + o) = *reinterpret_cast<const vec_t*>(v);
+                    LdgN<NT2>::st(P.dpre1 + o, *reinterpret_cast<const vec_t*>(v));
                 }
                 *reinterpret_cast<vec_t*>(wide + row * LW + col) = *reinterpret_cast<const vec_t*>(v);
             }
@@ -329,14 +331,24 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         __syncthreads();
         colsum16(wide, LW, nullptr, 0, DFF, part + 384);
         {
-            f32x4 acc[2];
+            f32x4 acc[4];
             zero_acc(acc);
-            frag_mma_nn(fw1, wide, LW, acc);
+            frag_mma_nn(fw1, wide + kh * (DFF / 2), LW, acc);
+            float* red = qk;                    // [16][LD] scratch (the q|k|v|g tile is loaded later)
+            if (kh == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + 2 * lr;
-                ds[row * LD + col] = acc[0][i] + t2[row * LD + col];
-                ds[row * LD + col + 1] = acc[1][i] + t2[row * LD + col + 1];
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(red + (lq * 4 + i) * LD + cg * 64 + 4 * lr) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = (lq * 4 + i) * LD + cg * 64 + 4 * lr;
+                    const float4 rv = *reinterpret_cast<const float4*>(red + o), tv = *reinterpret_cast<const float4*>(t2 + o);
+                    *reinterpret_cast<float4*>(ds + o) = make_float4(acc[0][i] + rv.x + tv.x, acc[1][i] + rv.y + tv.y, acc[2][i] + rv.z + tv.z,
+                                                                    acc[3][i] + rv.w + tv.w);
+                }
             }
         }
         __syncthreads();
@@ -351,10 +363,10 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
             const float* qg = P.qkvg + (size_t)row0 * kRW;
             for (int i = tid; i < T * (kRW / 4); i += 256) {
                 const int row = i >> 8, c4 = i & 255;
-                *reinterpret_cast<float4*>(qk + row * kQkLd + c4 * 4) = *reinterpret_cast<const float4*>(qg + (size_t)row * kRW + c4 * 4);
+                *reinterpret_cast<float4*>(qk + row * kQkLd + c4 * 4) = ldg4(qg + (size_t)row * kRW + c4 * 4);
             }
             const float* pg = P.p + (size_t)g * kRH * TT;
-            for (int i = tid; i < kRH * TT; i += 256) p_s[i] = pg[i];
+            for (int i = tid; i < kRH * TT; i += 256) p_s[i] = ldg(pg + i);
         }
         __syncthreads();
         colsum16(ds, LD, nullptr, 0, kD, part + 640 + DFF);
@@ -367,12 +379,12 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
                 const int row = lq * 4 + i, col = w * (kRDm / 4) + 4 * lr;
                 const float4 v = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
                 *reinterpret_cast<float4*>(wide + row * LW + col) = v;
-                if (row < T) *reinterpret_cast<float4*>(P.da + (size_t)(row0 + row) * kRDm + col) = v;
+                if (row < T) stg4(P.da + (size_t)(row0 + row) * kRDm + col, v);
             }
         }
         CF_STAMP(6);
-        FragNN<2, 16> fda, fdb;           // first K-chunk of the input-gradient product
-        frag_load_nn(fda, P.watt + w * 32, kD);
+        FragNN<4, 32> fd;                 // input-gradient product: this wave's K half of the q|k|v|g weight
+        frag_load_nn(fd, P.watt + (size_t)(kh * 512) * kD + cg * 64, kD);
         __syncthreads();
         CF_STAMP(7);
         // ---- attention backward (gate, value, softmax, score sides)
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         if (tid < kRH) {
             float sm = 0.f;
             for (int i = 0; i < T; ++i) sm += red_s[tid * T + i];
-            P.dgam[(size_t)g * kRH + tid] = sm;
+            stg(P.dgam + (size_t)g * kRH + tid, sm);
         }
         for (int idx = tid; idx < T * kRDm; idx += 256) {
             const int i = idx >> 8, c = idx & 255, h = c >> 5;
@@ -444,28 +456,31 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
             float* dg = P.dqkvg + (size_t)row0 * kRW;
             for (int i = tid; i < T * (kRW / 4); i += 256) {
                 const int row = i >> 8, c4 = i & 255;
-                *reinterpret_cast<float4*>(dg + (size_t)row * kRW + c4 * 4) = *reinterpret_cast<const float4*>(dqk + row * kQkLd + c4 * 4);
+                stg4(dg + (size_t)row * kRW + c4 * 4, *reinterpret_cast<const float4*>(dqk + row * kQkLd + c4 * 4));
             }
         }
         CF_STAMP(11);
-        // ---- d(layer input) = dt1 + dqkvg Watt   (K = 1024 in four chunks)
+        // ---- d(layer input) = dt1 + dqkvg Watt   (K = 1024: two halves x two column groups)
         {
-            f32x4 acc[2];
+            f32x4 acc[4];
             zero_acc(acc);
+            frag_mma_nn(fd, dqk + kh * 512, kQkLd, acc);
+            float* red = wide;                  // [16][LD] scratch (da is dead)
+            if (kh == 1) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                FragNN<2, 16>& cur = (c & 1) ? fdb : fda;
-                FragNN<2, 16>& nxt = (c & 1) ? fda : fdb;
-                if (c < 3) frag_load_nn(nxt, P.watt + (size_t)((c + 1) * 256) * kD + w * 32, kD);
-                frag_mma_nn(cur, dqk + c * 256, kQkLd, acc);
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(red + (lq * 4 + i) * LD + cg * 64 + 4 * lr) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
             }
+            __syncthreads();
+            if (kh == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + 2 * lr;
-                const float v0 = acc[0][i] + ds[row * LD + col], v1 = acc[1][i] + ds[row * LD + col + 1];
-                ds[row * LD + col] = v0;
-                ds[row * LD + col + 1] = v1;
-                if (row < T) *reinterpret_cast<float2*>(P.dxin + (size_t)(row0 + row) * kD + col) = make_float2(v0, v1);
+                for (int i = 0; i < 4; ++i) {
+                    const int row = lq * 4 + i, o = row * LD + cg * 64 + 4 * lr;
+                    const float4 rv = *reinterpret_cast<const float4*>(red + o), tv = *reinterpret_cast<const float4*>(ds + o);
+                    const float4 v = make_float4(acc[0][i] + rv.x + tv.x, acc[1][i] + rv.y + tv.y, acc[2][i] + rv.z + tv.z, acc[3][i] + rv.w + tv.w);
+                    *reinterpret_cast<float4*>(ds + o) = v;
+                    if (row < T) stg4(P.dxin + (size_t)(row0 + row) * kD + cg * 64 + 4 * lr, v);
+                }
             }
         }
         CF_STAMP(12);

@@ -190,11 +190,18 @@ def test_g4_train_step_golden(reg):
     b = dict(batch)
     b["label"] = label
     orc.train_step(P, opt, b, regression=reg)
-    # the first AdamW update is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 the fp32 rounding noise of g is
-    # amplified to a fraction of lr = 3e-5, hence 5e-6 rather than 1e-7
+    # the first AdamW update is u = lr * g / (|g| + eps) with du/dg = lr * eps / (|g| + eps)^2: where |g| is far
+    # above eps = 1e-8 the update is insensitive to rounding noise in g (checked to 2e-7); where |g| ~ eps the
+    # noise of g (~1e-9, in the oracle as well) is amplified up to a fraction of lr = 3e-5 (bounded by 2e-5)
     sd = model.state_dict()
     for k in P:
-        assert (sd[k].cpu() - P[k].detach()).abs().max().item() < 5e-6, k
+        d = (sd[k].cpu() - P[k].detach()).abs()
+        if P[k].grad is None:
+            assert d.max().item() == 0.0, k
+            continue
+        big = P[k].grad.abs() > 1e-6
+        assert d[big].max().item() < 2e-7 if big.any() else True, k
+        assert d.max().item() < 2e-5, k
 
 
 def test_three_adamw_steps_track_oracle():
