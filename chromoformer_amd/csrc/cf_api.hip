@@ -413,6 +413,18 @@ static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const C
     push_wg(out, wg1(b.dt2, kD, b.hdn, dff, rpg, h->G_(ff_pre + "l2.weight"), dff, kD, dff));
 }
 
+// the fused Regulation kernels are instantiated for the default token count (T = 9, loops over tokens
+// unrolled) and once with a run-time T
+static const void* reg_kernel(bool bwd, int dff, int T) {
+    const bool t9 = T == 9;
+    if (!bwd) {
+        if (dff == 128) return t9 ? (const void*)k_reg_fwd<128, 9> : (const void*)k_reg_fwd<128, 0>;
+        return t9 ? (const void*)k_reg_fwd<256, 9> : (const void*)k_reg_fwd<256, 0>;
+    }
+    if (dff == 128) return t9 ? (const void*)k_reg_bwd<128, 9> : (const void*)k_reg_bwd<128, 0>;
+    return t9 ? (const void*)k_reg_bwd<256, 9> : (const void*)k_reg_bwd<256, 0>;
+}
+
 static int build_reg_table(cf_handle* h) {
     const cf_config& c = h->cfg;
     if (h->reg_fused) {
@@ -653,10 +665,9 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         const size_t need = std::max(reg_fwd_smem(T), reg_bwd_smem(T));
         h->reg_fused = T <= kTile && need <= 160 * 1024;
         if (h->reg_fused) {
-            hipError_t e1 = hipFuncSetAttribute((const void*)k_reg_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_fwd_smem(T));
-            hipError_t e2 = hipFuncSetAttribute((const void*)k_reg_fwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_fwd_smem(T));
-            hipError_t e3 = hipFuncSetAttribute((const void*)k_reg_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_bwd_smem(T));
-            hipError_t e4 = hipFuncSetAttribute((const void*)k_reg_bwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_bwd_smem(T));
+            hipError_t e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, T), hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_fwd_smem(T));
+            hipError_t e2 = hipFuncSetAttribute(reg_kernel(true, c.reg_dff, T), hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_bwd_smem(T));
+            hipError_t e3 = hipSuccess, e4 = hipSuccess;
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) h->reg_fused = false;
         }
     }
@@ -921,8 +932,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         ra.freq = bt->interaction_freq;
         ra.save = save;
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        if (c.reg_dff == 128) hipLaunchKernelGGL((k_reg_fwd<128>), dim3(B, nres), dim3(256), reg_fwd_smem(T), st, ra);
-        else hipLaunchKernelGGL((k_reg_fwd<256>), dim3(B, nres), dim3(256), reg_fwd_smem(T), st, ra);
+        void* kargs[] = {&ra};
+        HIP_TRY(hipLaunchKernel(reg_kernel(false, c.reg_dff, T), dim3(B, nres), dim3(256), kargs, reg_fwd_smem(T), st));
         LAUNCH_CHECK("k_reg_fwd");
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
@@ -1064,8 +1075,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         ra.freq = bt->interaction_freq;
         ra.save = 1;
         ra.tdbg = getenv("CF_STAMP_BWD") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        if (c.reg_dff == 128) hipLaunchKernelGGL((k_reg_bwd<128>), dim3(B, nres), dim3(256), reg_bwd_smem(T), st, ra);
-        else hipLaunchKernelGGL((k_reg_bwd<256>), dim3(B, nres), dim3(256), reg_bwd_smem(T), st, ra);
+        void* kargs[] = {&ra};
+        HIP_TRY(hipLaunchKernel(reg_kernel(true, c.reg_dff, T), dim3(B, nres), dim3(256), kargs, reg_bwd_smem(T), st));
         LAUNCH_CHECK("k_reg_bwd");
     }
     for (int l = (h->reg_fused ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback

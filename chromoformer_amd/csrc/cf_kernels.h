@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__(256) void k_dgrad(DgradArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c + 2 < NC) fetch((c + 2) % 3, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float4 av = ra[c % 3][k];
@@ -1332,6 +1333,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
             for (int u = 0; u < 3; ++u) {
                 if (it + u < nfull) {
                     if (it + u + 2 < nfull) fetch((u + 2) % 3, (it + u + 2) * 16);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         acc[0] = mfma4(ra[u][i], rb[u][i].x, acc[0]);

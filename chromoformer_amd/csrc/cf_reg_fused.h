@@ -31,17 +31,38 @@ struct RegArgs {
 
 constexpr int kQkLd = kRW + 4;
 __host__ __device__ constexpr size_t reg_fwd_smem(int T) {
-    return (size_t)(2 * kTile * (kD + 4) + 2 * kTile * (kRDm + 4) + T * kQkLd + kRH * T * T + 2 * T * T) * sizeof(float);
+    return (size_t)(2 * kTile * (kD + 4) + 2 * kTile * (kRDm + 4) + T * kQkLd + kRH * T * T + 2 * T * T + 16) * sizeof(float);
 }
 __host__ __device__ constexpr size_t reg_bwd_smem(int T) {
-    return (size_t)(3 * kTile * (kD + 4) + kTile * (kRDm + 4) + T * kQkLd + kTile * kQkLd + 2 * kRH * T * T + kRH * T + 2 * T * T) *
+    return (size_t)(3 * kTile * (kD + 4) + kTile * (kRDm + 4) + T * kQkLd + kTile * kQkLd + 2 * kRH * T * T + kRH * T + 2 * T * T + 16) *
            sizeof(float);
 }
 
-template <int DFF>
+// Small per-head products of the attention on the matrix cores: D[16 x 16] = A[16 x 4*KS] . B[4*KS x 16],
+// operands fetched element-wise through branch-free functors: indices are clamped into valid data (rows / columns
+// >= T only produce results that are discarded) and reduction indices >= T read a zero word on the A side.
+// Lane (r, q): A(row = r, k = 4*ks + q), B(k = 4*ks + q, col = r); result reg ii = D[4q + ii][r].
+template <int KS, class FA, class FB>
+__device__ __forceinline__ f32x4 mfma_small(FA fa, FB fb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    float av[KS], bv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {      // all operand reads first (branch-free functors), then the MFMA chain
+        av[ks] = fa(r, 4 * ks + q);
+        bv[ks] = fb(4 * ks + q, r);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = mfma4(av[ks], bv[ks], acc);
+    return acc;
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// TC: compile-time token count (0 = take a.T at run time); with TC > 0 every loop over tokens unrolls.
+template <int DFF, int TC>
 __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int g = blockIdx.x, r = blockIdx.y, T = a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
+    const int g = blockIdx.x, r = blockIdx.y, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     constexpr int LD = kD + 4, LW = kRDm + 4;
     float* xs = smem;                    // [16][LD]   layer input / output
@@ -52,6 +73,9 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
     float* p_s = qk + T * kQkLd;         // [8][T][T]
     float* fq_s = p_s + kRH * TT;        // [T][T]     interaction frequencies of the gene
     float* mk_s = fq_s + TT;             // [T][T]     interaction mask (1 = masked)
+    float* gam_s = mk_s + TT;            // [8] + one zero word read by the padded reduction indices
+    const int ZI = (int)(gam_s + 8 - p_s);
+    if (tid == 0) gam_s[8] = 0.f;
     const RegLayerDev* tab = a.tab + (size_t)r * a.n_layers;
     const float scale = sqrtf((float)kRDh);
     {
@@ -137,51 +161,67 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
                 stg4(qg + (size_t)row * kRW + c4 * 4, *reinterpret_cast<const float4*>(qk + row * kQkLd + c4 * 4));
             }
         }
-        // ---- attention (modules.py:58-81): 16 lanes per (head, query) row, lane j = key
-        for (int row = tid >> 4; row < kRH * T; row += 16) {
-            const int h = row / T, i = row - h * T, j = tid & 15;
-            float sc = -INFINITY;
-            if (j < T) {
-                const float4* qp = reinterpret_cast<const float4*>(qk + i * kQkLd + h * kRDh);
-                const float4* kp = reinterpret_cast<const float4*>(qk + j * kQkLd + kRDm + h * kRDh);
-                float d = 0.f;
+        // ---- attention (modules.py:58-81) on the matrix cores: wave w owns heads 2w, 2w+1
+        constexpr int KT = TC > 0 ? (TC + 3) / 4 : (kRMaxT + 3) / 4;     // k-steps covering the tokens
+        if (tid < kRH) gam_s[tid] = gam;
 #pragma unroll
-                for (int e = 0; e < kRDh / 4; ++e) {
-                    const float4 qv = qp[e], kv = kp[e];
-                    d = fmaf(qv.x, kv.x, d);
-                    d = fmaf(qv.y, kv.y, d);
-                    d = fmaf(qv.z, kv.z, d);
-                    d = fmaf(qv.w, kv.w, d);
+        for (int hh = 0; hh < 2; ++hh) {
+            const int h = 2 * w + hh;
+            const f32x4 sc = mfma_small<kRDh / 4>(
+                [&](int i, int d) { return qk[min(i, T - 1) * kQkLd + h * kRDh + d]; },
+                [&](int d, int j) { return qk[min(j, T - 1) * kQkLd + kRDm + h * kRDh + d]; });
+            const float gm = ldg(P.gamma + h);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = lq * 4 + ii, j = lr;
+                if (i < T && j < T) {
+                    float v = sc[ii] / scale + gm * fq_s[i * T + j];
+                    if (mk_s[i * T + j] != 0.f) v = kMaskFill;
+                    p_s[(h * T + i) * T + j] = v;
                 }
-                sc = d / scale + __shfl(gam, h, 64) * fq_s[i * T + j];
-                if (mk_s[i * T + j] != 0.f) sc = kMaskFill;
-            } else {
-                (void)__shfl(gam, h, 64);
             }
-            float m = sc;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-            const float e = j < T ? expf(sc - m) : 0.f;
-            const float z = group16_sum(e);
-            if (j < T) p_s[row * T + j] = e / z;
         }
         CF_STAMP(3);
+        __syncthreads();
+        for (int row = tid; row < kRH * T; row += 256) {
+            float* pr = p_s + row * T;
+            float m = -INFINITY;
+            _Pragma("unroll") for (int j = 0; j < T; ++j) m = fmaxf(m, pr[j]);
+            float e[TC > 0 ? TC : kRMaxT];
+            float z = 0.f;
+            _Pragma("unroll") for (int j = 0; j < (TC > 0 ? TC : kRMaxT); ++j) {
+                e[j] = j < T ? expf(pr[j] - m) : 0.f;
+                z += e[j];
+            }
+            const float rz = 1.0f / z;
+            _Pragma("unroll") for (int j = 0; j < (TC > 0 ? TC : kRMaxT); ++j)
+                if (j < T) pr[j] = e[j] * rz;
+        }
         CF_STAMP(4);
         __syncthreads();
         if (a.save) {
             float* pg = P.p + (size_t)g * kRH * TT;
             for (int i = tid; i < kRH * TT; i += 256) stg(pg + i, p_s[i]);
         }
-        for (int idx = tid; idx < T * kRDm; idx += 256) {
-            const int i = idx >> 8, c = idx & 255, h = c >> 5;
-            const float* pr = p_s + (h * T + i) * T;
-            float o = 0.f;
-            for (int j = 0; j < T; ++j) o = fmaf(pr[j], qk[j * kQkLd + 2 * kRDm + c], o);
-            const float gt = qk[i * kQkLd + 3 * kRDm + c];
-            const float v = o * (1.0f / (1.0f + expf(-gt)));
-            if (a.save) stg(P.a + (size_t)(row0 + i) * kRDm + c, v);
-            as_[i * LW + c] = v;
-        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int h = 2 * w + hh, col = h * kRDh + nt * 16 + lr;
+                const f32x4 o = mfma_small<KT>(
+                    [&](int i, int j) { return p_s[j < T ? (h * T + min(i, T - 1)) * T + j : ZI]; },
+                    [&](int j, int n) { return qk[min(j, T - 1) * kQkLd + 2 * kRDm + h * kRDh + nt * 16 + n]; });
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = lq * 4 + ii;
+                    if (i < T) {
+                        const float gt = qk[i * kQkLd + 3 * kRDm + col];
+                        const float v = o[ii] * fast_sigmoid(gt);
+                        if (a.save) stg(P.a + (size_t)(row0 + i) * kRDm + col, v);
+                        as_[i * LW + col] = v;
+                    }
+                }
+            }
         CF_STAMP(5);
         __syncthreads();
         CF_STAMP(6);
@@ -248,10 +288,10 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
     }
 }
 
-template <int DFF>
+template <int DFF, int TC>
 __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int g = blockIdx.x, r = blockIdx.y, T = a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
+    const int g = blockIdx.x, r = blockIdx.y, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     constexpr int LD = kD + 4, LW = kRDm + 4, NT2 = DFF / 64, PW = post_partial_width(DFF);
     float* ds = smem;                    // [16][LD]  d(layer output) -> dy1 -> dt1 -> d(layer input)
@@ -265,6 +305,9 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
     float* red_s = s_s + kRH * TT;       // [8*T]
     float* fq_s = red_s + kRH * T;       // [T][T]
     float* mk_s = fq_s + TT;             // [T][T]
+    float* zero_s = mk_s + TT;           // one zero word read by the padded reduction indices
+    const int ZI = (int)(zero_s - p_s), ZS = (int)(zero_s - s_s);
+    if (tid == 0) zero_s[0] = 0.f;
     float* do_s = xh;                    // [T][256] aliases xh|t2 (both dead during the attention backward)
     const RegLayerDev* tab = a.tab + (size_t)r * a.n_layers;
     const float scale = sqrtf((float)kRDh);
@@ -387,70 +430,90 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         frag_load_nn(fd, P.watt + (size_t)(kh * 512) * kD + cg * 64, kD);
         __syncthreads();
         CF_STAMP(7);
-        // ---- attention backward (gate, value, softmax, score sides)
-        for (int idx = tid; idx < T * kRDm; idx += 256) {
-            const int i = idx >> 8, c = idx & 255, h = c >> 5;
-            const float* pr = p_s + (h * T + i) * T;
-            float o = 0.f;
-            for (int j = 0; j < T; ++j) o = fmaf(pr[j], qk[j * kQkLd + 2 * kRDm + c], o);
-            const float gt = qk[i * kQkLd + 3 * kRDm + c];
-            const float sg = 1.0f / (1.0f + expf(-gt));
-            const float da = wide[i * LW + c];
-            do_s[idx] = da * sg;
-            dqk[i * kQkLd + 3 * kRDm + c] = da * o * sg * (1.0f - sg);
-        }
-        __syncthreads();
-        CF_STAMP(8);
-        for (int idx = tid; idx < kRH * TT; idx += 256) {
-            const int h = idx / TT, ij = idx - h * TT, i = ij / T, j = ij - i * T;
-            const float4* dp = reinterpret_cast<const float4*>(do_s + i * kRDm + h * kRDh);
-            const float4* vp = reinterpret_cast<const float4*>(qk + j * kQkLd + 2 * kRDm + h * kRDh);
-            float sc = 0.f;
+        // ---- attention backward on the matrix cores (wave w owns heads 2w, 2w+1)
+        constexpr int KT = TC > 0 ? (TC + 3) / 4 : (kRMaxT + 3) / 4;
 #pragma unroll
-            for (int d = 0; d < kRDh / 4; ++d) {
-                const float4 x = dp[d], y = vp[d];
-                sc = fmaf(x.x, y.x, sc);
-                sc = fmaf(x.y, y.y, sc);
-                sc = fmaf(x.z, y.z, sc);
-                sc = fmaf(x.w, y.w, sc);
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {       // o = p v (recomputed), gate: do = da s(g), dg = da o s(1-s)
+                const int h = 2 * w + hh, col = h * kRDh + nt * 16 + lr;
+                const f32x4 o = mfma_small<KT>(
+                    [&](int i, int j) { return p_s[j < T ? (h * T + min(i, T - 1)) * T + j : ZI]; },
+                    [&](int j, int n) { return qk[min(j, T - 1) * kQkLd + 2 * kRDm + h * kRDh + nt * 16 + n]; });
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = lq * 4 + ii;
+                    if (i < T) {
+                        const float gt = qk[i * kQkLd + 3 * kRDm + col];
+                        const float sg = fast_sigmoid(gt);
+                        const float da = wide[i * LW + col];
+                        do_s[i * kRDm + col] = da * sg;
+                        dqk[i * kQkLd + 3 * kRDm + col] = da * o[ii] * sg * (1.0f - sg);
+                    }
+                }
             }
-            s_s[idx] = sc;
-        }
+        CF_STAMP(8);
         __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {           // dp[i][j] = do[i] . v[j]
+            const int h = 2 * w + hh;
+            const f32x4 dp = mfma_small<kRDh / 4>(
+                [&](int i, int d) { return do_s[min(i, T - 1) * kRDm + h * kRDh + d]; },
+                [&](int d, int j) { return qk[min(j, T - 1) * kQkLd + 2 * kRDm + h * kRDh + d]; });
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = lq * 4 + ii, j = lr;
+                if (i < T && j < T) s_s[(h * T + i) * T + j] = dp[ii];
+            }
+        }
         CF_STAMP(9);
+        __syncthreads();
         for (int row = tid; row < kRH * T; row += 256) {
             const float* pr = p_s + row * T;
             float* dr = s_s + row * T;
             const int i = row % T;
             float dot = 0.f;
-            for (int j = 0; j < T; ++j) dot = fmaf(pr[j], dr[j], dot);
+            _Pragma("unroll") for (int j = 0; j < T; ++j) dot = fmaf(pr[j], dr[j], dot);
             float gsum = 0.f;
-            for (int j = 0; j < T; ++j) {
+            _Pragma("unroll") for (int j = 0; j < T; ++j) {
                 const float v = mk_s[i * T + j] != 0.f ? 0.f : pr[j] * (dr[j] - dot);
                 gsum = fmaf(v, fq_s[i * T + j], gsum);
                 dr[j] = v;
             }
             red_s[row] = gsum;
         }
-        __syncthreads();
         CF_STAMP(10);
+        __syncthreads();
         if (tid < kRH) {
             float sm = 0.f;
-            for (int i = 0; i < T; ++i) sm += red_s[tid * T + i];
+            _Pragma("unroll") for (int i = 0; i < T; ++i) sm += red_s[tid * T + i];
             stg(P.dgam + (size_t)g * kRH + tid, sm);
         }
-        for (int idx = tid; idx < T * kRDm; idx += 256) {
-            const int i = idx >> 8, c = idx & 255, h = c >> 5;
-            float dq = 0.f, dk = 0.f, dv = 0.f;
-            for (int j = 0; j < T; ++j) {
-                dq = fmaf(s_s[(h * T + i) * T + j], qk[j * kQkLd + kRDm + c], dq);
-                dk = fmaf(s_s[(h * T + j) * T + i], qk[j * kQkLd + c], dk);
-                dv = fmaf(p_s[(h * T + j) * T + i], do_s[j * kRDm + c], dv);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int h = 2 * w + hh, cb = h * kRDh + nt * 16, col = cb + lr;
+                // dq[i] = sum_j ds[i][j] k[j];  dk[j] = sum_i ds[i][j] q[i];  dv[j] = sum_i p[i][j] do[i]
+                const f32x4 dq = mfma_small<KT>(
+                    [&](int i, int j) { return s_s[j < T ? (h * T + min(i, T - 1)) * T + j : ZS]; },
+                    [&](int j, int n) { return qk[min(j, T - 1) * kQkLd + kRDm + cb + n]; });
+                const f32x4 dk = mfma_small<KT>(
+                    [&](int j, int i) { return s_s[i < T ? (h * T + i) * T + min(j, T - 1) : ZS]; },
+                    [&](int i, int n) { return qk[min(i, T - 1) * kQkLd + cb + n]; });
+                const f32x4 dv = mfma_small<KT>(
+                    [&](int j, int i) { return p_s[i < T ? (h * T + i) * T + min(j, T - 1) : ZI]; },
+                    [&](int i, int n) { return do_s[min(i, T - 1) * kRDm + cb + n]; });
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int row = lq * 4 + ii;
+                    if (row < T) {
+                        dqk[row * kQkLd + col] = dq[ii] / scale;
+                        dqk[row * kQkLd + kRDm + col] = dk[ii] / scale;
+                        dqk[row * kQkLd + 2 * kRDm + col] = dv[ii];
+                    }
+                }
             }
-            dqk[i * kQkLd + c] = dq / scale;
-            dqk[i * kQkLd + kRDm + c] = dk / scale;
-            dqk[i * kQkLd + 2 * kRDm + c] = dv;
-        }
         __syncthreads();
         {
             float* dg = P.dqkvg + (size_t)row0 * kRW;
