@@ -344,6 +344,88 @@ __device__ __forceinline__ void ln_bwd_rows(float* dys, int ld, const float* xh,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 16-lanes-per-row LayerNorm (used by the fused kernels): a wave normalises its 4 rows at once,
+// lane (row = lane >> 4, sub = lane & 15) owns columns 8*sub .. 8*sub+7, so a row reduction is four
+// xor-shuffle steps inside a 16-lane group instead of six full-wave steps per row.
+// ---------------------------------------------------------------------------------------
+struct LnParams {
+    float4 g0, g1, b0, b1;
+};
+__device__ __forceinline__ LnParams ln_params_load(const float* g, const float* b) {
+    const int sub = threadIdx.x & 15;
+    LnParams p;
+    p.g0 = ldg4(g + sub * 8);
+    p.g1 = ldg4(g + sub * 8 + 4);
+    p.b0 = ldg4(b + sub * 8);
+    p.b1 = ldg4(b + sub * 8 + 4);
+    return p;
+}
+__device__ __forceinline__ float sum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float4 f4_sub(float4 v, float m) { return make_float4(v.x - m, v.y - m, v.z - m, v.w - m); }
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
+    return make_float4(a.x * b.x + c.x, a.y * b.y + c.y, a.z * b.z + c.z, a.w * b.w + c.w);
+}
+// forward: ts (LDS tile, in place -> y); xhat / rstd / y to global rows row0 + row when row < nvalid
+__device__ __forceinline__ void ln_fwd_tile16(float* ts, int ld, const LnParams& P, int row0, int nvalid, float* xhat_g, float* rstd_g,
+                                              float* y_g) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, row = w * 4 + (lane >> 4), sub = lane & 15;
+    float* tp = ts + row * ld + sub * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(tp), v1 = *reinterpret_cast<const float4*>(tp + 4);
+    const float mean = group16_sum(sum4(v0) + sum4(v1)) * (1.0f / kD);
+    const float4 d0 = f4_sub(v0, mean), d1 = f4_sub(v1, mean);
+    const float var = group16_sum(sum4(f4_mul(d0, d0)) + sum4(f4_mul(d1, d1))) * (1.0f / kD);
+    const float rstd = 1.0f / sqrtf(var + kLnEps);
+    const float4 x0 = f4_scale(d0, rstd), x1 = f4_scale(d1, rstd);
+    const float4 y0 = f4_fma(x0, P.g0, P.b0), y1 = f4_fma(x1, P.g1, P.b1);
+    *reinterpret_cast<float4*>(tp) = y0;
+    *reinterpret_cast<float4*>(tp + 4) = y1;
+    if (row < nvalid) {
+        const size_t o = (size_t)(row0 + row) * kD + sub * 8;
+        if (xhat_g) {
+            stg4(xhat_g + o, x0);
+            stg4(xhat_g + o + 4, x1);
+            if (sub == 0) stg(rstd_g + row0 + row, rstd);
+        }
+        if (y_g) {
+            stg4(y_g + o, y0);
+            stg4(y_g + o + 4, y1);
+        }
+    }
+}
+// backward: dst = rstd * (a - mean(a) - xhat * mean(a * xhat)),  a = dy * g   (src, dst, xh: LDS tiles)
+__device__ __forceinline__ void ln_bwd_tile16(const float* src, float* dst, int ld, const float* xh, int ldx, float4 g0, float4 g1,
+                                              const float* rstd_g, int row0, int nvalid, float* dx_g) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, row = w * 4 + (lane >> 4), sub = lane & 15;
+    const float* sp = src + row * ld + sub * 8;
+    const float* xp = xh + row * ldx + sub * 8;
+    const float4 a0 = f4_mul(*reinterpret_cast<const float4*>(sp), g0), a1 = f4_mul(*reinterpret_cast<const float4*>(sp + 4), g1);
+    const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
+    const float m1 = group16_sum(sum4(a0) + sum4(a1)) * (1.0f / kD);
+    const float m2 = group16_sum(sum4(f4_mul(a0, x0)) + sum4(f4_mul(a1, x1))) * (1.0f / kD);
+    const float rs = row < nvalid ? ldg(rstd_g + row0 + row) : 0.f;
+    const float4 o0 = make_float4(rs * (a0.x - m1 - x0.x * m2), rs * (a0.y - m1 - x0.y * m2), rs * (a0.z - m1 - x0.z * m2), rs * (a0.w - m1 - x0.w * m2));
+    const float4 o1 = make_float4(rs * (a1.x - m1 - x1.x * m2), rs * (a1.y - m1 - x1.y * m2), rs * (a1.z - m1 - x1.z * m2), rs * (a1.w - m1 - x1.w * m2));
+    float* dp = dst + row * ld + sub * 8;
+    *reinterpret_cast<float4*>(dp) = o0;
+    *reinterpret_cast<float4*>(dp + 4) = o1;
+    if (row < nvalid) {
+        const size_t o = (size_t)(row0 + row) * kD + sub * 8;
+        stg4(dx_g + o, o0);
+        stg4(dx_g + o + 4, o1);
+    }
+}
+// column sums over the first nrows rows of an LDS tile
+__device__ __forceinline__ void colsum_rows(const float* A, int lda, const float* Bt, int ldb, int ncols, int nrows, float* out) {
+    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+        float s = 0.f;
+        for (int rr = 0; rr < nrows; ++rr) s += Bt ? A[rr * lda + c] * Bt[rr * ldb + c] : A[rr * lda + c];
+        stg(out + c, s);
+    }
+}
+
 // column sums over the 16 rows of an LDS tile: out[c] = sum_r A[r][c] (* Bt[r][c])
 __device__ __forceinline__ void colsum16(const float* A, int lda, const float* Bt, int ldb, int ncols, float* out) {
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) {

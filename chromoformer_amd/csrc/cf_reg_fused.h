@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         float b1v[DFF / 64];
 #pragma unroll
         for (int t = 0; t < DFF / 64; ++t) b1v[t] = ldg(P.b1 + w * (DFF / 4) + t * 16 + lr);
-        const float ln1[4] = {ldg(P.g1 + lane), ldg(P.g1 + lane + 64), ldg(P.be1 + lane), ldg(P.be1 + lane + 64)};
-        const float ln2[4] = {ldg(P.g2 + lane), ldg(P.g2 + lane + 64), ldg(P.be2 + lane), ldg(P.be2 + lane + 64)};
+        const LnParams ln1 = ln_params_load(P.g1, P.be1), ln2 = ln_params_load(P.g2, P.be2);
         float gam = 0.f;
         if (lane < kRH) gam = ldg(P.gamma + lane);
         {
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         frag_load_nt(f1, P.w1_t + (size_t)(w * (DFF / 4)) * kD, kD);
         CF_STAMP(7);
         __syncthreads();
-        ln_fwd_rows_r(ts, LD, ln1, row0, T, a.save ? P.xh1 : nullptr, P.rs1, a.save ? P.y1 : nullptr, identity_map());
+        ln_fwd_tile16(ts, LD, ln1, row0, T, a.save ? P.xh1 : nullptr, P.rs1, a.save ? P.y1 : nullptr);
         CF_STAMP(8);
         __syncthreads();
         {
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         }
         CF_STAMP(10);
         __syncthreads();
-        ln_fwd_rows_r(xs, LD, ln2, row0, T, a.save ? P.xh2 : nullptr, P.rs2, P.xout, identity_map());
+        ln_fwd_tile16(xs, LD, ln2, row0, T, a.save ? P.xh2 : nullptr, P.rs2, P.xout);
         CF_STAMP(11);
         __syncthreads();
     }
@@ -329,22 +328,22 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         const RegLayerDev P = tab[l];
         float* part = P.partial + (size_t)g * PW;
         CF_STAMP(0);
+        const float4 lg2a = ldg4(P.g2 + (lane & 15) * 8), lg2b = ldg4(P.g2 + (lane & 15) * 8 + 4);
+        const float4 lg1a = ldg4(P.g1 + (lane & 15) * 8), lg1b = ldg4(P.g1 + (lane & 15) * 8 + 4);
         FragNN<NT2, 8> fw2;
         frag_load_nn(fw2, P.w2 + w * (DFF / 4), DFF);
         load_rows(xh, P.xh2);
         __syncthreads();
-        colsum16(ds, LD, xh, LD, kD, part + 0);
-        colsum16(ds, LD, nullptr, 0, kD, part + 128);
-        for (int i = tid; i < kTile * kD; i += 256) t2[(i >> 7) * LD + (i & 127)] = ds[(i >> 7) * LD + (i & 127)];
-        __syncthreads();
+        colsum_rows(ds, LD, xh, LD, kD, T, part + 0);
+        colsum_rows(ds, LD, nullptr, 0, kD, T, part + 128);
         CF_STAMP(1);
-        ln_bwd_rows(t2, LD, xh, LD, P.g2, P.rs2, row0, T, P.dt2);
+        ln_bwd_tile16(ds, t2, LD, xh, LD, lg2a, lg2b, P.rs2, row0, T, P.dt2);      // t2 = dt2
         CF_STAMP(2);
         const int cg = w & 1, kh = w >> 1;      // products with 128 output columns: 2 column groups x 2 K halves
         FragNN<4, DFF / 32> fw1;
         frag_load_nn(fw1, P.w1 + (size_t)(kh * (DFF / 2)) * kD + cg * 64, kD);
         __syncthreads();
-        colsum16(t2, LD, nullptr, 0, kD, part + 256);
+        colsum_rows(t2, LD, nullptr, 0, kD, T, part + 256);
         {
             f32x4 acc[NT2];
             zero_acc(acc);
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         FragNN<4, 8> fwo;
         frag_load_nn(fwo, P.wo + w * (kRDm / 4), kRDm);
         __syncthreads();
-        colsum16(wide, LW, nullptr, 0, DFF, part + 384);
+        colsum_rows(wide, LW, nullptr, 0, DFF, T, part + 384);
         {
             f32x4 acc[4];
             zero_acc(acc);
@@ -396,10 +395,10 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
         }
         __syncthreads();
         CF_STAMP(4);
-        colsum16(ds, LD, xh, LD, kD, part + 384 + DFF);
-        colsum16(ds, LD, nullptr, 0, kD, part + 512 + DFF);
+        colsum_rows(ds, LD, xh, LD, kD, T, part + 384 + DFF);
+        colsum_rows(ds, LD, nullptr, 0, kD, T, part + 512 + DFF);
         __syncthreads();
-        ln_bwd_rows(ds, LD, xh, LD, P.g1, P.rs1, row0, T, P.dt1);       // ds = dt1
+        ln_bwd_tile16(ds, ds, LD, xh, LD, lg1a, lg1b, P.rs1, row0, T, P.dt1);       // ds = dt1 (each lane rewrites only what it read)
         CF_STAMP(5);
         // operands of the attention backward: in flight during the out-projection product
         {
@@ -412,7 +411,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
             for (int i = tid; i < kRH * TT; i += 256) p_s[i] = ldg(pg + i);
         }
         __syncthreads();
-        colsum16(ds, LD, nullptr, 0, kD, part + 640 + DFF);
+        colsum_rows(ds, LD, nullptr, 0, kD, T, part + 640 + DFF);
         {
             f32x4 acc[4];
             zero_acc(acc);
