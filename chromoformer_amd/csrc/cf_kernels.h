@@ -370,7 +370,7 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
 }
 // forward: ts (LDS tile, in place -> y); xhat / rstd / y to global rows row0 + row when row < nvalid
 __device__ __forceinline__ void ln_fwd_tile16(float* ts, int ld, const LnParams& P, int row0, int nvalid, float* xhat_g, float* rstd_g,
-                                              float* y_g) {
+                                              float* y_g, const RowMap ymap = RowMap{1, 1, 0, 0}) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, row = w * 4 + (lane >> 4), sub = lane & 15;
     float* tp = ts + row * ld + sub * 8;
     const float4 v0 = *reinterpret_cast<const float4*>(tp), v1 = *reinterpret_cast<const float4*>(tp + 4);
@@ -390,8 +390,9 @@ __device__ __forceinline__ void ln_fwd_tile16(float* ts, int ld, const LnParams&
             if (sub == 0) stg(rstd_g + row0 + row, rstd);
         }
         if (y_g) {
-            stg4(y_g + o, y0);
-            stg4(y_g + o + 4, y1);
+            const size_t oy = (size_t)map_row(ymap, row0 + row) * kD + sub * 8;
+            stg4(y_g + oy, y0);
+            stg4(y_g + oy + 4, y1);
         }
     }
 }
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     FragNT<2, DM / 16> fo;
     frag_load_nt(fo, a.wo[r] + (size_t)(w * 32) * DM, DM);
+    const LnParams lnp1 = ln_params_load(a.g1[r], a.be1[r]), lnp2 = ln_params_load(a.g2[r], a.be2[r]);
     load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, N, a.xmap);
     if (VPROJ) {
         FragNT<2, 8> fv;
@@ -849,8 +851,7 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
     FragNT<NT1, 8> f1;      // issued before the LayerNorm so the L2 latency hides behind it
     frag_load_nt(f1, a.w1[r] + (size_t)(w * (DFF / 4)) * kD, kD);
     __syncthreads();
-    ln_fwd_rows(&ts[0][0], kD + 4, a.g1[r], a.be1[r], row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r],
-                a.save ? a.y1[r] : nullptr, identity_map());
+    ln_fwd_tile16(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
     __syncthreads();
     {   // hdn = relu(y1 W1^T + b1)
         f32x4 acc[NT1];
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
             }
     }
     __syncthreads();
-    ln_fwd_rows(&xs[0][0], kD + 4, a.g2[r], a.be2[r], row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+    ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
 }
 
 // backward of the chain.  Per tile it also emits the column sums that make up the
@@ -929,9 +930,11 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0);      // d ln2.weight
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128);           // d ln2.bias
-    for (int i = threadIdx.x; i < kTile * kD; i += 256) t2[i >> 7][i & 127] = ds[i >> 7][i & 127];
-    __syncthreads();
-    ln_bwd_rows(&t2[0][0], kD + 4, &xh[0][0], kD + 4, a.g2[r], a.rs2[r], row0, min(kTile, N - row0), a.dt2[r]);   // t2 = dt2
+    {
+        const int sub = threadIdx.x & 15;
+        ln_bwd_tile16(&ds[0][0], &t2[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g2[r] + sub * 8), ldg4(a.g2[r] + sub * 8 + 4), a.rs2[r], row0,
+                      min(kTile, N - row0), a.dt2[r]);   // t2 = dt2
+    }
     FragNN<2, DFF / 16> fw1;
     frag_load_nn(fw1, a.w1[r] + w * 32, kD);
     __syncthreads();
@@ -978,7 +981,11 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF);   // d ln1.weight
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 512 + DFF);          // d ln1.bias
     __syncthreads();
-    ln_bwd_rows(&ds[0][0], kD + 4, &xh[0][0], kD + 4, a.g1[r], a.rs1[r], row0, min(kTile, N - row0), a.dt1[r]);   // ds = dt1
+    {
+        const int sub = threadIdx.x & 15;
+        ln_bwd_tile16(&ds[0][0], &ds[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g1[r] + sub * 8), ldg4(a.g1[r] + sub * 8 + 4), a.rs1[r], row0,
+                      min(kTile, N - row0), a.dt1[r]);   // ds = dt1
+    }
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF);     // d out-proj bias
     {   // da = dt1 Wo
