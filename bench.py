@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regime", default="dense", choices=["dense", "realistic"])
-    ap.add_argument("--roofline-kernel", default="k_wgrad")
+    ap.add_argument("--roofline-kernel", default="k_reg_bwd", help="kernel timed with HIP events: k_reg_bwd (dominant), k_reg_fwd (needs --no-graph), k_wgrad, k_adamw")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

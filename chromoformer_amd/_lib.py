@@ -57,6 +57,8 @@ SYMBOLS = {
     "cf_backward": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cf_backward_chain": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cf_backward_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_backward_part": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_kernel_flops": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int]),
     "cf_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cf_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "cf_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -933,7 +933,9 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         ra.save = save;
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
         void* kargs[] = {&ra};
+        h->time_mark("k_reg_fwd", st);
         HIP_TRY(hipLaunchKernel(reg_kernel(false, c.reg_dff, T), dim3(B, nres), dim3(256), kargs, reg_fwd_smem(T), st));
+        h->time_mark("k_reg_fwd", st);
         LAUNCH_CHECK("k_reg_fwd");
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
@@ -1034,12 +1036,13 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
 // ------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------
-static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
+// parts: 1 = head, 2 = Regulation stack, 4 = Pairwise + Embedding (the activation-gradient chain in order)
+static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int parts = 7) {
     const cf_config& c = h->cfg;
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
     const float scale_c = sqrtf(64.f);
-    // head
+    if (parts & 1) {   // head
     hipLaunchKernelGGL(k_head_bwd1, dim3(B), dim3(128), 0, st, h->dlogits, h->P_("fc_head.2.weight"), h->h1, h->dh1, c.n_out);
     LAUNCH_CHECK("k_head_bwd1");
     {
@@ -1066,7 +1069,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         hipLaunchKernelGGL(k_head_scatter, dim3(B, nres), dim3(128), 0, st, sc);
         LAUNCH_CHECK("k_head_scatter");
     }
-    if (h->reg_fused) {
+    }
+    if ((parts & 2) && h->reg_fused) {
         RegArgs ra;
         ra.tab = h->reg_tab;
         ra.n_layers = c.reg_layers;
@@ -1076,10 +1080,12 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         ra.save = 1;
         ra.tdbg = getenv("CF_STAMP_BWD") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
         void* kargs[] = {&ra};
+        h->time_mark("k_reg_bwd", st);
         HIP_TRY(hipLaunchKernel(reg_kernel(true, c.reg_dff, T), dim3(B, nres), dim3(256), kargs, reg_bwd_smem(T), st));
+        h->time_mark("k_reg_bwd", st);
         LAUNCH_CHECK("k_reg_bwd");
     }
-    for (int l = (h->reg_fused ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback
+    for (int l = ((h->reg_fused || !(parts & 2)) ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback
         PostBwdArgs pb;
         AttrArgs at;
         DgradArgs dg;
@@ -1135,6 +1141,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st) {
         hipLaunchKernelGGL((k_dgrad<kRW / 64>), dim3(tiles_of(NR), kD / 32, nres), dim3(256), 0, st, dg);
         LAUNCH_CHECK("k_dgrad<qkvg>");
     }
+    if (!(parts & 4)) return 0;
     // one centre-row layer backward: post chain -> attention -> query chain
     auto centre_bwd = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* dout, RowMap dmap,
                           const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff) -> int {
@@ -1268,24 +1275,32 @@ static int reduce_impl(cf_handle* h, int B, hipStream_t st) {
     return 0;
 }
 
-static int check_bwd(cf_handle* h, const cf_batch* bt) {
+// `first`: the call starts a backward pass (later pieces may follow a replayed graph, which bypasses the host-side record)
+static int check_bwd(cf_handle* h, const cf_batch* bt, bool first = true) {
     if (check_batch(h, bt)) return -1;
     if (!h->grads) return fail("cf_backward: no gradient buffer bound");
-    if (h->last_fwd_B != bt->B) return fail("cf_backward must follow cf_forward(save_for_backward=1) on the same batch");
+    if (first && h->last_fwd_B != bt->B) return fail("cf_backward must follow cf_forward(save_for_backward=1) on the same batch");
+    return 0;
+}
+
+extern "C" int cf_backward_part(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out, int parts,
+                                void* stream) {
+    if (check_bwd(h, bt, (parts & 1) != 0)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (parts & 1) {
+        if (!labels) return fail("cf_backward: labels is null");
+        hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, (const float*)h->logits, labels, bt->B, h->cfg.n_out, loss_scale,
+                           h->dlogits, h->loss);
+        LAUNCH_CHECK("k_loss");
+    }
+    if (backward_impl(h, bt, st, parts)) return -1;
+    if ((parts & 1) && loss_out) HIP_TRY(hipMemcpyAsync(loss_out, h->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
 extern "C" int cf_backward_chain(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out,
                                  void* stream) {
-    if (check_bwd(h, bt)) return -1;
-    if (!labels) return fail("cf_backward: labels is null");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, (const float*)h->logits, labels, bt->B, h->cfg.n_out, loss_scale,
-                       h->dlogits, h->loss);
-    LAUNCH_CHECK("k_loss");
-    if (backward_impl(h, bt, st)) return -1;
-    if (loss_out) HIP_TRY(hipMemcpyAsync(loss_out, h->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
-    return 0;
+    return cf_backward_part(h, bt, labels, loss_scale, loss_out, 7, stream);
 }
 
 extern "C" int cf_backward_reduce(cf_handle* h, int B, void* stream) {
@@ -1364,6 +1379,19 @@ extern "C" int cf_timing_read(cf_handle* h, float* total_ms, int* count) {
     return 0;
 }
 extern "C" double cf_wgrad_flops(cf_handle* h, int B) { return h ? h->wg_flops_per_gene * B : 0.0; }
+// Algorithmic flops (2 * MAC, valid rows only -- the dead rows of a 16-row tile are not counted) of one launch.
+extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
+    if (!h || !kernel) return 0.0;
+    const cf_config& c = h->cfg;
+    const double T = c.i_max + 1, dff = c.reg_dff;
+    const std::string k = kernel;
+    if (k == "k_wgrad") return h->wg_flops_per_gene * B;
+    const double lin_fwd = 2.0 * T * (kD * (double)kRW + kRDm * (double)kD + kD * dff + dff * kD);     // q|k|v|g, out-proj, FFN
+    const double att_fwd = 2.0 * T * T * kRDm * 2.0;                                                   // q k^T and p v
+    if (k == "k_reg_fwd") return (lin_fwd + att_fwd) * c.reg_layers * c.n_res * B;
+    if (k == "k_reg_bwd") return (lin_fwd + 2.0 * T * T * kRDm * 5.0) * c.reg_layers * c.n_res * B;    // dX products + p v, dp, dq, dk, dv
+    return 0.0;
+}
 
 // ------------------------------------------------------------------------------------
 // optimiser

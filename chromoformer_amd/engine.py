@@ -78,11 +78,25 @@ class Trainer:
     def _stream(self):
         return self.stream.cuda_stream
 
-    def _fwd_bwd_chain(self, slot, st):
+    def _part(self, slot, st, parts):
+        m, L = self.model, self._L
+        _lib.check(L.cf_backward_part(m._handle, C.byref(slot.struct), slot.label.data_ptr(), 1.0 / self.world,
+                                      slot.loss.data_ptr(), parts, st), "cf_backward_part")
+
+    def _seq_a(self, slot, st):      # forward + loss + head backward
         m, L = self.model, self._L
         _lib.check(L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 1, st), "cf_forward")
-        _lib.check(L.cf_backward_chain(m._handle, C.byref(slot.struct), slot.label.data_ptr(), 1.0 / self.world,
-                                       slot.loss.data_ptr(), st), "cf_backward_chain")
+        self._part(slot, st, 1)
+
+    def _capture(self, fn, slot, st):
+        m, L = self.model, self._L
+        gid = C.c_int()
+        _lib.check(L.cf_capture_begin(m._handle, st), "cf_capture_begin")
+        try:
+            fn(slot, st)
+        finally:
+            _lib.check(L.cf_capture_end(m._handle, st, C.byref(gid)), "cf_capture_end")
+        return gid.value
 
     def step(self, slot):
         """One optimisation step on a staged batch (train.py:182-196)."""
@@ -93,19 +107,19 @@ class Trainer:
         m, L = self.model, self._L
         st = self._stream()
         if not self.use_graph:
-            self._fwd_bwd_chain(slot, st)
+            self._seq_a(slot, st)
+            self._part(slot, st, 2)
+            self._part(slot, st, 4)
         else:
             if slot.graph is None:
-                self._fwd_bwd_chain(slot, st)          # eager once (also validates the arguments)
+                self._seq_a(slot, st)                  # eager once (also validates the arguments)
+                self._part(slot, st, 6)
                 torch.cuda.synchronize()
-                gid = C.c_int()
-                _lib.check(L.cf_capture_begin(m._handle, st), "cf_capture_begin")
-                try:
-                    self._fwd_bwd_chain(slot, st)
-                finally:
-                    _lib.check(L.cf_capture_end(m._handle, st, C.byref(gid)), "cf_capture_end")
-                slot.graph = gid.value
-            _lib.check(L.cf_graph_launch(m._handle, slot.graph, st), "cf_graph_launch")
+                # two graphs around the Regulation backward, which is launched eagerly so that HIP events can time it
+                slot.graph = (self._capture(self._seq_a, slot, st), self._capture(lambda s_, t_: self._part(s_, t_, 4), slot, st))
+            _lib.check(L.cf_graph_launch(m._handle, slot.graph[0], st), "cf_graph_launch")
+            self._part(slot, st, 2)
+            _lib.check(L.cf_graph_launch(m._handle, slot.graph[1], st), "cf_graph_launch")
         _lib.check(L.cf_backward_reduce(m._handle, slot.B, st), "cf_backward_reduce")
         if self.world > 1:
             torch.distributed.all_reduce(m.active_grads(), group=self.pg)
@@ -140,8 +154,8 @@ class Trainer:
         if not launches:
             return None
         avg_s = total_ms / launches * 1e-3
-        if kernel == "k_wgrad":
-            flops = self._L.cf_wgrad_flops(self.model._handle, B)
+        if kernel in ("k_wgrad", "k_reg_fwd", "k_reg_bwd"):
+            flops = self._L.cf_kernel_flops(self.model._handle, kernel.encode(), B)
             ach = flops / avg_s / 1e12
             return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(ach / 157.3, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),

@@ -129,6 +129,11 @@ int cf_backward(cf_handle* h, const cf_batch* batch, const void* labels, float l
 int cf_backward_chain(cf_handle* h, const cf_batch* batch, const void* labels, float loss_scale,
                       float* loss_out, void* stream);
 int cf_backward_reduce(cf_handle* h, int B, void* stream);
+/* cf_backward_chain in pieces (bit mask `parts`: 1 = loss + head, 2 = Regulation stack, 4 = Pairwise +
+ * Embedding), so that a caller replaying graphs can launch one piece eagerly between two graphs (bench.py times
+ * the Regulation backward kernel with HIP events that way).  Pieces must run in the order 1, 2, 4. */
+int cf_backward_part(cf_handle* h, const cf_batch* batch, const void* labels, float loss_scale,
+                     float* loss_out, int parts, void* stream);
 /* Same, but from a caller-supplied d(loss)/d(logits) [B, n_out]. */
 int cf_backward_from(cf_handle* h, const cf_batch* batch, const float* dlogits, void* stream);
 /* torch.optim.AdamW.step (train.py:157, 196): decoupled weight decay, bias correction
@@ -146,13 +151,15 @@ int cf_capture_end(cf_handle* h, void* stream, int* graph_id);
 int cf_graph_launch(cf_handle* h, int graph_id, void* stream);
 
 /* ---- introspection (tests / profiling) -------------------------------------------- */
-/* HIP-event timing of one eagerly launched kernel ("k_wgrad", "k_colsum", "k_adamw"; NULL
+/* HIP-event timing of one eagerly launched kernel ("k_wgrad", "k_colsum", "k_adamw", "k_reg_fwd", "k_reg_bwd"; NULL
  * = off): events are recorded on the launch stream around every launch of that kernel;
  * cf_timing_read waits for them and returns the summed duration and the launch count. */
 int cf_timing_select(cf_handle* h, const char* kernel);
 int cf_timing_read(cf_handle* h, float* total_ms, int* count);
 /* Executed flops (2*M*N*K summed over the tile table) of one k_wgrad launch at batch B. */
 double cf_wgrad_flops(cf_handle* h, int B);
+/* Algorithmic flops (2 * MAC over the valid rows) of one launch of "k_wgrad", "k_reg_fwd" or "k_reg_bwd". */
+double cf_kernel_flops(cf_handle* h, const char* kernel, int B);
 /* Copies a named workspace buffer (e.g. "E0.qt", "dP2.1.xbar") to dst (device);
  * *n_floats receives its size; dst may be NULL to query. */
 int cf_debug_copy(cf_handle* h, const char* name, float* dst, long long* n_floats, void* stream);
