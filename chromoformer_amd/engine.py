@@ -14,6 +14,18 @@ import torch
 from . import _lib
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/pmc_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied), or None when there is no entry."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path))["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 class Slot:
     """One batch resident in HBM at fixed addresses (what a captured graph reads)."""
 
@@ -158,12 +170,12 @@ class Trainer:
             flops = self._L.cf_kernel_flops(self.model._handle, kernel.encode(), B)
             ach = flops / avg_s / 1e12
             return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": round(ach / 157.3, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "frac": round(ach / 157.3, 4), "traffic": _pmc_traffic(kernel), "avg_launch_us": round(avg_s * 1e6, 2),
                     "algorithmic_gflop_per_launch": round(flops / 1e9, 4)}
         if kernel == "k_adamw":
             nbytes = 7.0 * 4.0 * self.model._layout.n_active
             ach = nbytes / avg_s / 1e9
             return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "frac": round(ach / 8000.0, 4), "traffic": _pmc_traffic(kernel), "avg_launch_us": round(avg_s * 1e6, 2),
                     "algorithmic_mb_per_launch": round(nbytes / 1e6, 3)}
         return {"kernel": kernel, "avg_launch_us": round(avg_s * 1e6, 2)}
