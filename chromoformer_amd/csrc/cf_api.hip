@@ -205,6 +205,8 @@ struct cf_handle {
     bool planning = true;
     // stage buffers
     float *pe[kMaxRes], *pet[kMaxRes];
+    float *pe2[kMaxRes], *pet2[kMaxRes];      // padded layouts of the gene-batched attention kernel (cf_attc2.h)
+    bool attc2 = false;
     float *featc[kMaxRes], *ex0[kMaxRes], *edx0[kMaxRes], *edout[kMaxRes];
     CentreBuf E[kMaxRes];
     float *xp0[kMaxRes], *dxp0[kMaxRes], *resid[kMaxRes];
@@ -297,6 +299,8 @@ static void plan_workspace(cf_handle* h) {
         const int L = c.n_bins[r];
         h->pe[r] = h->ws_get(fmt("pe%d", r), (size_t)L * kD);
         h->pet[r] = h->ws_get(fmt("pet%d", r), (size_t)L * kD);
+        h->pe2[r] = h->ws_get(fmt("pe2_%d", r), (size_t)attc2_lpad(L) * kD);
+        h->pet2[r] = h->ws_get(fmt("pet2_%d", r), (size_t)kD * attc2_lt(L));
         h->featc[r] = h->ws_get(fmt("E%d.featc", r), NE * 8);
         h->lp_part_e[r] = h->ws_get(fmt("dE%d.lp_partial", r), ((MB + kLpGenes - 1) / kLpGenes) * kD * 8);
         h->lp_part_p[r] = h->ws_get(fmt("dP%d.lp_partial", r), ((MB + kLpGenes - 1) / kLpGenes) * kD * 8);
@@ -652,7 +656,12 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         std::vector<float> t((size_t)L * kD);
         for (int j = 0; j < L; ++j)
             for (int d = 0; d < kD; ++d) t[(size_t)d * L + j] = pe_host[r][(size_t)j * kD + d];
-        if (hipMemcpy(h->pe[r], pe_host[r], (size_t)L * kD * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        std::vector<float> t2((size_t)kD * attc2_lt(L), 0.f);
+        for (int j = 0; j < L; ++j)
+            for (int d = 0; d < kD; ++d) t2[(size_t)d * attc2_lt(L) + j] = pe_host[r][(size_t)j * kD + d];
+        if (hipMemcpy(h->pe2[r], pe_host[r], (size_t)L * kD * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||       // rows >= L stay zero
+            hipMemcpy(h->pet2[r], t2.data(), t2.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->pe[r], pe_host[r], (size_t)L * kD * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(h->pet[r], t.data(), (size_t)L * kD * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(h->arena);
             delete h;
@@ -669,6 +678,16 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             hipError_t e2 = hipFuncSetAttribute(reg_kernel(true, c.reg_dff, T), hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_bwd_smem(T));
             hipError_t e3 = hipSuccess, e4 = hipSuccess;
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) h->reg_fused = false;
+        }
+    }
+    {   // gene-batched attention kernel when its LDS image (8 regions of features + 16 score rows) fits
+        size_t need = 0;
+        for (int r = 0; r < c.n_res; ++r) need = std::max(need, attc2_smem(c.n_bins[r], c.n_feats));
+        h->attc2 = need <= 160 * 1024;
+        if (h->attc2) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)k_attc2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            hipError_t e2 = hipFuncSetAttribute((const void*)k_attc2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            if (e1 != hipSuccess || e2 != hipSuccess) h->attc2 = false;
         }
     }
     const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
@@ -868,7 +887,34 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         po.save = save;
         hipLaunchKernelGGL(k_qchain_fwd, dim3(tiles_of(N), nres), dim3(256), 0, st, q);
         LAUNCH_CHECK("k_qchain_fwd");
-        hipLaunchKernelGGL((k_attc<false>), dim3(N, nres), dim3(256), smem, st, at);
+        if (h->attc2) {
+            Attc2Args a2;
+            size_t sm2 = 0;
+            for (int r = 0; r < nres; ++r) {
+                a2.feats[r] = at.feats[r];
+                a2.mask[r] = at.mask[r];
+                a2.mstride[r] = at.mstride[r];
+                a2.pe[r] = h->pe2[r];
+                a2.pet[r] = h->pet2[r];
+                a2.wlp[r] = at.wlp[r];
+                a2.vin[r] = at.vin[r];
+                a2.p[r] = at.p[r];
+                a2.w[r] = at.w[r];
+                a2.vout[r] = at.vout[r];
+                a2.L[r] = at.L[r];
+                a2.Lpad[r] = attc2_lpad(at.L[r]);
+                a2.LT[r] = attc2_lt(at.L[r]);
+                sm2 = std::max(sm2, attc2_smem(at.L[r], F));
+            }
+            a2.N = N;
+            a2.F = F;
+            a2.scale = scale_c;
+            a2.rscale = 1.0f / a2.scale;
+            a2.tdbg = getenv("CF_STAMP_ATTC") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
+            hipLaunchKernelGGL((k_attc2<false>), dim3((N + kAG - 1) / kAG, nres), dim3(kAT), sm2, st, a2);
+        } else {
+            hipLaunchKernelGGL((k_attc<false>), dim3(N, nres), dim3(256), smem, st, at);
+        }
         LAUNCH_CHECK("k_attc<fwd>");
         launch_post_fwd<true, 128>(dff, dim3(tiles_of(N), nres), st, po);
         LAUNCH_CHECK("k_post_fwd<centre>");
@@ -1195,7 +1241,34 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         qb.N = N;
         launch_post_bwd<true, 128>(dff, dim3(tiles_of(N), nres), st, pb);
         LAUNCH_CHECK("k_post_bwd<centre>");
-        hipLaunchKernelGGL((k_attc<true>), dim3(N, nres), dim3(256), smem, st, at);
+        if (h->attc2) {
+            Attc2Args a2;
+            size_t sm2 = 0;
+            for (int r = 0; r < nres; ++r) {
+                a2.feats[r] = at.feats[r];
+                a2.mask[r] = at.mask[r];
+                a2.mstride[r] = at.mstride[r];
+                a2.pe[r] = h->pe2[r];
+                a2.pet[r] = h->pet2[r];
+                a2.wlp[r] = at.wlp[r];
+                a2.vin[r] = at.vin[r];
+                a2.p[r] = at.p[r];
+                a2.w[r] = at.w[r];
+                a2.vout[r] = at.vout[r];
+                a2.L[r] = at.L[r];
+                a2.Lpad[r] = attc2_lpad(at.L[r]);
+                a2.LT[r] = attc2_lt(at.L[r]);
+                sm2 = std::max(sm2, attc2_smem(at.L[r], F));
+            }
+            a2.N = N;
+            a2.F = F;
+            a2.scale = scale_c;
+            a2.rscale = 1.0f / a2.scale;
+            a2.tdbg = getenv("CF_STAMP_ATTC") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
+            hipLaunchKernelGGL((k_attc2<true>), dim3((N + kAG - 1) / kAG, nres), dim3(kAT), sm2, st, a2);
+        } else {
+            hipLaunchKernelGGL((k_attc<true>), dim3(N, nres), dim3(256), smem, st, at);
+        }
         LAUNCH_CHECK("k_attc<bwd>");
         hipLaunchKernelGGL(k_qchain_bwd, dim3(tiles_of(N), nres), dim3(256), 0, st, qb);
         LAUNCH_CHECK("k_qchain_bwd");

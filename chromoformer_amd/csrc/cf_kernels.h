@@ -1562,3 +1562,4 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
 }  // namespace cf
 
 #include "cf_reg_fused.h"
+#include "cf_attc2.h"
