@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchromoformer_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 MAX_RES = 3
+BUCKET_REG, BUCKET_PE = 1, 2
 
 
 class cf_config(C.Structure):
@@ -57,6 +58,9 @@ SYMBOLS = {
     "cf_backward": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cf_backward_chain": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cf_backward_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_grad_bucket": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "cf_backward_reduce_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cf_adamw_step_part": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_int, C.c_void_p]),
     "cf_backward_part": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "cf_kernel_flops": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int]),
     "cf_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -207,6 +207,8 @@ struct cf_handle {
     float *pe[kMaxRes], *pet[kMaxRes];
     float *pe2[kMaxRes], *pet2[kMaxRes];      // padded layouts of the gene-batched attention kernel (cf_attc2.h)
     bool attc2 = false;
+    int n_wg_r = 0, n_cs_r = 0;               // leading entries of wg_tiles / cs_tiles that belong to the Regulation + head bucket
+    long long bucket_split = 0;               // flat offset of the first Regulation parameter (bucket boundary)
     float *featc[kMaxRes], *ex0[kMaxRes], *edx0[kMaxRes], *edout[kMaxRes];
     CentreBuf E[kMaxRes];
     float *xp0[kMaxRes], *dxp0[kMaxRes], *resid[kMaxRes];
@@ -232,11 +234,29 @@ struct cf_handle {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     // captured launch sequences
-    std::vector<hipGraphExec_t> graphs;
     bool capturing = false;
+
+    // A captured sequence is replayed as [graph piece 1] -> [the timed kernel, launched eagerly between two HIP
+    // events] -> [graph piece 2] when it contains the kernel selected with cf_timing_select (event-record nodes
+    // inside a graph cost ~60 us per replay on this runtime, an eager launch between two graphs costs nothing
+    // measurable), and as one graph otherwise.
+    struct Hole {
+        const void* func = nullptr;
+        dim3 grid, block;
+        size_t smem = 0;
+        RegArgs args;
+    };
+    struct Replay {
+        hipGraphExec_t first = nullptr, second = nullptr;
+        bool has_hole = false;
+        Hole hole;
+    };
+    std::vector<Replay> replays;
+    Replay cap;                    // under construction
 
     void time_mark(const char* name, hipStream_t st) {
         if (timed.empty() || capturing || timed != name) return;
+        if (ev_used >= 16384) return;      // nobody is reading: stop recording rather than grow without bound
         if (ev_used == ev.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;
@@ -486,8 +506,10 @@ static int build_reg_table(cf_handle* h) {
 static int build_tables(cf_handle* h) {
     const cf_config& c = h->cfg;
     const int S = c.i_max, T = S + 1, F = c.n_feats;
-    std::vector<WgTile> wg;
-    std::vector<CsTile> cs;
+    // two gradient buckets: `wg` / `cs` take Embedding + Pairwise (ready after the whole backward chain), `wgR` / `csR`
+    // the Regulation stacks and the head (ready after k_reg_bwd, i.e. before Pairwise + Embedding backward starts)
+    std::vector<WgTile> wg, wgR;
+    std::vector<CsTile> cs, csR;
     std::vector<LpJob> lpj;
     for (int r = 0; r < c.n_res; ++r) {
         const int bs = c.binsizes[r];
@@ -539,35 +561,39 @@ static int build_tables(cf_handle* h) {
             const std::string lp = fmt("regulation.%d.transformer.layers.%d.", bs, l);
             const RegBuf& b = h->R[r][l];
             const int dff = c.reg_dff;
-            push_wg(wg, wg1(b.dqkvg, kRW, h->Rx[r][l], kD, T, h->G_(lp + "self_att.att.weight"), kD, kRW, kD));
-            push_wg(wg, wg1(b.dt1, kD, b.a, kRDm, T, h->G_(lp + "self_att.ff.weight"), kRDm, kD, kRDm));
-            push_wg(wg, wg1(b.dpre1, dff, b.y1, kD, T, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
-            push_wg(wg, wg1(b.dt2, kD, b.hdn, dff, T, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
+            push_wg(wgR, wg1(b.dqkvg, kRW, h->Rx[r][l], kD, T, h->G_(lp + "self_att.att.weight"), kD, kRW, kD));
+            push_wg(wgR, wg1(b.dt1, kD, b.a, kRDm, T, h->G_(lp + "self_att.ff.weight"), kRDm, kD, kRDm));
+            push_wg(wgR, wg1(b.dpre1, dff, b.y1, kD, T, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
+            push_wg(wgR, wg1(b.dt2, kD, b.hdn, dff, T, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
             if (h->reg_fused) {       // one partial row per gene instead of per 16-row tile
                 const int pw = post_partial_width(dff);
                 const std::string ap = lp + "self_att.", fp = lp + "ff.";
-                push_cs(cs, b.partial + 0, pw, kD, 1, 1, h->G_(fp + "ln.weight"));
-                push_cs(cs, b.partial + 128, pw, kD, 1, 1, h->G_(fp + "ln.bias"));
-                push_cs(cs, b.partial + 256, pw, kD, 1, 1, h->G_(fp + "l2.bias"));
-                push_cs(cs, b.partial + 384, pw, dff, 1, 1, h->G_(fp + "l1.bias"));
-                push_cs(cs, b.partial + 384 + dff, pw, kD, 1, 1, h->G_(ap + "ln.weight"));
-                push_cs(cs, b.partial + 512 + dff, pw, kD, 1, 1, h->G_(ap + "ln.bias"));
-                push_cs(cs, b.partial + 640 + dff, pw, kD, 1, 1, h->G_(ap + "ff.bias"));
+                push_cs(csR, b.partial + 0, pw, kD, 1, 1, h->G_(fp + "ln.weight"));
+                push_cs(csR, b.partial + 128, pw, kD, 1, 1, h->G_(fp + "ln.bias"));
+                push_cs(csR, b.partial + 256, pw, kD, 1, 1, h->G_(fp + "l2.bias"));
+                push_cs(csR, b.partial + 384, pw, dff, 1, 1, h->G_(fp + "l1.bias"));
+                push_cs(csR, b.partial + 384 + dff, pw, kD, 1, 1, h->G_(ap + "ln.weight"));
+                push_cs(csR, b.partial + 512 + dff, pw, kD, 1, 1, h->G_(ap + "ln.bias"));
+                push_cs(csR, b.partial + 640 + dff, pw, kD, 1, 1, h->G_(ap + "ff.bias"));
             } else {
-                push_post_cs(cs, h, b.partial, dff, T, lp + "self_att.", lp + "ff.");
+                push_post_cs(csR, h, b.partial, dff, T, lp + "self_att.", lp + "ff.");
             }
-            push_cs(cs, b.dgam, kRH, kRH, 1, 1, h->G_(lp + "self_att.gamma_f"));
+            push_cs(csR, b.dgam, kRH, kRH, 1, 1, h->G_(lp + "self_att.gamma_f"));
         }
     }
-    push_wg(wg, wg1(h->dh1, kD, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, kD, 3 * kD));
-    push_wg(wg, wg1(h->dlogits, c.n_out, h->h1, kD, 1, h->G_("fc_head.2.weight"), kD, c.n_out, kD));
-    push_cs(cs, h->dh1, kD, kD, 1, 1, h->G_("fc_head.0.bias"));
-    push_cs(cs, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
+    push_wg(wgR, wg1(h->dh1, kD, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, kD, 3 * kD));
+    push_wg(wgR, wg1(h->dlogits, c.n_out, h->h1, kD, 1, h->G_("fc_head.2.weight"), kD, c.n_out, kD));
+    push_cs(csR, h->dh1, kD, kD, 1, 1, h->G_("fc_head.0.bias"));
+    push_cs(csR, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
 
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
     h->n_lp = (int)lpj.size();
     HIP_TRY(hipMalloc(&h->lp_jobs, lpj.size() * sizeof(LpJob)));
     HIP_TRY(hipMemcpy(h->lp_jobs, lpj.data(), lpj.size() * sizeof(LpJob), hipMemcpyHostToDevice));
+    h->n_wg_r = (int)wgR.size();
+    h->n_cs_r = (int)csR.size();
+    wg.insert(wg.begin(), wgR.begin(), wgR.end());      // table layout: [Regulation + head | Embedding + Pairwise]
+    cs.insert(cs.begin(), csR.begin(), csR.end());
     h->wg_flops_per_gene = 0.0;
     for (const WgTile& t : wg) {
         if (t.n0 || t.k0) continue;      // count each job once
@@ -626,6 +652,20 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         return -1;
     }
     for (size_t i = 0; i < h->table.size(); ++i) h->index[h->table[i].name] = (int)i;
+    {   // bucket boundary: trainable tensors are laid out in state_dict order (embed | pairwise | regulation | fc_head)
+        long long split = -1, pe_end = 0;
+        for (const PDesc& p : h->table) {
+            if (!p.trainable) continue;
+            const bool late = p.name.rfind("regulation.", 0) == 0 || p.name.rfind("fc_head.", 0) == 0;
+            if (late && split < 0) split = p.offset;
+            if (!late) pe_end = std::max(pe_end, p.offset + (p.numel + 3) / 4 * 4);
+        }
+        if (split < 0 || pe_end > split) {
+            delete h;
+            return fail("cf_create: parameter layout does not split into [embed, pairwise | regulation, head] ranges");
+        }
+        h->bucket_split = split;
+    }
     {
         std::vector<RetileUnit> units;
         for (const PDesc& p : h->table)
@@ -707,7 +747,10 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (h->reg_tab) (void)hipFree(h->reg_tab);
     if (h->tiled) (void)hipFree(h->tiled);
     if (h->retile_units) (void)hipFree(h->retile_units);
-    for (hipGraphExec_t g : h->graphs) (void)hipGraphExecDestroy(g);
+    for (cf_handle::Replay& rp : h->replays) {
+        if (rp.first) (void)hipGraphExecDestroy(rp.first);
+        if (rp.second) (void)hipGraphExecDestroy(rp.second);
+    }
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -794,6 +837,33 @@ static int check_batch(const cf_handle* h, const cf_batch* b) {
         if (!b->promoter_feats[r] || !b->pcre_feats[r] || !b->promoter_mask_row[r] || !b->pcre_mask_row[r] || !b->interaction_mask[r])
             return fail("batch pointer for resolution %d is null", r);
     if (!b->interaction_freq) return fail("interaction_freq is null");
+    return 0;
+}
+
+// Launch of a fused Regulation kernel.  Under capture, if it is the kernel selected with cf_timing_select, the
+// capture is split around it: the launch is remembered instead of recorded and cf_graph_launch issues it eagerly,
+// between two HIP events, between the two graph pieces.
+static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid, size_t smem, RegArgs& ra, hipStream_t st) {
+    if (h->capturing && h->timed == name && !h->cap.has_hole) {
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamEndCapture(st, &g));
+        hipError_t e = hipGraphInstantiate(&h->cap.first, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        h->cap.has_hole = true;
+        h->cap.hole.func = fn;
+        h->cap.hole.grid = grid;
+        h->cap.hole.block = dim3(256);
+        h->cap.hole.smem = smem;
+        h->cap.hole.args = ra;
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        return 0;
+    }
+    void* kargs[] = {&ra};
+    h->time_mark(name, st);
+    HIP_TRY(hipLaunchKernel(fn, grid, dim3(256), kargs, smem, st));
+    h->time_mark(name, st);
+    LAUNCH_CHECK(name);
     return 0;
 }
 
@@ -978,11 +1048,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         ra.freq = bt->interaction_freq;
         ra.save = save;
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        void* kargs[] = {&ra};
-        h->time_mark("k_reg_fwd", st);
-        HIP_TRY(hipLaunchKernel(reg_kernel(false, c.reg_dff, T), dim3(B, nres), dim3(256), kargs, reg_fwd_smem(T), st));
-        h->time_mark("k_reg_fwd", st);
-        LAUNCH_CHECK("k_reg_fwd");
+        if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T), dim3(B, nres), reg_fwd_smem(T), ra, st)) return -1;
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
         LinArgs la;
@@ -1125,11 +1191,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         ra.freq = bt->interaction_freq;
         ra.save = 1;
         ra.tdbg = getenv("CF_STAMP_BWD") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        void* kargs[] = {&ra};
-        h->time_mark("k_reg_bwd", st);
-        HIP_TRY(hipLaunchKernel(reg_kernel(true, c.reg_dff, T), dim3(B, nres), dim3(256), kargs, reg_bwd_smem(T), st));
-        h->time_mark("k_reg_bwd", st);
-        LAUNCH_CHECK("k_reg_bwd");
+        if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T), dim3(B, nres), reg_bwd_smem(T), ra, st)) return -1;
     }
     for (int l = ((h->reg_fused || !(parts & 2)) ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback
         PostBwdArgs pb;
@@ -1334,17 +1396,24 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
 }
 
 // deferred weight / bias gradients: two launches over the tile tables
-static int reduce_impl(cf_handle* h, int B, hipStream_t st) {
-    hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
-    LAUNCH_CHECK("k_wgrad_lp");
-    h->time_mark("k_wgrad", st);
-    hipLaunchKernelGGL(k_wgrad, dim3(h->n_wg), dim3(256), 0, st, (const WgTile*)h->wg_tiles, B);
-    h->time_mark("k_wgrad", st);
-    LAUNCH_CHECK("k_wgrad");
-    h->time_mark("k_colsum", st);
-    hipLaunchKernelGGL(k_colsum, dim3(h->n_cs), dim3(256), 0, st, (const CsTile*)h->cs_tiles, B);
-    h->time_mark("k_colsum", st);
-    LAUNCH_CHECK("k_colsum");
+static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUCKET_REG | CF_BUCKET_PE) {
+    if (buckets & CF_BUCKET_PE) {
+        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
+        LAUNCH_CHECK("k_wgrad_lp");
+    }
+    for (int bk = 0; bk < 2; ++bk) {
+        if (!(buckets & (bk == 0 ? CF_BUCKET_REG : CF_BUCKET_PE))) continue;
+        const int w0 = bk == 0 ? 0 : h->n_wg_r, wn = bk == 0 ? h->n_wg_r : h->n_wg - h->n_wg_r;
+        const int c0 = bk == 0 ? 0 : h->n_cs_r, cn = bk == 0 ? h->n_cs_r : h->n_cs - h->n_cs_r;
+        h->time_mark("k_wgrad", st);
+        hipLaunchKernelGGL(k_wgrad, dim3(wn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, B);
+        h->time_mark("k_wgrad", st);
+        LAUNCH_CHECK("k_wgrad");
+        h->time_mark("k_colsum", st);
+        hipLaunchKernelGGL(k_colsum, dim3(cn), dim3(256), 0, st, (const CsTile*)h->cs_tiles + c0, B);
+        h->time_mark("k_colsum", st);
+        LAUNCH_CHECK("k_colsum");
+    }
     return 0;
 }
 
@@ -1382,6 +1451,27 @@ extern "C" int cf_backward_reduce(cf_handle* h, int B, void* stream) {
     return reduce_impl(h, B, (hipStream_t)stream);
 }
 
+extern "C" int cf_backward_reduce_part(cf_handle* h, int B, int buckets, void* stream) {
+    if (!h || !h->grads) return fail("cf_backward_reduce_part: no gradient buffer bound");
+    if (B < 1 || B > h->cfg.max_batch) return fail("cf_backward_reduce_part: bad batch size %d", B);
+    if (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE)) return fail("cf_backward_reduce_part: bad bucket mask %d", buckets);
+    return reduce_impl(h, B, (hipStream_t)stream, buckets);
+}
+
+extern "C" int cf_grad_bucket(cf_handle* h, int bucket, long long* offset, long long* numel) {
+    if (!h || !offset || !numel) return fail("cf_grad_bucket: null argument");
+    if (bucket == CF_BUCKET_PE) {
+        *offset = 0;
+        *numel = h->bucket_split;
+    } else if (bucket == CF_BUCKET_REG) {
+        *offset = h->bucket_split;
+        *numel = h->lay.n_active - h->bucket_split;
+    } else {
+        return fail("cf_grad_bucket: bucket must be CF_BUCKET_REG or CF_BUCKET_PE");
+    }
+    return 0;
+}
+
 extern "C" int cf_backward(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out, void* stream) {
     if (cf_backward_chain(h, bt, labels, loss_scale, loss_out, stream)) return -1;
     return reduce_impl(h, bt->B, (hipStream_t)stream);
@@ -1402,6 +1492,7 @@ extern "C" int cf_backward_from(cf_handle* h, const cf_batch* bt, const float* d
 extern "C" int cf_capture_begin(cf_handle* h, void* stream) {
     if (!h) return fail("null handle");
     if (h->capturing) return fail("cf_capture_begin: already capturing");
+    h->cap = cf_handle::Replay();
     HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
     h->capturing = true;
     return 0;
@@ -1416,13 +1507,24 @@ extern "C" int cf_capture_end(cf_handle* h, void* stream, int* graph_id) {
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    h->graphs.push_back(ge);
-    *graph_id = (int)h->graphs.size() - 1;
+    if (h->cap.has_hole) h->cap.second = ge;
+    else h->cap.first = ge;
+    h->replays.push_back(h->cap);
+    *graph_id = (int)h->replays.size() - 1;
     return 0;
 }
 extern "C" int cf_graph_launch(cf_handle* h, int graph_id, void* stream) {
-    if (!h || graph_id < 0 || graph_id >= (int)h->graphs.size()) return fail("cf_graph_launch: bad graph id %d", graph_id);
-    HIP_TRY(hipGraphLaunch(h->graphs[graph_id], (hipStream_t)stream));
+    if (!h || graph_id < 0 || graph_id >= (int)h->replays.size()) return fail("cf_graph_launch: bad graph id %d", graph_id);
+    cf_handle::Replay& rp = h->replays[graph_id];
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipGraphLaunch(rp.first, st));
+    if (rp.has_hole) {
+        void* kargs[] = {&rp.hole.args};
+        h->time_mark(h->timed.c_str(), st);
+        HIP_TRY(hipLaunchKernel(rp.hole.func, rp.hole.grid, rp.hole.block, kargs, rp.hole.smem, st));
+        h->time_mark(h->timed.c_str(), st);
+        HIP_TRY(hipGraphLaunch(rp.second, st));
+    }
     return 0;
 }
 
@@ -1469,23 +1571,31 @@ extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
 // ------------------------------------------------------------------------------------
 // optimiser
 // ------------------------------------------------------------------------------------
-extern "C" int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
-                             void* stream) {
+extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
+                                  int buckets, void* stream) {
     if (!h || !h->params || !h->grads || !h->m || !h->v) return fail("cf_adamw_step: params / grads / moments not bound");
     if (step < 1) return fail("cf_adamw_step: step is 1-based");
+    if (!buckets || (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE))) return fail("cf_adamw_step_part: bad bucket mask %d", buckets);
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)std::sqrt(bc2);
     const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
-    const long long n4 = h->lay.n_active / 4;
+    // the buckets are adjacent ranges of the flat buffers: [0, split) = Embedding + Pairwise, [split, n_active) = Regulation + head
+    const long long lo = (buckets & CF_BUCKET_PE) ? 0 : h->bucket_split;
+    const long long hi = (buckets & CF_BUCKET_REG) ? h->lay.n_active : h->bucket_split;
+    const long long n4 = (hi - lo) / 4;      // every tensor starts 16-byte aligned, so both bounds are multiples of 4
     const int grid = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
     h->time_mark("k_adamw", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params, (const float*)h->grads, h->m, h->v, n4,
-                       decay, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps);
+    hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
+                       h->v + lo, n4, decay, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps);
     h->time_mark("k_adamw", (hipStream_t)stream);
     LAUNCH_CHECK("k_adamw");
     return 0;
+}
+extern "C" int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
+                             void* stream) {
+    return cf_adamw_step_part(h, lr, beta1, beta2, eps, weight_decay, step, CF_BUCKET_REG | CF_BUCKET_PE, stream);
 }
 
 // ------------------------------------------------------------------------------------

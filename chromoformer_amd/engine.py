@@ -72,15 +72,39 @@ class Slot:
 
 
 class Trainer:
+    """One optimisation step = forward, loss, backward, gradient reductions, [all-reduce], AdamW.
+
+    Single GPU: everything up to the optimiser is one captured hipGraph (the launch sequence is static); AdamW is
+    launched eagerly behind it because its bias corrections change every step.
+    Data parallel: two graphs.  The first ends with the Regulation + head gradient bucket (78 % of the bytes), whose
+    RCCL all-reduce then runs on a side stream while the second graph (Pairwise + Embedding backward and their
+    bucket) runs on the main one.
+    ``timed_kernel``: bench.py's roofline kernel; its launches are bracketed by HIP events.  The library splits the
+    capture around a Regulation kernel and launches it eagerly between the two graph pieces (event-record nodes
+    inside a graph cost ~60 us per replay with this runtime; an eager launch between two graphs costs nothing)."""
+
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
-                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
+        self.dp = world_size > 1 or process_group is not None
         self.betas, self.eps, self.wd = betas, eps, weight_decay
         self._L = _lib.lib()
         self._last = None
         # hipGraph capture needs a non-default stream; all work of the trainer runs on it
         self.stream = torch.cuda.Stream(device=model._device)
+        self.side = torch.cuda.Stream(device=model._device)       # all-reduce of the early gradient bucket
+        self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        self._buckets = {}
+        for b in (_lib.BUCKET_REG, _lib.BUCKET_PE):
+            off, n = C.c_longlong(), C.c_longlong()
+            _lib.check(self._L.cf_grad_bucket(model._handle, b, C.byref(off), C.byref(n)), "cf_grad_bucket")
+            self._buckets[b] = model._gflat[off.value: off.value + n.value]
+        self.timed_kernel = timed_kernel
+        if timed_kernel in ("k_wgrad", "k_colsum"):
+            self.use_graph = False        # launched once per bucket: timed on the eager path, where every launch gets its events
+        self._t_ms, self._t_n = 0.0, 0
+        _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
     def stage(self, batch, slot=None):
         slot = slot or Slot(self.model, batch["interaction_freq"].shape[0])
@@ -90,15 +114,28 @@ class Trainer:
     def _stream(self):
         return self.stream.cuda_stream
 
+    # ---- launch sequences (eager or under capture)
     def _part(self, slot, st, parts):
         m, L = self.model, self._L
         _lib.check(L.cf_backward_part(m._handle, C.byref(slot.struct), slot.label.data_ptr(), 1.0 / self.world,
                                       slot.loss.data_ptr(), parts, st), "cf_backward_part")
 
-    def _seq_a(self, slot, st):      # forward + loss + head backward
+    def _reduce(self, slot, st, buckets):
+        _lib.check(self._L.cf_backward_reduce_part(self.model._handle, slot.B, buckets, st), "cf_backward_reduce_part")
+
+    def _seq_early(self, slot, st):     # forward, loss, head + Regulation backward, Regulation + head gradient bucket
         m, L = self.model, self._L
         _lib.check(L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 1, st), "cf_forward")
-        self._part(slot, st, 1)
+        self._part(slot, st, 3)
+        self._reduce(slot, st, _lib.BUCKET_REG)
+
+    def _seq_late(self, slot, st):      # Pairwise + Embedding backward and their gradient bucket
+        self._part(slot, st, 4)
+        self._reduce(slot, st, _lib.BUCKET_PE)
+
+    def _seq_all(self, slot, st):
+        self._seq_early(slot, st)
+        self._seq_late(slot, st)
 
     def _capture(self, fn, slot, st):
         m, L = self.model, self._L
@@ -110,6 +147,9 @@ class Trainer:
             _lib.check(L.cf_capture_end(m._handle, st, C.byref(gid)), "cf_capture_end")
         return gid.value
 
+    def _launch(self, gid, st):
+        _lib.check(self._L.cf_graph_launch(self.model._handle, gid, st), "cf_graph_launch")
+
     def step(self, slot):
         """One optimisation step on a staged batch (train.py:182-196)."""
         with torch.cuda.stream(self.stream):
@@ -118,23 +158,30 @@ class Trainer:
     def _step(self, slot):
         m, L = self.model, self._L
         st = self._stream()
-        if not self.use_graph:
-            self._seq_a(slot, st)
-            self._part(slot, st, 2)
-            self._part(slot, st, 4)
+        if self.use_graph and slot.graph is None:
+            self._seq_all(slot, st)                    # eager once (validates the arguments before anything is captured)
+            torch.cuda.synchronize()
+            first = self._seq_early if self.dp else self._seq_all
+            slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
+        if self.use_graph:
+            self._launch(slot.graph["first"], st)
+        elif self.dp:
+            self._seq_early(slot, st)
         else:
-            if slot.graph is None:
-                self._seq_a(slot, st)                  # eager once (also validates the arguments)
-                self._part(slot, st, 6)
-                torch.cuda.synchronize()
-                # two graphs around the Regulation backward, which is launched eagerly so that HIP events can time it
-                slot.graph = (self._capture(self._seq_a, slot, st), self._capture(lambda s_, t_: self._part(s_, t_, 4), slot, st))
-            _lib.check(L.cf_graph_launch(m._handle, slot.graph[0], st), "cf_graph_launch")
-            self._part(slot, st, 2)
-            _lib.check(L.cf_graph_launch(m._handle, slot.graph[1], st), "cf_graph_launch")
-        _lib.check(L.cf_backward_reduce(m._handle, slot.B, st), "cf_backward_reduce")
-        if self.world > 1:
-            torch.distributed.all_reduce(m.active_grads(), group=self.pg)
+            self._seq_all(slot, st)
+        if self.dp:
+            # the early bucket is complete: all-reduce it on the side stream, under the rest of the backward pass
+            self._ev_fork.record(self.stream)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self._ev_fork)
+                torch.distributed.all_reduce(self._buckets[_lib.BUCKET_REG], group=self.pg)     # SUM; dloss carries 1/world
+                self._ev_join.record(self.side)
+            if self.use_graph:
+                self._launch(slot.graph["late"], st)
+            else:
+                self._seq_late(slot, st)
+            torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
+            self.stream.wait_event(self._ev_join)
         m.adamw_step(self.lr, self.betas, self.eps, self.wd)
         self._last = slot
         return slot.logits, slot.loss
@@ -153,19 +200,26 @@ class Trainer:
         return self._last.loss.item() if self._last is not None else float("nan")
 
     # ------------------------------------------------------------------ measurement
-    def timing(self, kernel):
-        _lib.check(self._L.cf_timing_select(self.model._handle, kernel.encode() if kernel else None), "cf_timing_select")
+    def timing_reset(self):
+        self.timing_read()
+        self._t_ms, self._t_n = 0.0, 0
 
     def timing_read(self):
+        """-> (summed duration in ms, launches) of `timed_kernel` since the last reset (waits for the recorded events)."""
         ms, n = C.c_float(), C.c_int()
         _lib.check(self._L.cf_timing_read(self.model._handle, C.byref(ms), C.byref(n)), "cf_timing_read")
-        return ms.value, n.value
+        self._t_ms += ms.value
+        self._t_n += n.value
+        return self._t_ms, self._t_n
 
     def roofline(self, kernel, total_ms, launches, B):
         """Roofline entry of bench.py for the kernel timed with HIP events."""
         if not launches:
             return None
         avg_s = total_ms / launches * 1e-3
+        if kernel == "k_wgrad":
+            launches = (launches + 1) // 2            # one launch per gradient bucket; the flop count is the step's
+            avg_s = total_ms / launches * 1e-3
         if kernel in ("k_wgrad", "k_reg_fwd", "k_reg_bwd"):
             flops = self._L.cf_kernel_flops(self.model._handle, kernel.encode(), B)
             ach = flops / avg_s / 1e12

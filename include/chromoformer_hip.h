@@ -129,6 +129,17 @@ int cf_backward(cf_handle* h, const cf_batch* batch, const void* labels, float l
 int cf_backward_chain(cf_handle* h, const cf_batch* batch, const void* labels, float loss_scale,
                       float* loss_out, void* stream);
 int cf_backward_reduce(cf_handle* h, int B, void* stream);
+/* Gradient buckets.  The trainable parameters lie in state_dict order in the flat buffers, so the model splits
+ * into two adjacent ranges: CF_BUCKET_PE = Embedding + Pairwise stacks, [0, split), whose gradients exist only
+ * after the whole backward chain, and CF_BUCKET_REG = Regulation stacks + fc_head, [split, n_active), 78 % of the
+ * bytes, whose gradients can be reduced as soon as piece 2 of cf_backward_part has run.  A data-parallel caller
+ * reduces + all-reduces (+ steps) CF_BUCKET_REG on a second stream while piece 4 still runs on the first.
+ *   cf_grad_bucket          -- the flat range (in floats) of one bucket;
+ *   cf_backward_reduce_part -- cf_backward_reduce restricted to a bucket mask. */
+#define CF_BUCKET_REG 1
+#define CF_BUCKET_PE 2
+int cf_grad_bucket(cf_handle* h, int bucket, long long* offset, long long* numel);
+int cf_backward_reduce_part(cf_handle* h, int B, int buckets, void* stream);
 /* cf_backward_chain in pieces (bit mask `parts`: 1 = loss + head, 2 = Regulation stack, 4 = Pairwise +
  * Embedding), so that a caller replaying graphs can launch one piece eagerly between two graphs (bench.py times
  * the Regulation backward kernel with HIP events that way).  Pieces must run in the order 1, 2, 4. */
@@ -140,6 +151,10 @@ int cf_backward_from(cf_handle* h, const cf_batch* batch, const float* dlogits, 
  * from `step` (1-based), over [0, n_active). */
 int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
                   long long step, void* stream);
+/* The same update restricted to a bucket mask (elementwise, so two calls with complementary masks and the same
+ * `step` equal one cf_adamw_step). */
+int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       long long step, int buckets, void* stream);
 
 /* ---- hipGraph capture ---------------------------------------------------------------- */
 /* The launch sequence of a step is static, so it can be captured once and replayed: every
@@ -156,6 +171,9 @@ int cf_graph_launch(cf_handle* h, int graph_id, void* stream);
  * cf_timing_read waits for them and returns the summed duration and the launch count. */
 int cf_timing_select(cf_handle* h, const char* kernel);
 int cf_timing_read(cf_handle* h, float* total_ms, int* count);
+/* Under capture the selected kernel (k_reg_fwd / k_reg_bwd) is not recorded: the capture is split around it and
+ * cf_graph_launch replays [piece 1] -> the kernel, eagerly, between two events -> [piece 2].  Select the kernel
+ * before cf_capture_begin. */
 /* Executed flops (2*M*N*K summed over the tile table) of one k_wgrad launch at batch B. */
 double cf_wgrad_flops(cf_handle* h, int B);
 /* Algorithmic flops (2 * MAC over the valid rows) of one launch of "k_wgrad", "k_reg_fwd" or "k_reg_bwd". */

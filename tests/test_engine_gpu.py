@@ -1,0 +1,85 @@
+"""Step engine on the GPU: hipGraph replay (one graph per step; two with the bucketed RCCL all-reduce of the
+data-parallel path, the early bucket reduced on a side stream), and HIP-event timing nodes inside the graphs, must
+all give the very same bits as the eager single-stream step."""
+import socket
+
+import pytest
+import torch
+
+from oracle import chromoformer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+B = 8
+
+
+def _run(steps=3, **kw):
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+    trainer = Trainer(model, lr=3e-5, **kw)
+    slots = [trainer.stage(orc.synthetic_batch(B, seed=7 + i, regime="realistic")) for i in range(2)]
+    losses = []
+    for i in range(steps):
+        _, loss = trainer.step(slots[i % 2])
+        with torch.cuda.stream(trainer.stream):
+            losses.append(loss.clone())
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return sd, [float(x) for x in losses]
+
+
+def test_graph_replay_and_event_timing_are_bit_identical_to_the_eager_step():
+    ref, ref_loss = _run(use_graph=False)
+    for kw in (dict(use_graph=True), dict(use_graph=True, timed_kernel="k_reg_bwd"), dict(use_graph=False, timed_kernel="k_wgrad")):
+        got, loss = _run(**kw)
+        assert loss == ref_loss, kw
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (kw, k)
+
+
+def test_graph_embedded_events_time_every_replay():
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+    tr = Trainer(model, timed_kernel="k_reg_bwd")
+    slot = tr.stage(orc.synthetic_batch(B, seed=3, regime="dense"))
+    tr.step(slot)
+    tr.timing_reset()
+    for _ in range(7):
+        tr.step(slot)
+    ms, n = tr.timing_read()
+    assert n == 7
+    assert 0.01 < ms / n < 5.0          # a Regulation backward launch at B = 8 takes a fraction of a millisecond
+    assert tr.timing_read()[1] == 7     # reading does not reset
+
+
+def test_grad_buckets_partition_the_active_range():
+    from chromoformer_amd import ChromoformerClassifier, _lib
+    from chromoformer_amd.engine import Trainer
+    model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+    tr = Trainer(model)
+    pe, reg = tr._buckets[_lib.BUCKET_PE], tr._buckets[_lib.BUCKET_REG]
+    assert pe.data_ptr() == model.active_grads().data_ptr()
+    assert reg.data_ptr() == pe.data_ptr() + 4 * pe.numel()
+    assert pe.numel() + reg.numel() == model.active_grads().numel()
+    names = [d["name"] for d in model._table if d["trainable"] and d["offset"] >= pe.numel()]
+    assert names and all(n.startswith(("regulation.", "fc_head.")) for n in names)
+    assert reg.numel() > 3 * pe.numel()          # the early bucket carries most of the bytes
+
+
+def test_one_rank_rccl_all_reduce_in_the_step():
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ref, ref_loss = _run(use_graph=True)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got, loss = _run(use_graph=True, world_size=1, process_group=dist.group.WORLD)
+        got2, loss2 = _run(use_graph=False, world_size=1, process_group=dist.group.WORLD, timed_kernel="k_reg_bwd")
+    finally:
+        dist.destroy_process_group()
+    assert loss == ref_loss and loss2 == ref_loss
+    for k in ref:
+        assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], got2[k]), k
