@@ -215,7 +215,7 @@ struct cf_handle {
     std::vector<CentreBuf> P[kMaxRes];
     std::vector<float*> Rx[kMaxRes], dRx[kMaxRes];
     std::vector<RegBuf> R[kMaxRes];
-    float *hin, *h1, *logits, *dlogits, *dh1, *dhin, *loss, *tdbg;
+    float *hin, *h1, *logits, *dlogits, *dh1, *dhin, *loss, *loss_part, *tdbg;
     // deferred-gradient tile tables
     WgTile* wg_tiles = nullptr;
     int n_wg = 0;
@@ -369,6 +369,7 @@ static void plan_workspace(cf_handle* h) {
     h->dh1 = h->ws_get("dH.h1", MB * kD);
     h->dhin = h->ws_get("dH.in", MB * 3 * kD);
     h->loss = h->ws_get("H.loss", 4);
+    h->loss_part = h->ws_get("H.loss_part", MB / kTile + 1);
     h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 40);      // shader-clock stamps (uint64) of the fused Regulation kernels
 }
 
@@ -731,8 +732,8 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         }
     }
     const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
-    h->n_fwd = 2 + 3 + 1 + 3 * c.pair_layers + reg_launches + 3;
-    h->n_bwd = 4 + reg_launches + 3 * c.pair_layers + 2 + 3 + 3;
+    h->n_fwd = 2 + 3 + 1 + 3 * c.pair_layers + reg_launches + 1;       // retile, x0 | Embedding | lin_proj_p | Pairwise | Regulation | head
+    h->n_bwd = 1 + reg_launches + 3 * c.pair_layers + 2 + 3 + 5;       // head | Regulation | Pairwise | join, dgrad | Embedding | reductions
     h->n_opt = 1;
     *out = h;
     return 0;
@@ -1044,11 +1045,13 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         ra.tab = h->reg_tab;
         ra.n_layers = c.reg_layers;
         ra.T = T;
+        ra.B = B;
+        ra.n_res = nres;
         for (int r = 0; r < nres; ++r) ra.mask[r] = bt->interaction_mask[r];
         ra.freq = bt->interaction_freq;
         ra.save = save;
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T), dim3(B, nres), reg_fwd_smem(T), ra, st)) return -1;
+        if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T), dim3(8 * ((B * nres + 7) / 8)), reg_fwd_smem(T), ra, st)) return -1;
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
         LinArgs la;
@@ -1111,36 +1114,26 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         LAUNCH_CHECK("k_post_fwd<reg>");
     }
     {   // head
-        HeadInArgs hi;
+        HeadFwdArgs a;
         for (int r = 0; r < nres; ++r) {
-            hi.xl[r] = h->Rx[r][c.reg_layers];
-            hi.x0[r] = h->Rx[r][0];
+            a.xl[r] = h->Rx[r][c.reg_layers];
+            a.x0[r] = h->Rx[r][0];
         }
-        hi.hin = h->hin;
-        hi.T = T;
-        hi.n_res = nres;
-        hipLaunchKernelGGL(k_head_in, dim3(B, nres), dim3(128), 0, st, hi);
-        LAUNCH_CHECK("k_head_in");
-        LinArgs a;
-        memset(&a, 0, sizeof a);
-        a.x[0] = h->hin;
-        a.w[0] = h->T_("fc_head.0.weight");
-        a.b[0] = h->P_("fc_head.0.bias");
-        a.y[0] = h->h1;
-        a.xmap = identity_map();
-        a.ldx = 3 * kD;
-        a.ldy = kD;
-        a.N = B;
-        a.K = 3 * kD;
-        a.Nout = kD;
-        a.relu = 1;
-        hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of(B), 1, 1), dim3(256), 0, st, a);
-        LAUNCH_CHECK("k_linear_fwd<head>");
-        hipLaunchKernelGGL(k_head_out, dim3(B), dim3(64), 0, st, h->h1, h->P_("fc_head.2.weight"), h->P_("fc_head.2.bias"),
-                           h->logits, c.n_out);
-        LAUNCH_CHECK("k_head_out");
+        a.w1_t = h->T_("fc_head.0.weight");
+        a.b1 = h->P_("fc_head.0.bias");
+        a.w2 = h->P_("fc_head.2.weight");
+        a.b2 = h->P_("fc_head.2.bias");
+        a.hin = h->hin;
+        a.h1 = h->h1;
+        a.logits = h->logits;
+        a.logits_user = logits;
+        a.B = B;
+        a.T = T;
+        a.n_res = nres;
+        a.n_out = c.n_out;
+        hipLaunchKernelGGL(k_head_fwd, dim3(tiles_of(B)), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_head_fwd");
     }
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, h->logits, (size_t)B * c.n_out * sizeof(float), hipMemcpyDeviceToDevice, st));
     h->last_fwd_B = save ? B : 0;
     return 0;
 }
@@ -1149,49 +1142,46 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
 // backward
 // ------------------------------------------------------------------------------------
 // parts: 1 = head, 2 = Regulation stack, 4 = Pairwise + Embedding (the activation-gradient chain in order)
-static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int parts = 7) {
+static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int parts = 7, const void* labels = nullptr,
+                         float loss_scale = 1.f, float* loss_out = nullptr) {
     const cf_config& c = h->cfg;
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
     const float scale_c = sqrtf(64.f);
-    if (parts & 1) {   // head
-    hipLaunchKernelGGL(k_head_bwd1, dim3(B), dim3(128), 0, st, h->dlogits, h->P_("fc_head.2.weight"), h->h1, h->dh1, c.n_out);
-    LAUNCH_CHECK("k_head_bwd1");
-    {
-        DgradArgs a;
-        memset(&a, 0, sizeof a);
-        a.dy[0] = h->dh1;
-        a.lddy = kD;
-        a.w[0] = h->P_("fc_head.0.weight");
-        a.ldw = 3 * kD;
-        a.res[0] = nullptr;
-        a.rmap = identity_map();
-        a.dx[0] = h->dhin;
-        a.lddx = 3 * kD;
-        a.N = B;
-        a.K = kD;
-        a.Ncols = 3 * kD;
-        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(B), 3 * kD / 32, 1), dim3(256), 0, st, a);
-        LAUNCH_CHECK("k_dgrad<head>");
-        HeadScatterArgs sc;
-        sc.dhin = h->dhin;
-        for (int r = 0; r < nres; ++r) sc.dxl[r] = h->dRx[r][c.reg_layers];
-        sc.T = T;
-        sc.n_res = nres;
-        hipLaunchKernelGGL(k_head_scatter, dim3(B, nres), dim3(128), 0, st, sc);
-        LAUNCH_CHECK("k_head_scatter");
-    }
+    if (parts & 1) {   // loss + head
+        HeadBwdArgs a;
+        a.logits = h->logits;
+        a.labels = labels;
+        a.w2 = h->P_("fc_head.2.weight");
+        a.h1 = h->h1;
+        a.w1 = h->P_("fc_head.0.weight");
+        a.dlogits = h->dlogits;
+        a.dh1 = h->dh1;
+        a.dhin = h->dhin;
+        for (int r = 0; r < nres; ++r) a.dxl[r] = h->dRx[r][c.reg_layers];
+        a.loss = h->loss;
+        a.loss_part = h->loss_part;
+        a.loss_user = loss_out;
+        a.gscale = loss_scale;
+        a.B = B;
+        a.T = T;
+        a.n_res = nres;
+        a.n_out = c.n_out;
+        hipLaunchKernelGGL(k_head_bwd, dim3(tiles_of(B)), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_head_bwd");
     }
     if ((parts & 2) && h->reg_fused) {
         RegArgs ra;
         ra.tab = h->reg_tab;
         ra.n_layers = c.reg_layers;
         ra.T = T;
+        ra.B = B;
+        ra.n_res = nres;
         for (int r = 0; r < nres; ++r) ra.mask[r] = bt->interaction_mask[r];
         ra.freq = bt->interaction_freq;
         ra.save = 1;
         ra.tdbg = getenv("CF_STAMP_BWD") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T), dim3(B, nres), reg_bwd_smem(T), ra, st)) return -1;
+        if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T), dim3(8 * ((B * nres + 7) / 8)), reg_bwd_smem(T), ra, st)) return -1;
     }
     for (int l = ((h->reg_fused || !(parts & 2)) ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback
         PostBwdArgs pb;
@@ -1429,15 +1419,8 @@ extern "C" int cf_backward_part(cf_handle* h, const cf_batch* bt, const void* la
                                 void* stream) {
     if (check_bwd(h, bt, (parts & 1) != 0)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    if (parts & 1) {
-        if (!labels) return fail("cf_backward: labels is null");
-        hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, (const float*)h->logits, labels, bt->B, h->cfg.n_out, loss_scale,
-                           h->dlogits, h->loss);
-        LAUNCH_CHECK("k_loss");
-    }
-    if (backward_impl(h, bt, st, parts)) return -1;
-    if ((parts & 1) && loss_out) HIP_TRY(hipMemcpyAsync(loss_out, h->loss, sizeof(float), hipMemcpyDeviceToDevice, st));
-    return 0;
+    if ((parts & 1) && !labels) return fail("cf_backward: labels is null");
+    return backward_impl(h, bt, st, parts, labels, loss_scale, loss_out);
 }
 
 extern "C" int cf_backward_chain(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out,

@@ -57,6 +57,7 @@ __device__ __forceinline__ void frag_load_nn_rt(FragNN<4, 8>& f, const float* __
 __device__ __forceinline__ void frag_mma_nn_rt(FragNN<4, 8>& f, const float* As, int lda, int nchunks, f32x4 (&acc)[4]) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
+    float4 a_nxt = *reinterpret_cast<const float4*>(ap);      // A operand one k-step ahead (rows are padded: reading one past is in bounds)
     for (int c0 = 0; c0 < nchunks; c0 += kRing) {
 #pragma unroll
         for (int u = 0; u < kRing; ++u) {
@@ -66,7 +67,8 @@ __device__ __forceinline__ void frag_mma_nn_rt(FragNN<4, 8>& f, const float* As,
             if (c < nchunks)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+                    const float4 a = a_nxt;
+                    a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
                     const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {

@@ -1,0 +1,165 @@
+// cf_head.h -- the prediction head, one kernel per direction (included by cf_kernels.h).
+//
+//   forward  (net.py:377-380): hin = cat_r(x_out[r][:, 0] + x_in[r][:, 0]);  h1 = relu(W1 hin + b1);  logits = W2 h1 + b2
+//   backward (train.py:156, 193-195): CrossEntropyLoss / MSELoss (mean over the batch) -> dlogits -> dh1 -> dhin, which
+//            is also the gradient of token 0 of every Regulation output
+//
+// One workgroup per 16 genes.  The head is a few MFLOP: what matters is that it is two launches instead of nine.
+#pragma once
+
+namespace cf {
+
+struct HeadFwdArgs {
+    const float* xl[kMaxRes];    // Regulation output [B*T, 128]
+    const float* x0[kMaxRes];    // Regulation input  [B*T, 128]
+    const float* w1_t;           // fc_head.0.weight [128, n_res*128], tiled copy
+    const float *b1, *w2, *b2;   // fc_head.0.bias, fc_head.2.weight [n_out, 128], fc_head.2.bias
+    float *hin, *h1, *logits;    // saved for the backward pass: [B, n_res*128], [B, 128], [B, n_out]
+    float* logits_user;          // caller's copy (may be null)
+    int B, T, n_res, n_out;
+};
+__global__ __launch_bounds__(256) void k_head_fwd(HeadFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[2][kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float hs[kTile][kD + 4];
+    const int row0 = blockIdx.x * kTile, K = a.n_res * kD, tid = threadIdx.x;
+    const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int col0 = w * 32;
+    f32x4 acc[2];
+    zero_acc(acc);
+    for (int r = 0, buf = 0; r < a.n_res; ++r, buf ^= 1) {       // reduction chunk r of W1 = resolution r of the concatenation
+        FragNT<2, 8> f;
+        frag_load_nt(f, a.w1_t + (size_t)col0 * K + (size_t)r * kD * 16, K);
+        for (int i = tid; i < kTile * (kD / 4); i += 256) {
+            const int row = i >> 5, c4 = i & 31, g = row0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < a.B) {
+                const size_t o = (size_t)g * a.T * kD + c4 * 4;
+                const float4 p = ldg4(a.xl[r] + o), q = ldg4(a.x0[r] + o);
+                v = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+                stg4(a.hin + (size_t)g * K + r * kD + c4 * 4, v);
+            }
+            *reinterpret_cast<float4*>(&xs[buf][row][c4 * 4]) = v;
+        }
+        __syncthreads();
+        frag_mma_nt(f, &xs[buf][0][0], kD + 4, acc);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lq * 4 + i, col = col0 + col_nt(t, lr);
+            const float v = fmaxf(acc[t][i] + a.b1[col], 0.f);
+            hs[row][col] = v;
+            if (row0 + row < a.B) a.h1[(size_t)(row0 + row) * kD + col] = v;
+        }
+    __syncthreads();
+    {   // logits: 16 lanes per gene
+        const int row = tid >> 4, sub = tid & 15, g = row0 + row;
+        for (int c = 0; c < a.n_out; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < kD / 16; ++k) s = fmaf(hs[row][sub + 16 * k], a.w2[c * kD + sub + 16 * k], s);
+            s = group16_sum(s);
+            if (sub == 0 && g < a.B) {
+                const float v = s + a.b2[c];
+                a.logits[g * a.n_out + c] = v;
+                if (a.logits_user) a.logits_user[g * a.n_out + c] = v;
+            }
+        }
+    }
+}
+
+struct HeadBwdArgs {
+    const float* logits;         // [B, n_out]
+    const void* labels;          // int64 [B] (n_out = 2) / float [B] (n_out = 1); null: dlogits is given
+    const float *w2, *h1;        // fc_head.2.weight, saved hidden layer
+    const float* w1;             // fc_head.0.weight [128, n_res*128], row-major
+    float *dlogits, *dh1, *dhin; // [B, n_out], [B, 128], [B, n_res*128]  (kept for the weight gradients / k_join)
+    float* dxl[kMaxRes];         // Regulation output gradient [B*T, 128]: token 0 receives dhin (the other rows stay zero)
+    float* loss;                 // [0] mean loss, [1] user copy flag unused, [2] arrival counter (uint), workspace
+    float* loss_part;            // [tiles]
+    float* loss_user;            // may be null
+    float gscale;
+    int B, T, n_res, n_out;
+};
+__global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];
+    __shared__ float dl[kTile][2];
+    __shared__ float li[kTile];
+    const int row0 = blockIdx.x * kTile, K = a.n_res * kD, tid = threadIdx.x;
+    const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    if (tid < kTile) {        // loss and d loss / d logits of one gene
+        const int g = row0 + tid;
+        float l = 0.f, d0 = 0.f, d1 = 0.f;
+        if (g < a.B) {
+            if (!a.labels) {
+                d0 = a.dlogits[g * a.n_out];
+                if (a.n_out == 2) d1 = a.dlogits[g * 2 + 1];
+            } else if (a.n_out == 1) {
+                const float y = reinterpret_cast<const float*>(a.labels)[g];
+                const float d = a.logits[g] - y;
+                l = d * d;
+                d0 = 2.0f * d * a.gscale / (float)a.B;
+                a.dlogits[g] = d0;
+            } else {
+                const int y = (int)reinterpret_cast<const long long*>(a.labels)[g];
+                const float z0 = a.logits[g * 2], z1 = a.logits[g * 2 + 1];
+                const float m = fmaxf(z0, z1);
+                const float lse = m + logf(expf(z0 - m) + expf(z1 - m));
+                l = lse - (y ? z1 : z0);
+                d0 = (expf(z0 - lse) - (y == 0 ? 1.f : 0.f)) * a.gscale / (float)a.B;
+                d1 = (expf(z1 - lse) - (y == 1 ? 1.f : 0.f)) * a.gscale / (float)a.B;
+                a.dlogits[g * 2] = d0;
+                a.dlogits[g * 2 + 1] = d1;
+            }
+        }
+        dl[tid][0] = d0;
+        dl[tid][1] = d1;
+        li[tid] = l;
+    }
+    __syncthreads();
+    if (a.labels && tid == 0) {       // mean loss: per-workgroup partials, summed in workgroup order by the last to arrive
+        float s = 0.f;
+        for (int i = 0; i < kTile; ++i) s += li[i];
+        a.loss_part[blockIdx.x] = s;
+        __threadfence();
+        unsigned* counter = reinterpret_cast<unsigned*>(a.loss + 2);
+        if (atomicAdd(counter, 1u) == gridDim.x - 1) {
+            __threadfence();
+            float tot = 0.f;
+            for (unsigned i = 0; i < gridDim.x; ++i) tot += *(volatile float*)(a.loss_part + i);
+            tot /= (float)a.B;
+            a.loss[0] = tot;
+            if (a.loss_user) a.loss_user[0] = tot;
+            *counter = 0u;
+        }
+    }
+    for (int i = tid; i < kTile * kD; i += 256) {      // dh1 = (dlogits W2) * (h1 > 0)
+        const int row = i >> 7, j = i & 127, g = row0 + row;
+        float s = dl[row][0] * a.w2[j];
+        if (a.n_out == 2) s = fmaf(dl[row][1], a.w2[kD + j], s);
+        const float v = (g < a.B && a.h1[(size_t)g * kD + j] > 0.f) ? s : 0.f;
+        ds[row][j] = v;
+        if (g < a.B) a.dh1[(size_t)g * kD + j] = v;
+    }
+    __syncthreads();
+    for (int jb = w; jb < K / 64; jb += 4) {          // dhin[:, 64 jb ..] = dh1 . W1[:, 64 jb ..]
+        FragNN<4, 8> f;
+        frag_load_nn(f, a.w1 + jb * 64, K);
+        f32x4 acc[4];
+        zero_acc(acc);
+        frag_mma_nn(f, &ds[0][0], kD + 4, acc);
+        const int r = jb >> 1, e0 = (jb & 1) * 64 + 4 * lr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = row0 + lq * 4 + i;
+            if (g < a.B) {
+                const float4 v = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                stg4(a.dhin + (size_t)g * K + jb * 64 + 4 * lr, v);
+                stg4(a.dxl[r] + (size_t)g * a.T * kD + e0, v);
+            }
+        }
+    }
+}
+
+}  // namespace cf

@@ -151,13 +151,15 @@ __device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, 
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
     constexpr int NC = KS / 2;
+    float4 a_nxt = *reinterpret_cast<const float4*>(ap);      // A operand one k-step ahead: its LDS latency hides behind the MFMAs
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c + kRing - 1 < NC) frag_chunk_nt(f, (c + kRing - 1) % kRing, c + kRing - 1);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+            const float4 a = a_nxt;
+            if (c * 2 + k + 1 < KS) a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float4 b = f.ring[c % kRing][k][t];
@@ -214,13 +216,15 @@ __device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, 
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
     constexpr int NC = KS / 2;
+    float4 a_nxt = *reinterpret_cast<const float4*>(ap);      // A operand one k-step ahead
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c + kRing - 1 < NC) frag_chunk_nn(f, (c + kRing - 1) % kRing, c + kRing - 1);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float4 a = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+            const float4 a = a_nxt;
+            if (c * 2 + k + 1 < KS) a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1280,77 +1284,7 @@ __global__ __launch_bounds__(256) void k_attr(AttrArgs a) {
 // =======================================================================================
 // Head  (net.py:377-380; loss train.py:156, 193)
 // =======================================================================================
-struct HeadInArgs {
-    const float* xl[kMaxRes];    // regulation output  [B*T,128]
-    const float* x0[kMaxRes];    // regulation input   [B*T,128]
-    float* hin;                  // [B, 3*128]
-    int T, n_res;
-};
-__global__ __launch_bounds__(128) void k_head_in(HeadInArgs a) {
-    const int g = blockIdx.x, r = blockIdx.y, e = threadIdx.x;
-    const size_t o = (size_t)g * a.T * kD + e;
-    a.hin[(size_t)g * (a.n_res * kD) + r * kD + e] = a.xl[r][o] + a.x0[r][o];
-}
-
-// logits[g][c] = h1[g] . W2[c] + b2[c]        (n_out is 1 or 2: VALU)
-__global__ __launch_bounds__(64) void k_head_out(const float* __restrict__ h1, const float* __restrict__ w2,
-                                                 const float* __restrict__ b2, float* logits, int n_out) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    for (int c = 0; c < n_out; ++c) {
-        float s = h1[(size_t)g * kD + lane] * w2[c * kD + lane] + h1[(size_t)g * kD + lane + 64] * w2[c * kD + lane + 64];
-        s = wave_sum(s);
-        if (lane == 0) logits[g * n_out + c] = s + b2[c];
-    }
-}
-
-// CrossEntropyLoss (mean) / MSELoss (mean) and d loss / d logits, one workgroup.
-__global__ __launch_bounds__(256) void k_loss(const float* __restrict__ logits, const void* labels, int B, int n_out,
-                                              float gscale, float* dlogits, float* loss_out) {
-    __shared__ float red[4];
-    float li = 0.f;
-    for (int g = threadIdx.x; g < B; g += 256) {
-        if (n_out == 1) {
-            const float y = reinterpret_cast<const float*>(labels)[g];
-            const float d = logits[g] - y;
-            li += d * d;
-            dlogits[g] = 2.0f * d * gscale / (float)B;
-        } else {
-            const long long y = reinterpret_cast<const long long*>(labels)[g];
-            float m = -INFINITY;
-            for (int c = 0; c < n_out; ++c) m = fmaxf(m, logits[g * n_out + c]);
-            float z = 0.f;
-            for (int c = 0; c < n_out; ++c) z += expf(logits[g * n_out + c] - m);
-            const float lse = m + logf(z);
-            li += lse - logits[g * n_out + (int)y];
-            for (int c = 0; c < n_out; ++c)
-                dlogits[g * n_out + c] = (expf(logits[g * n_out + c] - lse) - (c == (int)y ? 1.f : 0.f)) * gscale / (float)B;
-        }
-    }
-    li = wave_sum(li);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
-    __syncthreads();
-    if (threadIdx.x == 0) loss_out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
-}
-
-// dh1pre[g][j] = (sum_c dlogits[g][c] W2[c][j]) * (h1 > 0)
-__global__ __launch_bounds__(128) void k_head_bwd1(const float* __restrict__ dlogits, const float* __restrict__ w2,
-                                                   const float* __restrict__ h1, float* dh1, int n_out) {
-    const int g = blockIdx.x, j = threadIdx.x;
-    float s = 0.f;
-    for (int c = 0; c < n_out; ++c) s = fmaf(dlogits[g * n_out + c], w2[c * kD + j], s);
-    dh1[(size_t)g * kD + j] = h1[(size_t)g * kD + j] > 0.f ? s : 0.f;
-}
-
-// scatter d hin onto token 0 of the (pre-zeroed) regulation output gradient
-struct HeadScatterArgs {
-    const float* dhin;
-    float* dxl[kMaxRes];
-    int T, n_res;
-};
-__global__ __launch_bounds__(128) void k_head_scatter(HeadScatterArgs a) {
-    const int g = blockIdx.x, r = blockIdx.y, e = threadIdx.x;
-    a.dxl[r][(size_t)g * a.T * kD + e] = a.dhin[(size_t)g * (a.n_res * kD) + r * kD + e];
-}
+// (the head kernels live in cf_head.h)
 
 // Joins the gradient streams that meet at the promoter embedding e_c of a gene:
 //   dxp0[g] = sum_s dxP[g*S+s]       (lin_proj_p output is broadcast over the S slots)
@@ -1563,3 +1497,4 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
 
 #include "cf_reg_fused.h"
 #include "cf_attc2.h"
+#include "cf_head.h"

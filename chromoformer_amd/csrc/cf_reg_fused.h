@@ -17,7 +17,7 @@ struct RegLayerDev {
 };
 struct RegArgs {
     const RegLayerDev* tab;          // [n_res][n_layers]
-    int n_layers, T;
+    int n_layers, T, B, n_res;
     const uint8_t* mask[kMaxRes];    // [B,T,T]
     const float* freq;               // [B,T,T]
     int save;
@@ -25,7 +25,7 @@ struct RegArgs {
 };
 #define CF_STAMP(slot)                                                                                 \
     do {                                                                                               \
-        if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                          \
+        if (a.tdbg && g == 0 && r == 0 && threadIdx.x == 0)                                              \
             a.tdbg[l * 16 + (slot)] = __builtin_amdgcn_s_memtime();                                    \
     } while (0)
 
@@ -62,7 +62,12 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn
 template <int DFF, int TC>
 __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int g = blockIdx.x, r = blockIdx.y, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
+    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2.  XCD x
+    // takes the contiguous slice [x * per, (x + 1) * per) of the (resolution-major) sequence list, so six XCDs stream
+    // the weights of one resolution (5.5 MB) and two of them those of two, instead of all eight streaming all three.
+    const int per = gridDim.x >> 3, v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (v >= a.B * a.n_res) return;
+    const int g = v % a.B, r = v / a.B, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     constexpr int LD = kD + 4, LW = kRDm + 4;
     float* xs = smem;                    // [16][LD]   layer input / output
@@ -120,6 +125,9 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
         {
             f32x4 acc[4];
             const float* ap = xs + lr * LD + lq * 4;
+            float4 av8[8];      // the A operand (this layer's input tile) is the same for all four column chunks: read it once
+#pragma unroll
+            for (int k = 0; k < 8; ++k) av8[k] = *reinterpret_cast<const float4*>(ap + k * 16);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (i + kRing - 1 < 16) qfetch((i + kRing - 1) % kRing, i + kRing - 1, P.watt_t);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
                 if ((i & 3) == 0) zero_acc(acc);
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const float4 av = *reinterpret_cast<const float4*>(ap + ((i & 3) * 2 + k) * 16);
+                    const float4 av = av8[(i & 3) * 2 + k];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const float4 b = qring[i % kRing][k][t];
@@ -290,7 +298,12 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
 template <int DFF, int TC>
 __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int g = blockIdx.x, r = blockIdx.y, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
+    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2.  XCD x
+    // takes the contiguous slice [x * per, (x + 1) * per) of the (resolution-major) sequence list, so six XCDs stream
+    // the weights of one resolution (5.5 MB) and two of them those of two, instead of all eight streaming all three.
+    const int per = gridDim.x >> 3, v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (v >= a.B * a.n_res) return;
+    const int g = v % a.B, r = v / a.B, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     constexpr int LD = kD + 4, LW = kRDm + 4, NT2 = DFF / 64, PW = post_partial_width(DFF);
     float* ds = smem;                    // [16][LD]  d(layer output) -> dy1 -> dt1 -> d(layer input)
