@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchromoformer_hip.so")
+LIB_PATH = os.environ.get("CF_LIB_PATH") or os.path.join(_HERE, "libchromoformer_hip.so")      # override: A/B experiments only
 CSRC = os.path.join(_HERE, "csrc")
 MAX_RES = 3
 BUCKET_REG, BUCKET_PE = 1, 2

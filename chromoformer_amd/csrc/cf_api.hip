@@ -207,6 +207,7 @@ struct cf_handle {
     float *pe[kMaxRes], *pet[kMaxRes];
     float *pe2[kMaxRes], *pet2[kMaxRes];      // padded layouts of the gene-batched attention kernel (cf_attc2.h)
     bool attc2 = false;
+    int xcd_map = 1;                          // XCD-aware placement of the Regulation workgroups (CF_XCD_MAP=0 turns it off)
     int n_wg_r = 0, n_cs_r = 0;               // leading entries of wg_tiles / cs_tiles that belong to the Regulation + head bucket
     long long bucket_split = 0;               // flat offset of the first Regulation parameter (bucket boundary)
     float *featc[kMaxRes], *ex0[kMaxRes], *edx0[kMaxRes], *edout[kMaxRes];
@@ -731,6 +732,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             if (e1 != hipSuccess || e2 != hipSuccess) h->attc2 = false;
         }
     }
+    if (const char* e = getenv("CF_XCD_MAP")) h->xcd_map = atoi(e) != 0;
     const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
     h->n_fwd = 2 + 3 + 1 + 3 * c.pair_layers + reg_launches + 1;       // retile, x0 | Embedding | lin_proj_p | Pairwise | Regulation | head
     h->n_bwd = 1 + reg_launches + 3 * c.pair_layers + 2 + 3 + 5;       // head | Regulation | Pairwise | join, dgrad | Embedding | reductions
@@ -1047,6 +1049,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         ra.T = T;
         ra.B = B;
         ra.n_res = nres;
+        ra.xcd_map = h->xcd_map;
         for (int r = 0; r < nres; ++r) ra.mask[r] = bt->interaction_mask[r];
         ra.freq = bt->interaction_freq;
         ra.save = save;
@@ -1177,6 +1180,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         ra.T = T;
         ra.B = B;
         ra.n_res = nres;
+        ra.xcd_map = h->xcd_map;
         for (int r = 0; r < nres; ++r) ra.mask[r] = bt->interaction_mask[r];
         ra.freq = bt->interaction_freq;
         ra.save = 1;

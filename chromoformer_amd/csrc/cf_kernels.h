@@ -119,6 +119,9 @@ __device__ __forceinline__ float group16_sum(float v) {
 // contiguous floats in fragment order [q][r][4], so a wave's load is one contiguous 1 KB
 // (55-60 B/clk/CU measured).  A sub-matrix starting at a row multiple of 16 has the same offset in
 // both layouts.  Column map: col(t, r) = t*16 + r.  KS = K / 16, ldw = K of the full tensor.
+#ifndef CF_APREFETCH
+#define CF_APREFETCH 1      // read the A operand of a k-step one step ahead (experiment switch)
+#endif
 constexpr int kRing = 4;      // register ring slots: chunks c+1 .. c+kRing-1 are in flight while chunk c is multiplied
 template <int NT, int KS>
 struct FragNT {
@@ -158,8 +161,8 @@ __device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, 
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float4 a = a_nxt;
-            if (c * 2 + k + 1 < KS) a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
+            const float4 a = CF_APREFETCH ? a_nxt : *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+            if (CF_APREFETCH && c * 2 + k + 1 < KS) a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float4 b = f.ring[c % kRing][k][t];
@@ -223,8 +226,8 @@ __device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, 
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float4 a = a_nxt;
-            if (c * 2 + k + 1 < KS) a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
+            const float4 a = CF_APREFETCH ? a_nxt : *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+            if (CF_APREFETCH && c * 2 + k + 1 < KS) a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

@@ -17,7 +17,7 @@ struct RegLayerDev {
 };
 struct RegArgs {
     const RegLayerDev* tab;          // [n_res][n_layers]
-    int n_layers, T, B, n_res;
+    int n_layers, T, B, n_res, xcd_map;
     const uint8_t* mask[kMaxRes];    // [B,T,T]
     const float* freq;               // [B,T,T]
     int save;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_reg_fwd(RegArgs a) {
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2.  XCD x
     // takes the contiguous slice [x * per, (x + 1) * per) of the (resolution-major) sequence list, so six XCDs stream
     // the weights of one resolution (5.5 MB) and two of them those of two, instead of all eight streaming all three.
-    const int per = gridDim.x >> 3, v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int per = gridDim.x >> 3, v = a.xcd_map ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : (int)blockIdx.x;
     if (v >= a.B * a.n_res) return;
     const int g = v % a.B, r = v / a.B, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_reg_bwd(RegArgs a) {
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2.  XCD x
     // takes the contiguous slice [x * per, (x + 1) * per) of the (resolution-major) sequence list, so six XCDs stream
     // the weights of one resolution (5.5 MB) and two of them those of two, instead of all eight streaming all three.
-    const int per = gridDim.x >> 3, v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int per = gridDim.x >> 3, v = a.xcd_map ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : (int)blockIdx.x;
     if (v >= a.B * a.n_res) return;
     const int g = v % a.B, r = v / a.B, T = TC > 0 ? TC : a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
