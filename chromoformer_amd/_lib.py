@@ -36,6 +36,11 @@ class cf_layout(C.Structure):
     _fields_ = [("n_tensors", C.c_int), ("n_total", C.c_longlong), ("n_active", C.c_longlong), ("n_elems", C.c_longlong)]
 
 
+class cf_attn_shape(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int),
+                ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int)]
+
+
 class cf_batch(C.Structure):
     _fields_ = [
         ("B", C.c_int),
@@ -77,6 +82,8 @@ SYMBOLS = {
     "cf_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cf_op_attention_fwd": (C.c_int, [C.POINTER(cf_attn_shape)] + [C.c_void_p] * 9),
+    "cf_op_attention_bwd": (C.c_int, [C.POINTER(cf_attn_shape)] + [C.c_void_p] * 14),
 }
 
 _lib = None
@@ -84,7 +91,7 @@ _lib = None
 
 def build(force=False, verbose=False):
     """Compile csrc/ for gfx950 into libchromoformer_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("cf_api.hip", "cf_kernels.h", "cf_reg_fused.h", "cf_attc2.h", "cf_head.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("cf_api.hip", "cf_kernels.h", "cf_reg_fused.h", "cf_attc2.h", "cf_head.h", "cf_attn.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "chromoformer_hip.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH

@@ -1674,3 +1674,68 @@ extern "C" int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, in
     HIP_TRY(hipFree(d));
     return 0;
 }
+
+static int attn_args(const cf_attn_shape* sh, AttnArgs& a) {
+    if (!sh) return fail("cf_op_attention: null shape");
+    if (sh->N < 1 || sh->H < 1 || sh->Lq < 1 || sh->Lk < 1) return fail("cf_op_attention: bad shape");
+    if (sh->N > 65535 || sh->H > 65535) return fail("cf_op_attention: N and H are grid dimensions (<= 65535)");
+    if ((sh->ldq | sh->ldk | sh->ldv | sh->ldo) & 3) return fail("cf_op_attention: row strides must be multiples of 4 floats");
+    if (sh->ldq < sh->H * kADh || sh->ldk < sh->H * kADh || sh->ldv < sh->H * kADh || sh->ldo < sh->H * kADh)
+        return fail("cf_op_attention: row stride smaller than H * 64");
+    memset(&a, 0, sizeof a);
+    a.N = sh->N;
+    a.H = sh->H;
+    a.Lq = sh->Lq;
+    a.Lk = sh->Lk;
+    a.ldq = sh->ldq;
+    a.ldk = sh->ldk;
+    a.ldv = sh->ldv;
+    a.ldo = sh->ldo;
+    a.rscale = 1.0f / sqrtf((float)kADh);
+    return 0;
+}
+extern "C" int cf_op_attention_fwd(const cf_attn_shape* sh, const float* q, const float* k, const float* v, const unsigned char* qvalid,
+                                   const unsigned char* kvalid, const unsigned char* mask, float* o, float* stats, void* stream) {
+    AttnArgs a;
+    if (attn_args(sh, a)) return -1;
+    if (!q || !k || !v || !o) return fail("cf_op_attention_fwd: null tensor");
+    a.q = q;
+    a.k = k;
+    a.v = v;
+    a.qvalid = qvalid;
+    a.kvalid = kvalid;
+    a.mask = mask;
+    a.o = o;
+    a.stats = stats;
+    hipLaunchKernelGGL(k_attn_fwd, dim3((a.Lq + kABq - 1) / kABq, a.H, a.N), dim3(256), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK("k_attn_fwd");
+    return 0;
+}
+extern "C" int cf_op_attention_bwd(const cf_attn_shape* sh, const float* q, const float* k, const float* v, const unsigned char* qvalid,
+                                   const unsigned char* kvalid, const unsigned char* mask, const float* o, const float* stats,
+                                   const float* d_o, float* dq, float* dk, float* dv, float* delta_ws, void* stream) {
+    AttnArgs a;
+    if (attn_args(sh, a)) return -1;
+    if (!q || !k || !v || !o || !stats || !d_o || !dq || !dk || !dv || !delta_ws) return fail("cf_op_attention_bwd: null tensor");
+    a.q = q;
+    a.k = k;
+    a.v = v;
+    a.qvalid = qvalid;
+    a.kvalid = kvalid;
+    a.mask = mask;
+    a.o = const_cast<float*>(o);
+    a.stats = const_cast<float*>(stats);
+    a.d_o = d_o;
+    a.dq = dq;
+    a.dk = dk;
+    a.dv = dv;
+    a.delta = delta_ws;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_attn_delta, dim3((a.Lq + 15) / 16, a.H, a.N), dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_attn_delta");
+    hipLaunchKernelGGL(k_attn_bwd_kv, dim3((a.Lk + kABk - 1) / kABk, a.H, a.N), dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_attn_bwd_kv");
+    hipLaunchKernelGGL(k_attn_bwd_q, dim3((a.Lq + kABq - 1) / kABq, a.H, a.N), dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_attn_bwd_q");
+    return 0;
+}

@@ -1,0 +1,377 @@
+// cf_attn.h -- dense (all query rows) multi-head attention core, forward and backward, f32 on the matrix cores
+// (included by cf_kernels.h).
+//
+// The training hot path never needs it (only the centre query row is consumed); it is the
+// kernel of the stress configuration (800-bin sequences, all L x L rows, attention-bound)
+// and of any consumer of a full-length embedding.  Semantics of MultiHeadAttention._attention /
+// PairwiseMultiHeadAttention (modules.py:58-77, 170-188):
+//     S = Q K^T / sqrt(dh);  S[masked] = -1e9 (replace, not add);  P = softmax(S);  O = P V
+// with mask = not (qvalid x kvalid) (what the dataset produces, data.py:156-161, 180-185) or an arbitrary byte
+// mask [N, Lq, Lk].  A fully masked row is a uniform distribution over all Lk keys, never NaN.
+//
+// Flash-style: one workgroup = 64 query rows of one (sequence, head), 16 rows per wave; keys / values stream
+// through LDS in tiles of 64; the score tile never leaves registers except for the transposition of P (D layout
+// -> A layout) through a per-wave LDS patch.  Backward recomputes P from the saved row statistics: one kernel per
+// output owner (k_attn_bwd_kv: dK, dV for a key tile, looping over query tiles; k_attn_bwd_q: dQ for a query
+// tile, looping over key tiles), so that no gradient needs atomics and the result is bit-reproducible.
+#pragma once
+
+namespace cf {
+
+constexpr int kADh = 64;        // head width of the Embedding / Pairwise stacks
+constexpr int kABq = 64;        // query rows per workgroup
+constexpr int kABk = 64;        // keys per LDS tile
+constexpr int kALd = kADh + 4;  // LDS row stride (floats)
+
+struct AttnArgs {
+    const float *q, *k, *v;            // [N, L, ld]: head h occupies columns [h*64, h*64 + 64)
+    int ldq, ldk, ldv;
+    const uint8_t *qvalid, *kvalid;    // [N, Lq], [N, Lk], 1 = real bin; null = all real
+    const uint8_t* mask;               // optional [N, Lq, Lk], 1 = masked; takes precedence over the valid vectors
+    float* o;                          // [N, Lq, ldo]
+    int ldo;
+    float* stats;                      // [N, H, Lq, 2]  row maximum m and 1 / sum exp(s - m) of the (masked, scaled) scores
+                                       // (kept apart: m = -1e9 on a fully masked row would swallow log(sum) in one float)
+    // backward only
+    const float* d_o;                  // [N, Lq, ldo]
+    float *dq, *dk, *dv;               // same layouts as q, k, v
+    float* delta;                      // [N, H, Lq]  rowsum(dO * O), workspace
+    int N, H, Lq, Lk;
+    float rscale;                      // 1 / sqrt(dh)
+};
+
+__device__ __forceinline__ bool attn_masked(const AttnArgs& a, int n, int i, int j, bool qv, bool kv) {
+    if (a.mask) return a.mask[((size_t)n * a.Lq + i) * a.Lk + j] != 0;
+    return !(qv && kv);
+}
+__device__ __forceinline__ bool attn_kvalid(const AttnArgs& a, int n, int j) {
+    return j < a.Lk && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + j] != 0 : true);
+}
+
+// stage a [64 x 64] tile of rows r0.. of one head into LDS (rows beyond `rows` are zero)
+__device__ __forceinline__ void attn_stage(float* dst, const float* __restrict__ src, int ld, int r0, int rows) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int j = i >> 4, d4 = i & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + j < rows) v = ldg4(src + (size_t)(r0 + j) * ld + d4 * 4);
+        *reinterpret_cast<float4*>(dst + j * kALd + d4 * 4) = v;
+    }
+}
+
+// acc[t] (16 x 16 tiles, t = 0..3) += A[16 x 64] . B^T where B is a [64 x 64] LDS tile read along its rows:
+// out column 16t + r <-> B row 16t + r, reduction over the 64 columns of A and B (float4 reads, permuted k order).
+__device__ __forceinline__ void attn_mma_nt(const float4 (&af)[4], const float* Bs, f32x4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 b = *reinterpret_cast<const float4*>(Bs + (16 * t + r) * kALd + 16 * u + 4 * q);
+            acc[t] = mfma4(af[u].x, b.x, acc[t]);
+            acc[t] = mfma4(af[u].y, b.y, acc[t]);
+            acc[t] = mfma4(af[u].z, b.z, acc[t]);
+            acc[t] = mfma4(af[u].w, b.w, acc[t]);
+        }
+}
+// acc[t] += A[16 x 64] . B where B is a [64 x 64] LDS tile in natural [k][n] layout: out column 16t + r, the
+// reduction index runs over B's rows (scalar reads), A comes from an LDS patch [16][kALd] (float4 along k).
+__device__ __forceinline__ void attn_mma_nn(const float* As, const float* Bs, f32x4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float4 av = *reinterpret_cast<const float4*>(As + r * kALd + 16 * u + 4 * q);
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma4(a4[i], Bs[(16 * u + 4 * q + i) * kALd + 16 * t + r], acc[t]);
+    }
+}
+// store a D-layout tile set (rows 4q + reg, columns 16t + r) into an LDS patch [16][kALd]
+__device__ __forceinline__ void attn_store_d(float* Ps, const f32x4 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Ps[(4 * q + g) * kALd + 16 * t + r] = acc[t][g];
+}
+
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
+    __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
+    __shared__ __attribute__((aligned(16))) float Ps[4][16 * kALd];
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * kABq;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
+    const int row_a = q0 + 16 * w + r;                  // the row this lane feeds as A operand
+    float4 qf[4];
+    {
+        const float* qp = a.q + ((size_t)n * a.Lq + min(row_a, a.Lq - 1)) * a.ldq + h * kADh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qf[u] = row_a < a.Lq ? ldg4(qp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int rowi[4];
+    bool qv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        rowi[g] = q0 + 16 * w + 4 * qd + g;              // the rows this lane holds in D layout
+        qv[g] = rowi[g] < a.Lq && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + rowi[g]] != 0 : true);
+    }
+    float m[4], l[4];
+    f32x4 o[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+    }
+    zero_acc(o);
+    const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
+    const float* vbase = a.v + (size_t)n * a.Lk * a.ldv + h * kADh;
+    for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
+        __syncthreads();
+        attn_stage(Ks, kbase, a.ldk, k0, a.Lk);
+        attn_stage(Vs, vbase, a.ldv, k0, a.Lk);
+        __syncthreads();
+        f32x4 s[4];
+        zero_acc(s);
+        attn_mma_nt(qf, Ks, s);
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = k0 + 16 * t + r;
+            const bool kvj = attn_kvalid(a, n, j);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float x = s[t][g] * a.rscale;
+                if (j < a.Lk && rowi[g] < a.Lq) {
+                    if (attn_masked(a, n, rowi[g], j, qv[g], kvj)) x = kMaskFill;
+                } else {
+                    x = -INFINITY;                        // beyond the tensor: not part of the softmax at all
+                }
+                s[t][g] = x;
+                mx[g] = fmaxf(mx[g], x);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx[g] = fmaxf(mx[g], __shfl_xor(mx[g], off, 64));
+            const float mn = fmaxf(m[g], mx[g]);
+            const float alpha = mn == -INFINITY ? 1.f : __expf(m[g] - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float p = mn == -INFINITY ? 0.f : __expf(s[t][g] - mn);
+                s[t][g] = p;
+                ps += p;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+            l[g] = l[g] * alpha + ps;
+            m[g] = mn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t][g] *= alpha;
+        }
+        attn_store_d(&Ps[w][0], s);                       // per-wave patch: only this wave reads it back
+        __builtin_amdgcn_wave_barrier();
+        attn_mma_nn(&Ps[w][0], Vs, o);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (rowi[g] >= a.Lq) continue;
+        const float inv = 1.0f / l[g];
+        float* op = a.o + ((size_t)n * a.Lq + rowi[g]) * a.ldo + h * kADh;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) op[16 * t + r] = o[t][g] * inv;
+        if (a.stats && r == 0) {
+            float* sp = a.stats + (((size_t)n * a.H + h) * a.Lq + rowi[g]) * 2;
+            sp[0] = m[g];
+            sp[1] = inv;
+        }
+    }
+}
+
+// delta[n, h, i] = sum_d dO[n, i, h, d] * O[n, i, h, d]
+__global__ __launch_bounds__(256) void k_attn_delta(AttnArgs a) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15, h = blockIdx.y, n = blockIdx.z;
+    if (row >= a.Lq) return;
+    const size_t o = ((size_t)n * a.Lq + row) * a.ldo + h * kADh + 4 * sub;
+    const float4 x = ldg4(a.o + o), y = ldg4(a.d_o + o);
+    float s = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    s = group16_sum(s);
+    if (sub == 0) a.delta[((size_t)n * a.H + h) * a.Lq + row] = s;
+}
+
+// Recompute the probability tile of 16 query rows (this wave) x 64 keys in D layout and turn it into dS.
+//   p  = exp(s - m) / sum       (0 beyond the tensor; 1/Lk for a fully masked row, like the forward)
+//   ds = p * (dp - delta) / sqrt(dh), and 0 where the score was replaced by the mask fill
+__device__ __forceinline__ void attn_p_ds(const AttnArgs& a, int n, int k0, const int (&rowi)[4], const bool (&qv)[4],
+                                          const float (&mrow)[4], const float (&linv)[4], const float (&dl)[4], f32x4 (&s)[4],
+                                          const f32x4 (&dp)[4], f32x4 (&ds)[4]) {
+    const int r = threadIdx.x & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = k0 + 16 * t + r;
+        const bool kvj = attn_kvalid(a, n, j);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float p = 0.f, d = 0.f;
+            if (j < a.Lk && rowi[g] < a.Lq) {
+                const bool mk = attn_masked(a, n, rowi[g], j, qv[g], kvj);
+                const float x = mk ? kMaskFill : s[t][g] * a.rscale;
+                p = __expf(x - mrow[g]) * linv[g];
+                d = mk ? 0.f : p * (dp[t][g] - dl[g]) * a.rscale;
+            }
+            s[t][g] = p;
+            ds[t][g] = d;
+        }
+    }
+}
+
+// dK, dV of one key tile: loop over the query tiles.  Wave w owns keys 16w .. 16w+15 of the tile.
+//   dV[j] += sum_i p[i][j] dO[i]        dK[j] += sum_i ds[i][j] Q[i]
+__global__ __launch_bounds__(256) void k_attn_bwd_kv(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
+    __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
+    __shared__ __attribute__((aligned(16))) float Pt[4][16 * kALd];     // per-wave patches: p^T / ds^T [16 keys][64 rows]
+    const int n = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * kABk;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
+    // this wave's 16 keys as the A operand of S^T = K Q^T and dP^T = V dO^T
+    const int key_a = k0 + 16 * w + r;
+    float4 kf[4], vf[4];
+    {
+        const float* kp = a.k + ((size_t)n * a.Lk + min(key_a, a.Lk - 1)) * a.ldk + h * kADh;
+        const float* vp = a.v + ((size_t)n * a.Lk + min(key_a, a.Lk - 1)) * a.ldv + h * kADh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kf[u] = key_a < a.Lk ? ldg4(kp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vf[u] = key_a < a.Lk ? ldg4(vp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    int keyi[4];
+    bool kv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        keyi[g] = k0 + 16 * w + 4 * qd + g;              // keys this lane holds in D layout (rows of S^T)
+        kv[g] = keyi[g] < a.Lk && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + keyi[g]] != 0 : true);
+    }
+    f32x4 dk[4], dv[4];
+    zero_acc(dk);
+    zero_acc(dv);
+    const float* qbase = a.q + (size_t)n * a.Lq * a.ldq + h * kADh;
+    const float* gbase = a.d_o + (size_t)n * a.Lq * a.ldo + h * kADh;
+    const float* stp = a.stats + ((size_t)n * a.H + h) * a.Lq * 2;
+    const float* dlp = a.delta + ((size_t)n * a.H + h) * a.Lq;
+    for (int q0 = 0; q0 < a.Lq; q0 += kABq) {
+        __syncthreads();
+        attn_stage(Qs, qbase, a.ldq, q0, a.Lq);
+        attn_stage(Gs, gbase, a.ldo, q0, a.Lq);
+        __syncthreads();
+        f32x4 st[4], dpt[4];                               // S^T, dP^T: rows = keys 4qd+g, columns = query 16t + r
+        zero_acc(st);
+        zero_acc(dpt);
+        attn_mma_nt(kf, Qs, st);
+        attn_mma_nt(vf, Gs, dpt);
+        f32x4 pt[4], dst[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = q0 + 16 * t + r;
+            const bool iv = i < a.Lq;
+            const float mrow = iv ? stp[2 * i] : 0.f, linv = iv ? stp[2 * i + 1] : 0.f, dl = iv ? dlp[i] : 0.f;
+            const bool qvi = iv && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + i] != 0 : true);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float p = 0.f, d = 0.f;
+                if (iv && keyi[g] < a.Lk) {
+                    const bool mk = a.mask ? a.mask[((size_t)n * a.Lq + i) * a.Lk + keyi[g]] != 0 : !(qvi && kv[g]);
+                    const float x = mk ? kMaskFill : st[t][g] * a.rscale;
+                    p = __expf(x - mrow) * linv;
+                    d = mk ? 0.f : p * (dpt[t][g] - dl) * a.rscale;
+                }
+                pt[t][g] = p;
+                dst[t][g] = d;
+            }
+        }
+        attn_store_d(&Pt[w][0], pt);
+        __builtin_amdgcn_wave_barrier();
+        attn_mma_nn(&Pt[w][0], Gs, dv);                   // dV[16 keys x 64] += P^T[16 x 64 rows] . dO[64 rows x 64]
+        __builtin_amdgcn_wave_barrier();
+        attn_store_d(&Pt[w][0], dst);
+        __builtin_amdgcn_wave_barrier();
+        attn_mma_nn(&Pt[w][0], Qs, dk);                   // dK += dS^T . Q
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (keyi[g] >= a.Lk) continue;
+        float* dkp = a.dk + ((size_t)n * a.Lk + keyi[g]) * a.ldk + h * kADh;
+        float* dvp = a.dv + ((size_t)n * a.Lk + keyi[g]) * a.ldv + h * kADh;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dkp[16 * t + r] = dk[t][g];
+            dvp[16 * t + r] = dv[t][g];
+        }
+    }
+}
+
+// dQ of one query tile: loop over the key tiles.   dQ[i] += sum_j ds[i][j] K[j]
+__global__ __launch_bounds__(256) void k_attn_bwd_q(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
+    __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
+    __shared__ __attribute__((aligned(16))) float Ds[4][16 * kALd];
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * kABq;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
+    const int row_a = q0 + 16 * w + r;
+    float4 qf[4], gf[4];
+    {
+        const size_t ro = (size_t)n * a.Lq + min(row_a, a.Lq - 1);
+        const float* qp = a.q + ro * a.ldq + h * kADh;
+        const float* gp = a.d_o + ro * a.ldo + h * kADh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            qf[u] = row_a < a.Lq ? ldg4(qp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gf[u] = row_a < a.Lq ? ldg4(gp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    int rowi[4];
+    bool qv[4];
+    float mrow[4], linv[4], dl[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        rowi[g] = q0 + 16 * w + 4 * qd + g;
+        const bool iv = rowi[g] < a.Lq;
+        const size_t so = ((size_t)n * a.H + h) * a.Lq + (iv ? rowi[g] : 0);
+        qv[g] = iv && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + rowi[g]] != 0 : true);
+        mrow[g] = iv ? a.stats[2 * so] : 0.f;
+        linv[g] = iv ? a.stats[2 * so + 1] : 0.f;
+        dl[g] = iv ? a.delta[so] : 0.f;
+    }
+    f32x4 dq[4];
+    zero_acc(dq);
+    const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
+    const float* vbase = a.v + (size_t)n * a.Lk * a.ldv + h * kADh;
+    for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
+        __syncthreads();
+        attn_stage(Ks, kbase, a.ldk, k0, a.Lk);
+        attn_stage(Vs, vbase, a.ldv, k0, a.Lk);
+        __syncthreads();
+        f32x4 s[4], dp[4], ds[4];
+        zero_acc(s);
+        zero_acc(dp);
+        attn_mma_nt(qf, Ks, s);
+        attn_mma_nt(gf, Vs, dp);                          // dP = dO V^T
+        attn_p_ds(a, n, k0, rowi, qv, mrow, linv, dl, s, dp, ds);
+        attn_store_d(&Ds[w][0], ds);
+        __builtin_amdgcn_wave_barrier();
+        attn_mma_nn(&Ds[w][0], Ks, dq);                   // dQ += dS . K
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (rowi[g] >= a.Lq) continue;
+        float* dqp = a.dq + ((size_t)n * a.Lq + rowi[g]) * a.ldq + h * kADh;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dqp[16 * t + r] = dq[t][g];
+    }
+}
+
+}  // namespace cf

@@ -1501,3 +1501,4 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
 #include "cf_reg_fused.h"
 #include "cf_attc2.h"
 #include "cf_head.h"
+#include "cf_attn.h"

@@ -195,6 +195,29 @@ int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, int N, int K,
 /* dX[M,K] = dY[M,N] . W[N,K]                         -- its input gradient            */
 int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream);
 
+/* Dense attention core with ALL query rows (MultiHeadAttention._attention, modules.py:58-77;
+ * PairwiseMultiHeadAttention, modules.py:170-188), head width 64:
+ *     O = softmax(masked_fill(Q K^T / sqrt(64), mask, -1e9)) V        per (sequence n, head h)
+ * q, k, v, o are [N, L, ld*] row-major with head h in columns [64 h, 64 h + 64) -- i.e. the chunks of the
+ * reference's fused projection can be passed in place (pointer offset + ld).  mask = not (qvalid x kvalid) from
+ * two byte vectors (1 = real bin; null = all real), or an arbitrary byte mask [N, Lq, Lk] (1 = masked).
+ * stats [N, H, Lq, 2] receives the softmax row statistics the backward pass needs.  The training path does not
+ * call this (it evaluates the centre query row only); it serves the 800-bin stress configuration and consumers
+ * of full-length embeddings. */
+typedef struct cf_attn_shape {
+    int N, H, Lq, Lk;
+    int ldq, ldk, ldv, ldo;
+} cf_attn_shape;
+int cf_op_attention_fwd(const cf_attn_shape* shape, const float* q, const float* k, const float* v,
+                        const unsigned char* qvalid, const unsigned char* kvalid, const unsigned char* mask,
+                        float* o, float* stats, void* stream);
+/* Its backward: dq, dk, dv in the layouts of q, k, v (only the 64 H columns of the heads are written);
+ * delta_ws: workspace of N*H*Lq floats.  No atomics: bit-reproducible. */
+int cf_op_attention_bwd(const cf_attn_shape* shape, const float* q, const float* k, const float* v,
+                        const unsigned char* qvalid, const unsigned char* kvalid, const unsigned char* mask,
+                        const float* o, const float* stats, const float* d_o, float* dq, float* dk, float* dv,
+                        float* delta_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

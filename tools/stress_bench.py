@@ -1,0 +1,61 @@
+"""Stress configuration (BASELINE.json configs[3]): the dense attention core at 800-bin
+sequences, all L x L rows, forward + backward, timed with HIP (torch) events on the launch stream.
+    python tools/stress_bench.py [--n-seq 2176] [--reps 5]
+i_max = 16, bsz = 128 -> N = 128 * (1 + 16) = 2176 sequences, h = 2, dh = 64, L = 800.
+Algorithmic flops: forward 4 N H L^2 dh (QK^T and PV), backward 10 N H L^2 dh (dV, dP, dS.K, dS^T.Q + the recomputed
+QK^T is NOT counted: it is re-execution, not algorithmic work)."""
+import argparse, ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from chromoformer_amd import _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n-seq", type=int, default=2176)
+ap.add_argument("--L", type=int, default=800)
+ap.add_argument("--reps", type=int, default=5)
+args = ap.parse_args()
+N, H, L = args.n_seq, 2, args.L
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(0)
+proj = torch.randn(N, L, 3 * H * 64, device=dev, generator=g)
+q, k, v = proj[:, :, :128], proj[:, :, 128:256], proj[:, :, 256:]
+d_o = torch.randn(N, L, H * 64, device=dev, generator=g)
+o = torch.empty(N, L, H * 64, device=dev)
+stats = torch.empty(N, H, L, 2, device=dev)
+dproj = torch.zeros_like(proj)
+dq, dk, dv = dproj[:, :, :128], dproj[:, :, 128:256], dproj[:, :, 256:]
+ws = torch.empty(N * H * L, device=dev)
+valid = torch.ones(N, L, dtype=torch.uint8, device=dev)
+lib = _lib.lib()
+sh = _lib.cf_attn_shape(N, H, L, L, 3 * H * 64, 3 * H * 64, 3 * H * 64, H * 64)
+st = torch.cuda.current_stream().cuda_stream
+p = lambda t: C.c_void_p(t.data_ptr())
+
+
+def fwd():
+    _lib.check(lib.cf_op_attention_fwd(C.byref(sh), p(q), p(k), p(v), p(valid), p(valid), None, p(o), p(stats), st), "fwd")
+
+
+def bwd():
+    _lib.check(lib.cf_op_attention_bwd(C.byref(sh), p(q), p(k), p(v), p(valid), p(valid), None, p(o), p(stats), p(d_o), p(dq), p(dk), p(dv), p(ws), st), "bwd")
+
+
+def timed(fn):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / args.reps
+
+
+tf, tb = timed(fwd), timed(bwd)
+ff, fb = 4.0 * N * H * L * L * 64, 10.0 * N * H * L * L * 64
+print(json.dumps({"workload": "dense attention core, N=%d sequences x %d heads, L=%d, dh=64, f32" % (N, H, L),
+                  "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
+                  "fwd_tflops": round(ff / tf / 1e9, 2), "bwd_tflops": round(fb / tb / 1e9, 2),
+                  "fwd_bwd_tflops": round((ff + fb) / (tf + tb) / 1e9, 2), "peak_tflops_f32_mfma": 157.3,
+                  "frac": round((ff + fb) / (tf + tb) / 1e9 / 157.3, 4)}))
