@@ -48,13 +48,23 @@ __device__ __forceinline__ bool attn_kvalid(const AttnArgs& a, int n, int j) {
     return j < a.Lk && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + j] != 0 : true);
 }
 
-// stage a [64 x 64] tile of rows r0.. of one head into LDS (rows beyond `rows` are zero)
-__device__ __forceinline__ void attn_stage(float* dst, const float* __restrict__ src, int ld, int r0, int rows) {
-    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-        const int j = i >> 4, d4 = i & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + j < rows) v = ldg4(src + (size_t)(r0 + j) * ld + d4 * 4);
-        *reinterpret_cast<float4*>(dst + j * kALd + d4 * 4) = v;
+// [64 x 64] tile of rows r0.. of one head: global -> registers -> LDS (rows beyond `rows` are zero), in two halves,
+// so that the global loads of tile i+1 are in flight while tile i is multiplied
+struct AttnTileRegs {
+    float4 v[4];
+};
+__device__ __forceinline__ void attn_fetch(AttnTileRegs& t, const float* __restrict__ src, int ld, int r0, int rows) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = threadIdx.x + 256 * p, j = i >> 4, d4 = i & 15;
+        t.v[p] = r0 + j < rows ? ldg4(src + (size_t)(r0 + j) * ld + d4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void attn_put(float* dst, const AttnTileRegs& t) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = threadIdx.x + 256 * p, j = i >> 4, d4 = i & 15;
+        *reinterpret_cast<float4*>(dst + j * kALd + d4 * 4) = t.v[p];
     }
 }
 
@@ -126,11 +136,18 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     zero_acc(o);
     const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
     const float* vbase = a.v + (size_t)n * a.Lk * a.ldv + h * kADh;
+    AttnTileRegs kr, vr;
+    attn_fetch(kr, kbase, a.ldk, 0, a.Lk);
+    attn_fetch(vr, vbase, a.ldv, 0, a.Lk);
     for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
         __syncthreads();
-        attn_stage(Ks, kbase, a.ldk, k0, a.Lk);
-        attn_stage(Vs, vbase, a.ldv, k0, a.Lk);
+        attn_put(Ks, kr);
+        attn_put(Vs, vr);
         __syncthreads();
+        if (k0 + kABk < a.Lk) {
+            attn_fetch(kr, kbase, a.ldk, k0 + kABk, a.Lk);
+            attn_fetch(vr, vbase, a.ldv, k0 + kABk, a.Lk);
+        }
         f32x4 s[4];
         zero_acc(s);
         attn_mma_nt(qf, Ks, s);
@@ -261,11 +278,18 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv(AttnArgs a) {
     const float* gbase = a.d_o + (size_t)n * a.Lq * a.ldo + h * kADh;
     const float* stp = a.stats + ((size_t)n * a.H + h) * a.Lq * 2;
     const float* dlp = a.delta + ((size_t)n * a.H + h) * a.Lq;
+    AttnTileRegs qr, gr;
+    attn_fetch(qr, qbase, a.ldq, 0, a.Lq);
+    attn_fetch(gr, gbase, a.ldo, 0, a.Lq);
     for (int q0 = 0; q0 < a.Lq; q0 += kABq) {
         __syncthreads();
-        attn_stage(Qs, qbase, a.ldq, q0, a.Lq);
-        attn_stage(Gs, gbase, a.ldo, q0, a.Lq);
+        attn_put(Qs, qr);
+        attn_put(Gs, gr);
         __syncthreads();
+        if (q0 + kABq < a.Lq) {
+            attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
+            attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
+        }
         f32x4 st[4], dpt[4];                               // S^T, dP^T: rows = keys 4qd+g, columns = query 16t + r
         zero_acc(st);
         zero_acc(dpt);
@@ -349,11 +373,18 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q(AttnArgs a) {
     zero_acc(dq);
     const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
     const float* vbase = a.v + (size_t)n * a.Lk * a.ldv + h * kADh;
+    AttnTileRegs kr, vr;
+    attn_fetch(kr, kbase, a.ldk, 0, a.Lk);
+    attn_fetch(vr, vbase, a.ldv, 0, a.Lk);
     for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
         __syncthreads();
-        attn_stage(Ks, kbase, a.ldk, k0, a.Lk);
-        attn_stage(Vs, vbase, a.ldv, k0, a.Lk);
+        attn_put(Ks, kr);
+        attn_put(Vs, vr);
         __syncthreads();
+        if (k0 + kABk < a.Lk) {
+            attn_fetch(kr, kbase, a.ldk, k0 + kABk, a.Lk);
+            attn_fetch(vr, vbase, a.ldv, k0 + kABk, a.Lk);
+        }
         f32x4 s[4], dp[4], ds[4];
         zero_acc(s);
         zero_acc(dp);
