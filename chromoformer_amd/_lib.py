@@ -82,6 +82,7 @@ SYMBOLS = {
     "cf_op_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cf_bin_regions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_attention_fwd": (C.c_int, [C.POINTER(cf_attn_shape)] + [C.c_void_p] * 9),
     "cf_op_attention_bwd": (C.c_int, [C.POINTER(cf_attn_shape)] + [C.c_void_p] * 14),
 }
@@ -91,7 +92,7 @@ _lib = None
 
 def build(force=False, verbose=False):
     """Compile csrc/ for gfx950 into libchromoformer_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("cf_api.hip", "cf_kernels.h", "cf_reg_fused.h", "cf_attc2.h", "cf_head.h", "cf_attn.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("cf_api.hip", "cf_kernels.h", "cf_reg_fused.h", "cf_attc2.h", "cf_head.h", "cf_attn.h", "cf_bin.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "chromoformer_hip.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH

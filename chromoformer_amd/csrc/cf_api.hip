@@ -1739,3 +1739,14 @@ extern "C" int cf_op_attention_bwd(const cf_attn_shape* sh, const float* q, cons
     LAUNCH_CHECK("k_attn_bwd_q");
     return 0;
 }
+
+static_assert(sizeof(cf_bin_job) == sizeof(BinJob), "cf_bin_job layout");
+extern "C" int cf_bin_regions(const cf_bin_job* jobs, int n_jobs, int n_feats, int bin_size, int n_bins_out, void* stream) {
+    if (!jobs) return fail("cf_bin_regions: null job table");
+    if (n_jobs < 0 || n_feats < 1 || n_feats > 64 || bin_size < 1 || n_bins_out < 1) return fail("cf_bin_regions: bad argument");
+    if (n_jobs == 0) return 0;
+    hipLaunchKernelGGL(k_bin_regions, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const BinJob*>(jobs), n_feats,
+                       bin_size, n_bins_out);
+    LAUNCH_CHECK("k_bin_regions");
+    return 0;
+}

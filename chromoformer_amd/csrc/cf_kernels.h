@@ -1502,3 +1502,4 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
 #include "cf_attc2.h"
 #include "cf_head.h"
 #include "cf_attn.h"
+#include "cf_bin.h"

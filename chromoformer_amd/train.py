@@ -6,7 +6,8 @@ same config.yaml schema and same .pt checkpoint layout as
 
   * the model runs on the HIP path (chromoformer_amd.net) and a step is one library sequence
     (forward, loss, backward, [RCCL all-reduce], AdamW) replayed from a hipGraph;
-  * genes are binned once into a pinned host store instead of per step in 8 loader processes;
+  * genes are binned once, on the GPU (cf_bin_regions), into a store that stays resident in HBM, instead of per
+    step in 8 loader processes; batches are gathered on the device;
   * launched under torch.distributed.run it trains data-parallel, one process per GPU
     (`bsz` is then the per-GPU batch and the gradients are averaged over ranks);
   * `--binsizes` given on the command line are parsed as ints (the reference crashes on them).
@@ -135,7 +136,8 @@ def main(argv=None):
     def store_of(genes):
         ds = ChromoformerDataset(args.meta, args.npy_dir, genes, n_feats, i_max, args.binsizes, w_prom, w_max,
                                  regression=args.regression)
-        return GeneStore(ds, progress=(rank == 0))
+        # raw fp16 signals are binned on the GPU (cf_bin_regions) and the split stays resident in HBM
+        return GeneStore(ds, progress=(rank == 0), device=torch.device("cuda", local), resident=True)
 
     train_store, val_store = store_of(train_genes), store_of(val_genes)
 
@@ -269,7 +271,7 @@ def _validate(model, trainer, store, bsz, rank, world):
         parts = [torch.zeros_like(pad) for _ in range(world)]
         torch.distributed.all_gather(parts, pad)
         mine = torch.cat([p[: max(0, min(n, (r + 1) * per) - min(n, r * per))] for r, p in enumerate(parts)])
-    return mine.cpu(), store.label.clone()
+    return mine.cpu(), store.label.cpu().clone()
 
 
 if __name__ == "__main__":

@@ -195,6 +195,23 @@ int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, int N, int K,
 /* dX[M,K] = dY[M,N] . W[N,K]                         -- its input gradient            */
 int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream);
 
+/* ---- input pipeline ------------------------------------------------------------------ */
+/* ChromoformerDataset._bin_and_pad + strand flip (data.py:68-113) on the device: per region, the window
+ * [col0, col0 + ncols) of the raw fp16 signal [n_feats, ld] is averaged over bins of `bin_size` samples (short last
+ * bin included), passed through log(1 + x), centred in n_bins_out bins (ceil-left / floor-right zero padding) and
+ * mirrored if `flip`; out receives [n_bins_out, n_feats] fp32 (the slot of the region in a batch / store array),
+ * mask (optional) the pad bytes [n_bins_out] (1 = padding).  `jobs` is a DEVICE array.  The caller guarantees
+ * ceil(ncols / bin_size) <= n_bins_out (the reference raises for longer regions, data.py:168-169). */
+typedef struct cf_bin_job {
+    const void* raw;
+    long long ld;
+    int col0, ncols;
+    int flip, reserved;
+    float* out;
+    unsigned char* mask;
+} cf_bin_job;
+int cf_bin_regions(const cf_bin_job* jobs, int n_jobs, int n_feats, int bin_size, int n_bins_out, void* stream);
+
 /* Dense attention core with ALL query rows (MultiHeadAttention._attention, modules.py:58-77;
  * PairwiseMultiHeadAttention, modules.py:170-188), head width 64:
  *     O = softmax(masked_fill(Q K^T / sqrt(64), mask, -1e9)) V        per (sequence n, head h)
