@@ -1,0 +1,39 @@
+"""CV-sweep scheduler (replicas over GPUs, chromoformer/Snakefile): job plan, command lines, GPU pinning, resume."""
+import argparse
+import os
+
+from chromoformer_amd import sweep
+
+
+class _Proc:
+    def __init__(self, cmd, env, log):
+        self.cmd, self.env, self.polls = cmd, env, 0
+
+    def poll(self):
+        self.polls += 1
+        if self.polls < 2:
+            return None
+        open(self.cmd[self.cmd.index("-o") + 1], "w").write("ckpt")          # the training wrote its checkpoint
+        return 0
+
+
+def test_plan_commands_and_gpu_assignment(tmp_path):
+    jobs = sweep.plan(["E003", "E004"], ["1", "2", "3", "4"], "exp", "1", str(tmp_path / "ckpts"))
+    assert len(jobs) == 8 and jobs[0][2].endswith(os.path.join("E003", "exp-E003-conf1-fold1.pt"))
+    args = argparse.Namespace(config="c.yaml", exp_id="exp", meta_template="d/{eid}/train.csv", npy_dir_template="d/{eid}/npy",
+                              binsizes=None, regression=True, gpus=3, poll=0.0)
+    started = []
+
+    def launch(cmd, env, stdout, stderr):
+        p = _Proc(cmd, env, stdout)
+        started.append(p)
+        return p
+
+    done = sweep.run(jobs, args, launch=launch)
+    assert len(done) == 8 and set(done.values()) == {0}
+    assert {p.env["HIP_VISIBLE_DEVICES"] for p in started} == {"0", "1", "2"}
+    c = started[3].cmd                                    # E003 fold 4 -> train.py's fold 0
+    assert c[c.index("--fold") + 1] == "0" and "--regression" in c and c[c.index("-m", 3) + 1] == "d/E003/train.csv"
+    # resume: everything exists now, nothing is launched again
+    started.clear()
+    assert sweep.run(jobs, args, launch=launch) == done and not started
