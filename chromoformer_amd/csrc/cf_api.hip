@@ -724,12 +724,16 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     }
     {   // gene-batched attention kernel when its LDS image (8 regions of features + 16 score rows) fits
         size_t need = 0;
-        for (int r = 0; r < c.n_res; ++r) need = std::max(need, attc2_smem(c.n_bins[r], c.n_feats));
+        for (int r = 0; r < c.n_res; ++r) need = std::max(need, attc2_smem(c.n_bins[r], c.n_feats, kAGMax));
         h->attc2 = need <= 160 * 1024;
         if (h->attc2) {
-            hipError_t e1 = hipFuncSetAttribute((const void*)k_attc2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-            hipError_t e2 = hipFuncSetAttribute((const void*)k_attc2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-            if (e1 != hipSuccess || e2 != hipSuccess) h->attc2 = false;
+            for (int ag = 1; ag <= kAGMax; ag *= 2) {
+                size_t nd = 0;
+                for (int r = 0; r < c.n_res; ++r) nd = std::max(nd, attc2_smem(c.n_bins[r], c.n_feats, ag));
+                hipError_t e1 = hipFuncSetAttribute(attc2_kernel<false>(ag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nd);
+                hipError_t e2 = hipFuncSetAttribute(attc2_kernel<true>(ag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nd);
+                if (e1 != hipSuccess || e2 != hipSuccess) h->attc2 = false;
+            }
         }
     }
     if (const char* e = getenv("CF_XCD_MAP")) h->xcd_map = atoi(e) != 0;
@@ -961,6 +965,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         hipLaunchKernelGGL(k_qchain_fwd, dim3(tiles_of(N), nres), dim3(256), 0, st, q);
         LAUNCH_CHECK("k_qchain_fwd");
         if (h->attc2) {
+            const int ag = attc2_regions_per_wg(N);
             Attc2Args a2;
             size_t sm2 = 0;
             for (int r = 0; r < nres; ++r) {
@@ -977,14 +982,15 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
                 a2.L[r] = at.L[r];
                 a2.Lpad[r] = attc2_lpad(at.L[r]);
                 a2.LT[r] = attc2_lt(at.L[r]);
-                sm2 = std::max(sm2, attc2_smem(at.L[r], F));
+                sm2 = std::max(sm2, attc2_smem(at.L[r], F, ag));
             }
             a2.N = N;
             a2.F = F;
             a2.scale = scale_c;
             a2.rscale = 1.0f / a2.scale;
             a2.tdbg = getenv("CF_STAMP_ATTC") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
-            hipLaunchKernelGGL((k_attc2<false>), dim3((N + kAG - 1) / kAG, nres), dim3(kAT), sm2, st, a2);
+            void* kargs2[] = {&a2};
+            HIP_TRY(hipLaunchKernel(attc2_kernel<false>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
         } else {
             hipLaunchKernelGGL((k_attc<false>), dim3(N, nres), dim3(256), smem, st, at);
         }
@@ -1298,6 +1304,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         launch_post_bwd<true, 128>(dff, dim3(tiles_of(N), nres), st, pb);
         LAUNCH_CHECK("k_post_bwd<centre>");
         if (h->attc2) {
+            const int ag = attc2_regions_per_wg(N);
             Attc2Args a2;
             size_t sm2 = 0;
             for (int r = 0; r < nres; ++r) {
@@ -1314,14 +1321,15 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
                 a2.L[r] = at.L[r];
                 a2.Lpad[r] = attc2_lpad(at.L[r]);
                 a2.LT[r] = attc2_lt(at.L[r]);
-                sm2 = std::max(sm2, attc2_smem(at.L[r], F));
+                sm2 = std::max(sm2, attc2_smem(at.L[r], F, ag));
             }
             a2.N = N;
             a2.F = F;
             a2.scale = scale_c;
             a2.rscale = 1.0f / a2.scale;
             a2.tdbg = getenv("CF_STAMP_ATTC") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
-            hipLaunchKernelGGL((k_attc2<true>), dim3((N + kAG - 1) / kAG, nres), dim3(kAT), sm2, st, a2);
+            void* kargs2[] = {&a2};
+            HIP_TRY(hipLaunchKernel(attc2_kernel<true>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
         } else {
             hipLaunchKernelGGL((k_attc<true>), dim3(N, nres), dim3(256), smem, st, at);
         }

@@ -33,15 +33,15 @@ struct Attc2Args {
 };
 #define CF_STAMP2(slot)                                                                                   \
     do {                                                                                                  \
-        if (a.tdbg && blockIdx.x == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0)                  \
+        if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                              \
             a.tdbg[(BWD ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime();                               \
     } while (0)
-constexpr int kAG = 8;                                   // regions per workgroup
+constexpr int kAGMax = 8;                                // regions per workgroup: 8, 4, 2 or 1 (template parameter AG)
 constexpr int kAT = 512;                                 // threads per workgroup (8 waves)
 __host__ __device__ inline int attc2_lpad(int L) { return (L + 255) / 256 * 256; }
 __host__ __device__ inline int attc2_lt(int L) { return (L + 63) / 64 * 64 + 64; }
-__host__ __device__ inline size_t attc2_smem(int L, int F) {
-    return (size_t)(kTile * (attc2_lpad(L) + 4) + 2 * kTile * (kD + 4) + 2 * kTile * 8 + kD * 8 + kAG * L * F + 8) * sizeof(float) + (size_t)kAG * attc2_lpad(L);
+__host__ __device__ inline size_t attc2_smem(int L, int F, int AG) {
+    return (size_t)(kTile * (attc2_lpad(L) + 4) + 2 * kTile * (kD + 4) + 2 * kTile * 8 + kD * 8 + AG * L * F + 8) * sizeof(float) + (size_t)AG * attc2_lpad(L);
 }
 
 // C[16, 64] += A[16, 32*nchunks] . Bm (row-major [k][ldb]) with the 4-slot operand ring, any nchunks >= 1.
@@ -81,10 +81,12 @@ __device__ __forceinline__ void frag_mma_nn_rt(FragNN<4, 8>& f, const float* As,
     }
 }
 
-template <bool BWD>
+template <bool BWD, int AG>
 __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
+    constexpr int kAG = AG;                   // rows 2*AG .. 15 of the MFMA tile are dead (zero operand rows)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int r = blockIdx.y, n0 = blockIdx.x * kAG, tid = threadIdx.x;
+    // resolutions in reverse launch order: the long-sequence workgroups (last binsize) are dispatched first
+    const int r = gridDim.y - 1 - blockIdx.y, n0 = blockIdx.x * kAG, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int L = a.L[r], Lpad = a.Lpad[r], LT = a.LT[r], F = a.F, LS = Lpad + 4, N = a.N;
     constexpr int LD = kD + 4, NW = kAT / 64;
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {            // the lane's rows 4q..4q+3 = regions 2q, 2q+1 (two heads each)
                 const int s = lq * 2 + sp;
+                if (s >= kAG) continue;
                 float fv[4][8];                           // marks of bins j0..j0+3 of region s: 28 consecutive floats
                 if (j0 + 3 < L && F == 7) {
                     const float4* fp4 = reinterpret_cast<const float4*>(feats_s + (size_t)(s * L + j0) * 7);
@@ -240,41 +243,44 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
     const int cg = w & 1, kh = w >> 1, kper = Lpad / 4;      // pass 5: 2 column groups x 4 quarters of the bin range
     FragNN<4, 8> fp5;
     frag_load_nn_rt(fp5, a.pe[r] + (size_t)(kh * kper) * kD + cg * 64, kD, kper / 32);   // in flight across passes 3, 4
-    const int gm = tid >> 5, sub = tid & 31;      // 32 lanes per row m
+    // LPR lanes per row m: 32 with all 16 rows live, a whole wave per row when at most 8 are
+    constexpr int LPR = AG == 8 ? 32 : 64, LSH = AG == 8 ? 5 : 6;
+    const int gm = tid >> LSH, sub = tid & (LPR - 1);
+    const bool row_live = gm < 2 * kAG;
     auto sum32 = [](float v) {
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         return v;
     };
-    // ---- (3) softmax over the bins (fwd) / its backward (bwd): 32 lanes per row, each lane owns the 16-byte
-    //      strips j = 4*sub + 128*k; everything a lane needs is fetched before the arithmetic starts
+    // ---- (3) softmax over the bins (fwd) / its backward (bwd): LPR lanes per row, each lane owns the 16-byte
+    //      strips j = 4*sub + 4*LPR*k; everything a lane needs is fetched before the arithmetic starts
     auto softmax_pass = [&](auto kmax_c) {
         constexpr int KMAX = decltype(kmax_c)::value;      // strips per lane
         float* row = sc_s + gm * LS;
-        const bool present = (gm >> 1) < nreg;
-        const int nk = (L + 127) / 128;
+        const bool present = row_live && (gm >> 1) < nreg;
+        const int nk = (L + 4 * LPR - 1) / (4 * LPR);
         float4 xv[KMAX];
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k < nk) xv[k] = *reinterpret_cast<const float4*>(row + 4 * sub + 128 * k);      // entries j >= L are 0
+            if (k < nk) xv[k] = *reinterpret_cast<const float4*>(row + 4 * sub + 4 * LPR * k);      // entries j >= L are 0
         if (!BWD) {
             float mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < nk) {
-                    const int j = 4 * sub + 128 * k;
+                    const int j = 4 * sub + 4 * LPR * k;
                     if (j < L) mx = fmaxf(mx, xv[k].x);
                     if (j + 1 < L) mx = fmaxf(mx, xv[k].y);
                     if (j + 2 < L) mx = fmaxf(mx, xv[k].z);
                     if (j + 3 < L) mx = fmaxf(mx, xv[k].w);
                 }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            for (int o = LPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
             float z = 0.f;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < nk) {
-                    const int j = 4 * sub + 128 * k;
+                    const int j = 4 * sub + 4 * LPR * k;
                     xv[k].x = j < L ? expf(xv[k].x - mx) : 0.f;
                     xv[k].y = j + 1 < L ? expf(xv[k].y - mx) : 0.f;
                     xv[k].z = j + 2 < L ? expf(xv[k].z - mx) : 0.f;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < nk) {
-                    const int j = 4 * sub + 128 * k;
+                    const int j = 4 * sub + 4 * LPR * k;
                     const float4 pv = make_float4(xv[k].x * rz, xv[k].y * rz, xv[k].z * rz, xv[k].w * rz);
                     *reinterpret_cast<float4*>(row + j) = pv;
                     if (present) {
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < nk) {
-                    const int j = 4 * sub + 128 * k;
+                    const int j = 4 * sub + 4 * LPR * k;
                     pv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (present) {
                         if (j + 3 < L && (L & 3) == 0) pv[k] = ldg4(pg + j);
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < nk) {
-                    const int j = 4 * sub + 128 * k;
+                    const int j = 4 * sub + 4 * LPR * k;
                     const uint32_t mw = *reinterpret_cast<const uint32_t*>(mk + j);
                     float4 d;
                     d.x = (mw & 0xffu) ? 0.f : pv[k].x * (xv[k].x - dot) * a.rscale;
@@ -338,8 +344,10 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
                 }
         }
     };
-    if (L <= 512) softmax_pass(std::integral_constant<int, 4>{});
-    else softmax_pass(std::integral_constant<int, 8>{});      // L <= 1024 (checked on the host)
+    if (row_live) {
+        if (L <= 4 * LPR * 4) softmax_pass(std::integral_constant<int, 4>{});
+        else softmax_pass(std::integral_constant<int, 8>{});      // L <= 1024 (checked on the host)
+    }
     __syncthreads();
     CF_STAMP2(4);
     // ---- (4) w[m][f] = sum_j sc[m][j] f_j[f]
@@ -347,13 +355,13 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         float acc[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) acc[f] = 0.f;
-        const float* fp = feats_s + (gm >> 1) * L * F;
-        for (int j = sub; j < L; j += 32) {
+        const float* fp = feats_s + (row_live ? gm >> 1 : 0) * L * F;
+        for (int j = sub; j < (row_live ? L : 0); j += LPR) {
             const float pv = sc_s[gm * LS + j];
 #pragma unroll
             for (int f = 0; f < 8; ++f) acc[f] = fmaf(pv, fp[j * F + f], acc[f]);           // entries f >= F are dropped below
         }
-        // 8 sums over 32 lanes in 9 exchanges: each step trades half of the values with the partner lane
+        // 8 sums over LPR lanes in 9 (10) exchanges: each step trades half of the values with the partner lane
         float h4[4], h2[2], h1;
         {
             const bool up = sub & 1;
@@ -378,7 +386,8 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         }
         h1 += __shfl_xor(h1, 8, 64);
         h1 += __shfl_xor(h1, 16, 64);
-        if (sub < 8) {
+        if (LPR == 64) h1 += __shfl_xor(h1, 32, 64);
+        if (sub < 8 && row_live) {
             const int f = (sub & 1) * 4 + (sub & 2) + ((sub >> 2) & 1);
             const float sv = f < F ? h1 : 0.f;
             w_s[gm * 8 + f] = sv;
@@ -418,6 +427,24 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         }
     }
     CF_STAMP2(7);
+}
+
+// Regions per workgroup.  These kernels are latency-bound (a handful of workgroups per CU, dependent phases): the
+// time of a workgroup is ~19 K cycles + 5 K per region, and dead MFMA rows cost nothing that matters.  So take the
+// fewest regions per workgroup that still lets every long-sequence workgroup be resident at once.
+inline int attc2_regions_per_wg(int N) {
+    for (int ag = 1; ag < kAGMax; ag *= 2)
+        if ((N + ag - 1) / ag <= 256) return ag;
+    return kAGMax;
+}
+template <bool BWD>
+inline const void* attc2_kernel(int ag) {
+    switch (ag) {
+        case 1: return (const void*)k_attc2<BWD, 1>;
+        case 2: return (const void*)k_attc2<BWD, 2>;
+        case 4: return (const void*)k_attc2<BWD, 4>;
+        default: return (const void*)k_attc2<BWD, 8>;
+    }
 }
 
 }  // namespace cf
