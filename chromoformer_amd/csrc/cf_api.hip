@@ -207,6 +207,7 @@ struct cf_handle {
     float *pe[kMaxRes], *pet[kMaxRes];
     float *pe2[kMaxRes], *pet2[kMaxRes];      // padded layouts of the gene-batched attention kernel (cf_attc2.h)
     bool attc2 = false;
+    int attc_cap = 64;                        // most workgroups per resolution for which attc2 trades regions per workgroup for parallelism
     int xcd_map = 1;                          // XCD-aware placement of the Regulation workgroups (CF_XCD_MAP=0 turns it off)
     int n_wg_r = 0, n_cs_r = 0;               // leading entries of wg_tiles / cs_tiles that belong to the Regulation + head bucket
     long long bucket_split = 0;               // flat offset of the first Regulation parameter (bucket boundary)
@@ -737,6 +738,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         }
     }
     if (const char* e = getenv("CF_XCD_MAP")) h->xcd_map = atoi(e) != 0;
+    if (const char* e = getenv("CF_ATTC_CAP")) h->attc_cap = atoi(e);
     const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
     h->n_fwd = 2 + 3 + 1 + 3 * c.pair_layers + reg_launches + 1;       // retile, x0 | Embedding | lin_proj_p | Pairwise | Regulation | head
     h->n_bwd = 1 + reg_launches + 3 * c.pair_layers + 2 + 3 + 5;       // head | Regulation | Pairwise | join, dgrad | Embedding | reductions
@@ -965,7 +967,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         hipLaunchKernelGGL(k_qchain_fwd, dim3(tiles_of(N), nres), dim3(256), 0, st, q);
         LAUNCH_CHECK("k_qchain_fwd");
         if (h->attc2) {
-            const int ag = attc2_regions_per_wg(N);
+            const int ag = attc2_regions_per_wg(N, h->attc_cap);
             Attc2Args a2;
             size_t sm2 = 0;
             for (int r = 0; r < nres; ++r) {
@@ -1304,7 +1306,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         launch_post_bwd<true, 128>(dff, dim3(tiles_of(N), nres), st, pb);
         LAUNCH_CHECK("k_post_bwd<centre>");
         if (h->attc2) {
-            const int ag = attc2_regions_per_wg(N);
+            const int ag = attc2_regions_per_wg(N, h->attc_cap);
             Attc2Args a2;
             size_t sm2 = 0;
             for (int r = 0; r < nres; ++r) {

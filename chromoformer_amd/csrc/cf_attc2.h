@@ -432,9 +432,9 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 // Regions per workgroup.  These kernels are latency-bound (a handful of workgroups per CU, dependent phases): the
 // time of a workgroup is ~19 K cycles + 5 K per region, and dead MFMA rows cost nothing that matters.  So take the
 // fewest regions per workgroup that still lets every long-sequence workgroup be resident at once.
-inline int attc2_regions_per_wg(int N) {
+inline int attc2_regions_per_wg(int N, int cap) {
     for (int ag = 1; ag < kAGMax; ag *= 2)
-        if ((N + ag - 1) / ag <= 256) return ag;
+        if ((N + ag - 1) / ag <= cap) return ag;
     return kAGMax;
 }
 template <bool BWD>
