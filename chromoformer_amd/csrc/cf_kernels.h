@@ -1325,63 +1325,79 @@ struct WgTile {
     int ldc, Nn, Kk;
     int n0, k0;
 };
+// four consecutive floats of a row, zero beyond `ncols`; 16-byte load when the address allows it
+__device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col, int ncols, bool vec_ok) {
+    if (vec_ok && col + 3 < ncols) return ldg4(p + col);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < ncols) v.x = ldg(p + col);
+    if (col + 1 < ncols) v.y = ldg(p + col + 1);
+    if (col + 2 < ncols) v.z = ldg(p + col + 2);
+    if (col + 3 < ncols) v.w = ldg(p + col + 3);
+    return v;
+}
+constexpr int kWgM = 32;            // reduction rows per LDS stage
+constexpr int kWgLdA = 64 + 16;     // A stage row stride: a half-wave's scalar reads (two rows x 16 columns) hit 32 distinct banks
+constexpr int kWgLdB = 64 + 4;
 __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) {
-    // 64 x 64 output tile; wave w owns rows n0+16w..+15.  B is read 16 bytes per lane, so
-    // accumulator c holds the strided columns k0 + 4r + c (Kk % 4 == 0).
+    // 64 x 64 output tile; wave w owns rows n0+16w..+15.  Both operands are staged through LDS (every element of dY
+    // is used by one wave but every element of X by all four: reading X straight from L2 in each wave made the
+    // kernel L1-bound at 37 % of the MFMA peak), double-buffered, one barrier per 32 reduction rows; the global loads
+    // of stage i+1 are in flight while stage i is multiplied.  B is read 16 bytes per lane, so accumulator c holds
+    // the strided columns k0 + 4r + c.
+    __shared__ __attribute__((aligned(16))) float As[2][kWgM * kWgLdA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kWgM * kWgLdB];
     const WgTile& t = tiles[blockIdx.x];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int n = t.n0 + w * 16 + lr;
-    const bool nv = n < t.Nn;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int kc = t.k0 + 4 * lr;
     const bool kv = kc < t.Kk;
     f32x4 acc[4];
     zero_acc(acc);
+    const int sm = tid >> 4, sc = (tid & 15) * 4;          // staging: rows sm, sm + 16; columns sc .. sc + 3
     for (int s = 0; s < t.nseg; ++s) {
-        const WgSeg& sg = t.seg[s];
-        const int M = sg.rows_per_gene * batch;
-        const float* Ap = sg.A + (nv ? n : 0) + (size_t)lq * sg.lda;
-        const float* Bp = sg.B + (kv ? kc : 0) + (size_t)lq * sg.ldb;
-        int m0 = 0;
-        float ra[3][4];
-        float4 rb[3][4];
-        auto fetch = [&](int slot, int mm) {
+        const WgSeg sg = t.seg[s];
+        const int M = sg.rows_per_gene * batch, nst = (M + kWgM - 1) / kWgM;
+        const bool va = ((sg.lda | t.n0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.A) & 15) == 0;
+        const bool vb = ((sg.ldb | t.k0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.B) & 15) == 0;
+        float4 ra[2], rb[2];
+        auto fetch = [&](int st) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[slot][i] = Ap[(size_t)(mm + 4 * i) * sg.lda];
-                rb[slot][i] = *reinterpret_cast<const float4*>(Bp + (size_t)(mm + 4 * i) * sg.ldb);
-            }
-        };
-        const int nfull = M / 16;
-        if (nfull > 0) fetch(0, 0);
-        if (nfull > 1) fetch(1, 16);
-        for (int it = 0; it < nfull; it += 3) {      // three iterations per trip: static ring slots
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                if (it + u < nfull) {
-                    if (it + u + 2 < nfull) fetch((u + 2) % 3, (it + u + 2) * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[0] = mfma4(ra[u][i], rb[u][i].x, acc[0]);
-                        acc[1] = mfma4(ra[u][i], rb[u][i].y, acc[1]);
-                        acc[2] = mfma4(ra[u][i], rb[u][i].z, acc[2]);
-                        acc[3] = mfma4(ra[u][i], rb[u][i].w, acc[3]);
-                    }
+            for (int p = 0; p < 2; ++p) {
+                const int m = st * kWgM + sm + 16 * p;
+                if (m < M) {
+                    ra[p] = wg_load4(sg.A + (size_t)m * sg.lda, t.n0 + sc, t.Nn, va);
+                    rb[p] = wg_load4(sg.B + (size_t)m * sg.ldb, t.k0 + sc, t.Kk, vb);
+                } else {
+                    ra[p] = rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
-        }
-        m0 = nfull * 16;
-        if (m0 < M) {
+        };
+        auto put = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool mv = m0 + 4 * i + lq < M;
-                const float av = mv ? Ap[(size_t)(m0 + 4 * i) * sg.lda] : 0.f;
-                const float4 bv = mv ? *reinterpret_cast<const float4*>(Bp + (size_t)(m0 + 4 * i) * sg.ldb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = 0; p < 2; ++p) {
+                *reinterpret_cast<float4*>(&As[buf][(sm + 16 * p) * kWgLdA + sc]) = ra[p];
+                *reinterpret_cast<float4*>(&Bs[buf][(sm + 16 * p) * kWgLdB + sc]) = rb[p];
+            }
+        };
+        __syncthreads();                                       // the previous segment's last stage has been consumed
+        fetch(0);
+        put(0);
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nst) fetch(st + 1);
+            const float* ap = &As[buf][lq * kWgLdA + 16 * w + lr];
+            const float* bp = &Bs[buf][lq * kWgLdB + 4 * lr];
+#pragma unroll
+            for (int i = 0; i < kWgM / 4; ++i) {
+                const float av = ap[4 * i * kWgLdA];
+                const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * i * kWgLdB);
                 acc[0] = mfma4(av, bv.x, acc[0]);
                 acc[1] = mfma4(av, bv.y, acc[1]);
                 acc[2] = mfma4(av, bv.z, acc[2]);
                 acc[3] = mfma4(av, bv.w, acc[3]);
             }
+            if (st + 1 < nst) put(buf ^ 1);
+            __syncthreads();
         }
     }
     if (!kv) return;
