@@ -1358,10 +1358,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
         const int M = sg.rows_per_gene * batch, nst = (M + kWgM - 1) / kWgM;
         const bool va = ((sg.lda | t.n0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.A) & 15) == 0;
         const bool vb = ((sg.ldb | t.k0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.B) & 15) == 0;
-        float4 ra[2], rb[2];
+        float4 ra[kWgM / 16], rb[kWgM / 16];
         auto fetch = [&](int st) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < kWgM / 16; ++p) {
                 const int m = st * kWgM + sm + 16 * p;
                 if (m < M) {
                     ra[p] = wg_load4(sg.A + (size_t)m * sg.lda, t.n0 + sc, t.Nn, va);
@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
         };
         auto put = [&](int buf) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < kWgM / 16; ++p) {
                 *reinterpret_cast<float4*>(&As[buf][(sm + 16 * p) * kWgLdA + sc]) = ra[p];
                 *reinterpret_cast<float4*>(&Bs[buf][(sm + 16 * p) * kWgLdB + sc]) = rb[p];
             }
