@@ -87,12 +87,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    # test hooks (tests/test_dp_gpu.py drives the multi-process path on a one-GPU box): every rank on device 0, gloo
+    # instead of RCCL (RCCL refuses two ranks on one device)
+    if os.environ.get("CF_SHARE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("CF_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
     from chromoformer_amd import ChromoformerClassifier
