@@ -990,7 +990,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             a2.F = F;
             a2.scale = scale_c;
             a2.rscale = 1.0f / a2.scale;
-            a2.tdbg = getenv("CF_STAMP_ATTC") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
+            a2.tdbg = (getenv("CF_STAMP_ATTC") && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
+                          ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
             void* kargs2[] = {&a2};
             HIP_TRY(hipLaunchKernel(attc2_kernel<false>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
         } else {
@@ -1329,7 +1330,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             a2.F = F;
             a2.scale = scale_c;
             a2.rscale = 1.0f / a2.scale;
-            a2.tdbg = getenv("CF_STAMP_ATTC") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
+            a2.tdbg = (getenv("CF_STAMP_ATTC") && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
+                          ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
             void* kargs2[] = {&a2};
             HIP_TRY(hipLaunchKernel(attc2_kernel<true>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
         } else {

@@ -116,7 +116,6 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
                     const int i = tid + u * kAT;
                     v[u] = i < nf4 ? ldg4(fg + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                frag_load_nn(ft0, a.pet[r] + min(w, nblk - 1) * 64, LT);      // rides behind the HBM stream
 #pragma unroll
                 for (int u = 0; u < 12; ++u) {
                     const int i = tid + u * kAT;
@@ -127,7 +126,6 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
                 *reinterpret_cast<float4*>(feats_s + (size_t)i * 4) = i < nf4 ? ldg4(fg + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (tid < 8) feats_s[kAG * L * F + tid] = 0.f;
         } else {
-            frag_load_nn(ft0, a.pet[r] + min(w, nblk - 1) * 64, LT);
             for (int i = tid; i < kAG * L * F + 8; i += kAT) feats_s[i] = i < nf ? ldg(fg + i) : 0.f;
         }
         for (int i = tid; i < kD * 8; i += kAT) wlp_s[i] = (i & 7) < F ? ldg(a.wlp[r] + (i >> 3) * F + (i & 7)) : 0.f;
@@ -154,6 +152,9 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
             const int m = tid >> 5;                                // zero tail of the score rows (K padding of pass 5)
             for (int j = L + (tid & 31); j < Lpad; j += 32) sc_s[m * LS + j] = 0.f;
         }
+        // PE^T operand ring of pass 2: requested last (loads return in order: anything issued before the staging loads
+        // would have to land before their data can be stored), in flight across the barrier and pass 1
+        frag_load_nn(ft0, a.pet[r] + min(w, nblk - 1) * 64, LT);
     }
     __syncthreads();
     CF_STAMP2(1);
