@@ -107,6 +107,27 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
     {
         const float* fg = a.feats[r] + (size_t)n0 * L * F;
         const int nf = nreg * L * F;
+        const uint8_t* mg = a.mask[r] + (size_t)n0 * a.mstride[r];
+        const bool words = ((L | (int)a.mstride[r] | (int)(reinterpret_cast<uintptr_t>(a.mask[r]))) & 3) == 0;
+        const int LW = Lpad >> 2, lw = L >> 2;
+        constexpr int MW = kAG >= 2 ? kAG / 2 : 1;       // mask words per thread: kAG * (Lpad / 4 <= 256) / 512
+        // every load of the stage is issued before the first LDS store waits for one (loads return in order, so a
+        // load -> store -> load -> store sequence would pay the L2 latency once per array)
+        const float wl0 = (tid & 7) < F ? ldg(a.wlp[r] + (tid >> 3) * F + (tid & 7)) : 0.f;
+        const float wl1 = (tid & 7) < F ? ldg(a.wlp[r] + ((tid + kAT) >> 3) * F + (tid & 7)) : 0.f;      // kD * 8 = 2 * kAT entries
+        float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            const int m = tid >> 5, c4 = tid & 31;               // 16 rows x 32 float4
+            if ((m >> 1) < nreg) vv = ldg4(a.vin[r] + (size_t)n0 * 256 + m * kD + c4 * 4);
+        }
+        uint32_t mwv[MW];
+        if (words) {
+#pragma unroll
+            for (int k = 0; k < MW; ++k) {
+                const int idx = tid + k * kAT, sreg = idx / LW, jw = idx - sreg * LW;
+                mwv[k] = (idx < kAG * LW && sreg < nreg && jw < lw) ? *(const CF_GLOBAL uint32_t*)(mg + (size_t)sreg * a.mstride[r] + 4 * jw) : 0x01010101u;
+            }
+        }
         if (((L * F) & 3) == 0) {                      // 16-byte copies, 12 in flight per thread
             const int n4 = (kAG * L * F) >> 2, nf4 = nf >> 2;
             {                                          // first round: covers L*F <= 3072 (L = 400: 2800)
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 #pragma unroll
                 for (int u = 0; u < 12; ++u) {
                     const int i = tid + u * kAT;
-                    v[u] = i < nf4 ? ldg4(fg + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[u] = (u * kAT < n4 && i < nf4) ? ldg4(fg + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 12; ++u) {
@@ -128,21 +149,15 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         } else {
             for (int i = tid; i < kAG * L * F + 8; i += kAT) feats_s[i] = i < nf ? ldg(fg + i) : 0.f;
         }
-        for (int i = tid; i < kD * 8; i += kAT) wlp_s[i] = (i & 7) < F ? ldg(a.wlp[r] + (i >> 3) * F + (i & 7)) : 0.f;
-        {
-            const float* vg = a.vin[r] + (size_t)n0 * 256;
-            const int m = tid >> 5, c4 = tid & 31;               // 16 rows x 32 float4
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((m >> 1) < nreg) v = ldg4(vg + m * kD + c4 * 4);
-            *reinterpret_cast<float4*>(vin_s + m * LD + c4 * 4) = v;
-        }
-        const uint8_t* mg = a.mask[r] + (size_t)n0 * a.mstride[r];
-        if (((L | (int)a.mstride[r] | (int)(reinterpret_cast<uintptr_t>(a.mask[r]))) & 3) == 0) {   // whole words
-            const int LW = Lpad >> 2, lw = L >> 2;
+        static_assert(kD * 8 == 2 * kAT, "wlp staging assumes two entries per thread");
+        wlp_s[tid] = wl0;
+        wlp_s[tid + kAT] = wl1;
+        *reinterpret_cast<float4*>(vin_s + (tid >> 5) * LD + (tid & 31) * 4) = vv;
+        if (words) {
             uint32_t* mk_w = reinterpret_cast<uint32_t*>(mk_s);
-            for (int s = 0; s < kAG; ++s)
-                for (int jw = tid; jw < LW; jw += kAT)
-                    mk_w[s * LW + jw] = (s < nreg && jw < lw) ? *(const CF_GLOBAL uint32_t*)(mg + (size_t)s * a.mstride[r] + 4 * jw) : 0x01010101u;
+#pragma unroll
+            for (int k = 0; k < MW; ++k)
+                if (tid + k * kAT < kAG * LW) mk_w[tid + k * kAT] = mwv[k];
         } else {
             for (int s = 0; s < kAG; ++s)
                 for (int j = tid; j < Lpad; j += kAT)
