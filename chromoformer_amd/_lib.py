@@ -66,6 +66,9 @@ SYMBOLS = {
     "cf_grad_bucket": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "cf_backward_reduce_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cf_adamw_step_part": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_int, C.c_void_p]),
+    "cf_adamw_set": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p]),
+    "cf_adamw_step_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_backward_part": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "cf_kernel_flops": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int]),
     "cf_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),

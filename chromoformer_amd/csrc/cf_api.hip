@@ -207,6 +207,9 @@ struct cf_handle {
     float *pe[kMaxRes], *pet[kMaxRes];
     float *pe2[kMaxRes], *pet2[kMaxRes];      // padded layouts of the gene-batched attention kernel (cf_attc2.h)
     bool attc2 = false;
+    AdamHyper* hyper = nullptr;               // step-dependent AdamW scalars for the graph-replayed optimiser launch
+    std::vector<hipEvent_t> sync_ev;          // cf_stream_wait
+    size_t sync_ev_used = 0;
     int attc_cap = 64;                        // most workgroups per resolution for which attc2 trades regions per workgroup for parallelism
     int xcd_map = 1;                          // XCD-aware placement of the Regulation workgroups (CF_XCD_MAP=0 turns it off)
     int n_wg_r = 0, n_cs_r = 0;               // leading entries of wg_tiles / cs_tiles that belong to the Regulation + head bucket
@@ -675,7 +678,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             if (p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable)
                 for (int n0 = 0; n0 < p.shape[0]; n0 += 16) units.push_back(RetileUnit{p.offset + (long long)n0 * p.shape[1], p.shape[1]});
         h->n_retile = (int)units.size();
-        if (hipMalloc(&h->tiled, h->lay.n_total * sizeof(float)) != hipSuccess ||
+        if (hipMalloc(&h->hyper, sizeof(AdamHyper)) != hipSuccess || hipMalloc(&h->tiled, h->lay.n_total * sizeof(float)) != hipSuccess ||
             hipMalloc(&h->retile_units, units.size() * sizeof(RetileUnit)) != hipSuccess ||
             hipMemcpy(h->retile_units, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice) != hipSuccess) {
             delete h;
@@ -761,6 +764,8 @@ extern "C" void cf_destroy(cf_handle* h) {
         if (rp.second) (void)hipGraphExecDestroy(rp.second);
     }
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->sync_ev) (void)hipEventDestroy(e);
+    if (h->hyper) (void)hipFree(h->hyper);
     delete h;
 }
 
@@ -1570,26 +1575,79 @@ extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
 // ------------------------------------------------------------------------------------
 // optimiser
 // ------------------------------------------------------------------------------------
-extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
-                                  int buckets, void* stream) {
+static int adam_hyper(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, AdamHyper& hy) {
     if (!h || !h->params || !h->grads || !h->m || !h->v) return fail("cf_adamw_step: params / grads / moments not bound");
     if (step < 1) return fail("cf_adamw_step: step is 1-based");
-    if (!buckets || (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE))) return fail("cf_adamw_step_part: bad bucket mask %d", buckets);
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)std::sqrt(bc2);
-    const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
-    // the buckets are adjacent ranges of the flat buffers: [0, split) = Embedding + Pairwise, [split, n_active) = Regulation + head
-    const long long lo = (buckets & CF_BUCKET_PE) ? 0 : h->bucket_split;
+    hy.decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    hy.one_m_b1 = (float)(1.0 - (double)beta1);
+    hy.b2 = beta2;
+    hy.one_m_b2 = (float)(1.0 - (double)beta2);
+    hy.step_size = (float)((double)lr / bc1);
+    hy.bc2_sqrt = (float)std::sqrt(bc2);
+    hy.eps = eps;
+    hy.pad = 0.f;
+    return 0;
+}
+// the buckets are adjacent ranges of the flat buffers: [0, split) = Embedding + Pairwise, [split, n_active) = Regulation + head;
+// every tensor starts 16-byte aligned, so both bounds are multiples of 4
+static int adam_range(cf_handle* h, int buckets, long long& lo, long long& n4, int& grid) {
+    if (!buckets || (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE))) return fail("cf_adamw_step_part: bad bucket mask %d", buckets);
+    lo = (buckets & CF_BUCKET_PE) ? 0 : h->bucket_split;
     const long long hi = (buckets & CF_BUCKET_REG) ? h->lay.n_active : h->bucket_split;
-    const long long n4 = (hi - lo) / 4;      // every tensor starts 16-byte aligned, so both bounds are multiples of 4
-    const int grid = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
+    n4 = (hi - lo) / 4;
+    grid = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
+    return 0;
+}
+extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
+                                  int buckets, void* stream) {
+    AdamHyper hy;
+    long long lo, n4;
+    int grid;
+    if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy) || adam_range(h, buckets, lo, n4, grid)) return -1;
     h->time_mark("k_adamw", (hipStream_t)stream);
     hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
-                       h->v + lo, n4, decay, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps);
+                       h->v + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps);
     h->time_mark("k_adamw", (hipStream_t)stream);
     LAUNCH_CHECK("k_adamw");
+    return 0;
+}
+// Split form for callers that replay the optimiser launch from a hipGraph: cf_adamw_set (eager, once per step, before the
+// replay) writes the step's scalars to device memory, cf_adamw_step_dev (capturable) reads them.
+extern "C" int cf_adamw_set(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void* stream) {
+    AdamHyper hy;
+    if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy)) return -1;
+    if (h->capturing) return fail("cf_adamw_set must not be captured: its arguments change every step");
+    hipLaunchKernelGGL(k_adamw_set, dim3(1), dim3(1), 0, (hipStream_t)stream, h->hyper, hy);
+    LAUNCH_CHECK("k_adamw_set");
+    return 0;
+}
+extern "C" int cf_adamw_step_dev(cf_handle* h, int buckets, void* stream) {
+    if (!h || !h->params || !h->grads || !h->m || !h->v) return fail("cf_adamw_step: params / grads / moments not bound");
+    long long lo, n4;
+    int grid;
+    if (adam_range(h, buckets, lo, n4, grid)) return -1;
+    h->time_mark("k_adamw", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_adamw_dev, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
+                       h->v + lo, n4, (const AdamHyper*)h->hyper);
+    h->time_mark("k_adamw", (hipStream_t)stream);
+    LAUNCH_CHECK("k_adamw_dev");
+    return 0;
+}
+// `waiter` waits for everything enqueued on `signaller` so far (fork / join of a side stream; under capture this pulls
+// the other stream into the graph as a parallel branch).
+extern "C" int cf_stream_wait(cf_handle* h, void* waiter, void* signaller) {
+    if (!h) return fail("null handle");
+    const size_t slot = h->sync_ev_used++ % 64;           // a small ring: an event is re-recorded long after its waiters passed
+    if (slot >= h->sync_ev.size()) {
+        hipEvent_t ne;
+        HIP_TRY(hipEventCreateWithFlags(&ne, hipEventDisableTiming));
+        h->sync_ev.push_back(ne);
+    }
+    hipEvent_t e = h->sync_ev[slot];
+    HIP_TRY(hipEventRecord(e, (hipStream_t)signaller));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, e, 0));
     return 0;
 }
 extern "C" int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,

@@ -1493,7 +1493,40 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
         reinterpret_cast<float4*>(v)[i] = vv;
     }
 }
-
+// The same update with the step-dependent scalars read from device memory, so that the launch can sit inside a
+// replayed hipGraph (kernel arguments are frozen at capture): k_adamw_set writes them each step, outside the graph.
+struct AdamHyper {
+    float decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps, pad;
+};
+__global__ void k_adamw_set(AdamHyper* dst, AdamHyper v) { *dst = v; }
+__global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n4, const AdamHyper* __restrict__ hp) {
+    const AdamHyper h = *hp;
+    const float decay = h.decay, one_m_b1 = h.one_m_b1, b2 = h.b2, one_m_b2 = h.one_m_b2, step_size = h.step_size, bc2_sqrt = h.bc2_sqrt,
+                eps = h.eps;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pa = reinterpret_cast<float*>(&pp);
+        const float* ga = reinterpret_cast<const float*>(&gg);
+        float* ma = reinterpret_cast<float*>(&mm);
+        float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pa[k] = pa[k] * decay;
+            ma[k] = ma[k] + one_m_b1 * (ga[k] - ma[k]);
+            va[k] = va[k] * b2 + one_m_b2 * ga[k] * ga[k];
+            const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
+            pa[k] = pa[k] - step_size * (ma[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
 
 // =======================================================================================
 // Tiled copy of the Linear weights for the forward ("NT") products -- see FragNT.

@@ -75,7 +75,8 @@ class Trainer:
     """One optimisation step = forward, loss, backward, gradient reductions, [all-reduce], AdamW.
 
     Single GPU: everything up to the optimiser is one captured hipGraph (the launch sequence is static); AdamW is
-    launched eagerly behind it because its bias corrections change every step.
+    launched eagerly behind it because its bias corrections change every step (`opt_in_graph=True` moves it inside,
+    reading the scalars from device memory -- measured slower, see __init__).
     Data parallel: two graphs.  The first ends with the Regulation + head gradient bucket (78 % of the bytes), whose
     RCCL all-reduce then runs on a side stream while the second graph (Pairwise + Embedding backward and their
     bucket) runs on the main one.
@@ -84,7 +85,7 @@ class Trainer:
     inside a graph cost ~60 us per replay with this runtime; an eager launch between two graphs costs nothing)."""
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
-                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None):
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -101,8 +102,14 @@ class Trainer:
             _lib.check(self._L.cf_grad_bucket(model._handle, b, C.byref(off), C.byref(n)), "cf_grad_bucket")
             self._buckets[b] = model._gflat[off.value: off.value + n.value]
         self.timed_kernel = timed_kernel
-        if timed_kernel in ("k_wgrad", "k_colsum"):
+        if timed_kernel in ("k_wgrad", "k_colsum", "k_adamw"):
             self.use_graph = False        # launched once per bucket: timed on the eager path, where every launch gets its events
+        # Measured and left off by default: AdamW inside the graph (scalars from device memory) costs +5 us per step (one
+        # more launch per bucket plus cf_adamw_set), and running the early bucket's update as a parallel branch under the
+        # Pairwise + Embedding backward costs +36 us -- its 116 MB stream evicts the L2-resident tables those
+        # latency-bound kernels live on.  The default is one eager launch over the whole range behind the graph.
+        self.opt_in_graph = opt_in_graph and timed_kernel != "k_adamw"
+        self.overlap_opt = overlap_opt and self.opt_in_graph
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -133,9 +140,28 @@ class Trainer:
         self._part(slot, st, 4)
         self._reduce(slot, st, _lib.BUCKET_PE)
 
-    def _seq_all(self, slot, st):
+    def _opt(self, bucket, st):
+        _lib.check(self._L.cf_adamw_step_dev(self.model._handle, bucket, st), "cf_adamw_step_dev")
+
+    def _wait(self, waiter, signaller):
+        _lib.check(self._L.cf_stream_wait(self.model._handle, waiter, signaller), "cf_stream_wait")
+
+    def _seq_all(self, slot, st, opt=True):
+        """The whole single-GPU step.  With `opt`, AdamW of the early bucket (78 % of the 150 MB of optimiser traffic) runs
+        on the side stream under the Pairwise + Embedding backward -- an HBM stream next to latency-bound kernels."""
+        side = self.side.cuda_stream
         self._seq_early(slot, st)
+        if opt:
+            if self.overlap_opt:
+                self._wait(side, st)
+                self._opt(_lib.BUCKET_REG, side)
+            else:
+                self._opt(_lib.BUCKET_REG, st)
         self._seq_late(slot, st)
+        if opt:
+            self._opt(_lib.BUCKET_PE, st)
+            if self.overlap_opt:
+                self._wait(st, side)
 
     def _capture(self, fn, slot, st):
         m, L = self.model, self._L
@@ -159,30 +185,44 @@ class Trainer:
         m, L = self.model, self._L
         st = self._stream()
         if self.use_graph and slot.graph is None:
-            self._seq_all(slot, st)                    # eager once (validates the arguments before anything is captured)
+            self._seq_all(slot, st, opt=False)         # eager once (validates the arguments before anything is captured)
             torch.cuda.synchronize()
-            first = self._seq_early if self.dp else self._seq_all
+            first = self._seq_early if self.dp else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph))
             slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
-        if self.use_graph:
-            self._launch(slot.graph["first"], st)
-        elif self.dp:
-            self._seq_early(slot, st)
+        oig = self.opt_in_graph
+        if oig:      # this step's AdamW scalars go to device memory before anything is replayed
+            m._step += 1
+            _lib.check(L.cf_adamw_set(m._handle, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step, st), "cf_adamw_set")
+        if not self.dp:
+            if self.use_graph:
+                self._launch(slot.graph["first"], st)
+            else:
+                self._seq_all(slot, st, opt=oig)
         else:
-            self._seq_all(slot, st)
-        if self.dp:
+            if self.use_graph:
+                self._launch(slot.graph["first"], st)
+            else:
+                self._seq_early(slot, st)
             # the early bucket is complete: all-reduce it on the side stream, under the rest of the backward pass
             self._ev_fork.record(self.stream)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self._ev_fork)
                 torch.distributed.all_reduce(self._buckets[_lib.BUCKET_REG], group=self.pg)     # SUM; dloss carries 1/world
+                if self.overlap_opt:
+                    self._opt(_lib.BUCKET_REG, self.side.cuda_stream)
                 self._ev_join.record(self.side)
             if self.use_graph:
                 self._launch(slot.graph["late"], st)
             else:
                 self._seq_late(slot, st)
             torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
+            if oig:
+                self._opt(_lib.BUCKET_PE, st)
             self.stream.wait_event(self._ev_join)
-        m.adamw_step(self.lr, self.betas, self.eps, self.wd)
+            if oig and not self.overlap_opt:
+                self._opt(_lib.BUCKET_REG, st)
+        if not oig:
+            m.adamw_step(self.lr, self.betas, self.eps, self.wd)
         self._last = slot
         return slot.logits, slot.loss
 

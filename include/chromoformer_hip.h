@@ -155,6 +155,16 @@ int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, f
  * `step` equal one cf_adamw_step). */
 int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
                        long long step, int buckets, void* stream);
+/* The optimiser inside a replayed graph.  Kernel arguments are frozen at capture, so the step-dependent scalars
+ * live in device memory: cf_adamw_set (never captured; once per step, before the replay, on the stream the replay
+ * is launched on) writes them, cf_adamw_step_dev (capturable) applies the update to a bucket mask.  Same
+ * arithmetic, same bits as cf_adamw_step_part. */
+int cf_adamw_set(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 long long step, void* stream);
+int cf_adamw_step_dev(cf_handle* h, int buckets, void* stream);
+/* Fork / join of a side stream: `waiter` waits for everything enqueued on `signaller` so far.  Under capture the
+ * other stream becomes a parallel branch of the graph (it has to be joined back before cf_capture_end). */
+int cf_stream_wait(cf_handle* h, void* waiter, void* signaller);
 
 /* ---- hipGraph capture ---------------------------------------------------------------- */
 /* The launch sequence of a step is static, so it can be captured once and replayed: every

@@ -30,7 +30,9 @@ def _run(steps=3, **kw):
 
 def test_graph_replay_and_event_timing_are_bit_identical_to_the_eager_step():
     ref, ref_loss = _run(use_graph=False)
-    for kw in (dict(use_graph=True), dict(use_graph=True, timed_kernel="k_reg_bwd"), dict(use_graph=False, timed_kernel="k_wgrad")):
+    for kw in (dict(use_graph=True), dict(use_graph=True, timed_kernel="k_reg_bwd"), dict(use_graph=False, timed_kernel="k_wgrad"),
+               dict(use_graph=True, opt_in_graph=True), dict(use_graph=True, opt_in_graph=True, overlap_opt=True),
+               dict(use_graph=False, opt_in_graph=True, overlap_opt=True)):
         got, loss = _run(**kw)
         assert loss == ref_loss, kw
         for k in ref:
@@ -78,8 +80,9 @@ def test_one_rank_rccl_all_reduce_in_the_step():
     try:
         got, loss = _run(use_graph=True, world_size=1, process_group=dist.group.WORLD)
         got2, loss2 = _run(use_graph=False, world_size=1, process_group=dist.group.WORLD, timed_kernel="k_reg_bwd")
+        got3, loss3 = _run(use_graph=True, world_size=1, process_group=dist.group.WORLD, opt_in_graph=True, overlap_opt=True)
     finally:
         dist.destroy_process_group()
-    assert loss == ref_loss and loss2 == ref_loss
+    assert loss == ref_loss and loss2 == ref_loss and loss3 == ref_loss
     for k in ref:
-        assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], got2[k]), k
+        assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], got2[k]) and torch.equal(ref[k], got3[k]), k
