@@ -170,8 +170,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx[g] = fmaxf(mx[g], __shfl_xor(mx[g], off, 64));
+            mx[g] = group16_max(mx[g]);
             const float mn = fmaxf(m[g], mx[g]);
             const float alpha = mn == -INFINITY ? 1.f : __expf(m[g] - mn);
             float ps = 0.f;
@@ -181,8 +180,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
                 s[t][g] = p;
                 ps += p;
             }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+            ps = group16_sum(ps);
             l[g] = l[g] * alpha + ps;
             m[g] = mn;
 #pragma unroll

@@ -73,19 +73,36 @@ struct LdgN<4> {
     static __device__ __forceinline__ void st(float* p, float4 v) { stg4(p, v); }
 };
 
+// Reductions inside a row of 16 lanes run on DPP row rotations (one VALU op per step) instead of ds_bpermute.  Every
+// lane ends with the same bits: at each step the two lanes of a pair add the same two values, only commuted.
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group16_sum(float v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    v = fmaxf(v, row_ror<1>(v));
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = group16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = group16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 

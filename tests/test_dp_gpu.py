@@ -28,9 +28,13 @@ def _port():
 
 def _launch(args, env_extra, timeout=600):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port())] + args
-    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    for attempt in range(2):          # a second try on a fresh port if the rendezvous itself failed (not a test outcome)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_port())] + args
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 0 or not any(k in r.stderr for k in ("EADDRINUSE", "address already in use", "RendezvousConnectionError", "Connection refused")):
+            return r
+    return r
 
 
 @pytest.mark.parametrize("graph", ["1", "0"])
