@@ -264,8 +264,9 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
     const int gm = tid >> LSH, sub = tid & (LPR - 1);
     const bool row_live = gm < 2 * kAG;
     auto sum32 = [](float v) {
-#pragma unroll
-        for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        v = group16_sum(v);
+        v += __shfl_xor(v, 16, 64);
+        if (LPR == 64) v += __shfl_xor(v, 32, 64);
         return v;
     };
     // ---- (3) softmax over the bins (fwd) / its backward (bwd): LPR lanes per row, each lane owns the 16-byte
@@ -290,8 +291,9 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
                     if (j + 2 < L) mx = fmaxf(mx, xv[k].z);
                     if (j + 3 < L) mx = fmaxf(mx, xv[k].w);
                 }
-#pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mx = group16_max(mx);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            if (LPR == 64) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float z = 0.f;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
