@@ -106,7 +106,7 @@ __device__ __forceinline__ void attn_store_d(float* Ps, const f32x4 (&acc)[4]) {
         for (int g = 0; g < 4; ++g) Ps[(4 * q + g) * kALd + 16 * t + r] = acc[t][g];
 }
 
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Ps[4][16 * kALd];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_attn_delta(AttnArgs a) {
 //   ds = p * (dp - delta) / sqrt(dh), and 0 where the score was replaced by the mask fill
 __device__ __forceinline__ void attn_p_ds(const AttnArgs& a, int n, int k0, const int (&rowi)[4], const bool (&qv)[4],
                                           const float (&mrow)[4], const float (&linv)[4], const float (&dl)[4], f32x4 (&s)[4],
-                                          const f32x4 (&dp)[4], f32x4 (&ds)[4]) {
+                                          f32x4 (&dp)[4]) {
     const int r = threadIdx.x & 15;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -237,14 +237,14 @@ __device__ __forceinline__ void attn_p_ds(const AttnArgs& a, int n, int k0, cons
                 d = mk ? 0.f : p * (dp[t][g] - dl[g]) * a.rscale;
             }
             s[t][g] = p;
-            ds[t][g] = d;
+            dp[t][g] = d;                 // dS overwrites dP
         }
     }
 }
 
 // dK, dV of one key tile: loop over the query tiles.  Wave w owns keys 16w .. 16w+15 of the tile.
 //   dV[j] += sum_i p[i][j] dO[i]        dK[j] += sum_i ds[i][j] Q[i]
-__global__ __launch_bounds__(256) void k_attn_bwd_kv(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void k_attn_bwd_kv(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
     __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
     __shared__ __attribute__((aligned(16))) float Pt[4][16 * kALd];     // per-wave patches: p^T / ds^T [16 keys][64 rows]
@@ -276,24 +276,22 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv(AttnArgs a) {
     const float* gbase = a.d_o + (size_t)n * a.Lq * a.ldo + h * kADh;
     const float* stp = a.stats + ((size_t)n * a.H + h) * a.Lq * 2;
     const float* dlp = a.delta + ((size_t)n * a.H + h) * a.Lq;
-    AttnTileRegs qr, gr;
-    attn_fetch(qr, qbase, a.ldq, 0, a.Lq);
-    attn_fetch(gr, gbase, a.ldo, 0, a.Lq);
     for (int q0 = 0; q0 < a.Lq; q0 += kABq) {
         __syncthreads();
-        attn_put(Qs, qr);
-        attn_put(Gs, gr);
-        __syncthreads();
-        if (q0 + kABq < a.Lq) {
-            attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
-            attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
+        {   // three workgroups per CU hide this latency; a register prefetch of the next tile would cost the third one
+            AttnTileRegs qr, gr;
+            attn_fetch(qr, qbase, a.ldq, q0, a.Lq);
+            attn_fetch(gr, gbase, a.ldo, q0, a.Lq);
+            attn_put(Qs, qr);
+            attn_put(Gs, gr);
         }
+        __syncthreads();
         f32x4 st[4], dpt[4];                               // S^T, dP^T: rows = keys 4qd+g, columns = query 16t + r
         zero_acc(st);
         zero_acc(dpt);
         attn_mma_nt(kf, Qs, st);
         attn_mma_nt(vf, Gs, dpt);
-        f32x4 pt[4], dst[4];
+        // p^T overwrites S^T and dS^T overwrites dP^T (each element is read once, by the lane that rewrites it)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int i = q0 + 16 * t + r;
@@ -309,15 +307,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv(AttnArgs a) {
                     p = __expf(x - mrow) * linv;
                     d = mk ? 0.f : p * (dpt[t][g] - dl) * a.rscale;
                 }
-                pt[t][g] = p;
-                dst[t][g] = d;
+                st[t][g] = p;
+                dpt[t][g] = d;
             }
         }
-        attn_store_d(&Pt[w][0], pt);
+        attn_store_d(&Pt[w][0], st);
         __builtin_amdgcn_wave_barrier();
         attn_mma_nn(&Pt[w][0], Gs, dv);                   // dV[16 keys x 64] += P^T[16 x 64 rows] . dO[64 rows x 64]
         __builtin_amdgcn_wave_barrier();
-        attn_store_d(&Pt[w][0], dst);
+        attn_store_d(&Pt[w][0], dpt);
         __builtin_amdgcn_wave_barrier();
         attn_mma_nn(&Pt[w][0], Qs, dk);                   // dK += dS^T . Q
         __builtin_amdgcn_wave_barrier();
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_kv(AttnArgs a) {
 }
 
 // dQ of one query tile: loop over the key tiles.   dQ[i] += sum_j ds[i][j] K[j]
-__global__ __launch_bounds__(256) void k_attn_bwd_q(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void k_attn_bwd_q(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Ds[4][16 * kALd];
@@ -371,25 +369,23 @@ __global__ __launch_bounds__(256) void k_attn_bwd_q(AttnArgs a) {
     zero_acc(dq);
     const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
     const float* vbase = a.v + (size_t)n * a.Lk * a.ldv + h * kADh;
-    AttnTileRegs kr, vr;
-    attn_fetch(kr, kbase, a.ldk, 0, a.Lk);
-    attn_fetch(vr, vbase, a.ldv, 0, a.Lk);
     for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
         __syncthreads();
-        attn_put(Ks, kr);
-        attn_put(Vs, vr);
-        __syncthreads();
-        if (k0 + kABk < a.Lk) {
-            attn_fetch(kr, kbase, a.ldk, k0 + kABk, a.Lk);
-            attn_fetch(vr, vbase, a.ldv, k0 + kABk, a.Lk);
+        {
+            AttnTileRegs kr, vr;
+            attn_fetch(kr, kbase, a.ldk, k0, a.Lk);
+            attn_fetch(vr, vbase, a.ldv, k0, a.Lk);
+            attn_put(Ks, kr);
+            attn_put(Vs, vr);
         }
-        f32x4 s[4], dp[4], ds[4];
+        __syncthreads();
+        f32x4 s[4], dp[4];
         zero_acc(s);
         zero_acc(dp);
         attn_mma_nt(qf, Ks, s);
         attn_mma_nt(gf, Vs, dp);                          // dP = dO V^T
-        attn_p_ds(a, n, k0, rowi, qv, mrow, linv, dl, s, dp, ds);
-        attn_store_d(&Ds[w][0], ds);
+        attn_p_ds(a, n, k0, rowi, qv, mrow, linv, dl, s, dp);
+        attn_store_d(&Ds[w][0], dp);
         __builtin_amdgcn_wave_barrier();
         attn_mma_nn(&Ds[w][0], Ks, dq);                   // dQ += dS . K
         __builtin_amdgcn_wave_barrier();
