@@ -6,8 +6,7 @@
 //     (ceil left / floor right) -> mirrored for a '-' strand promoter (which swaps the pads)
 // written straight into the batch layout the kernels consume: features [L, n_feats] fp32 and the pad mask of
 // the region as bytes [L] (1 = padding).  A pure HBM scan: 2 bytes in per sample, 4 * n_feats bytes out per bin.
-// One workgroup per region; a wave owns an output bin at a time, lanes stride over its samples (coalesced
-// 128-byte reads), sums are reduced in a fixed order (deterministic).
+// One workgroup per region; every sum is reduced in a fixed order (deterministic).
 #pragma once
 
 namespace cf {
@@ -21,8 +20,9 @@ struct BinJob {                 // = cf_bin_job of the C ABI
     unsigned char* mask;        // [L] or null
 };
 
-__global__ __launch_bounds__(256) void k_bin_regions(const BinJob* __restrict__ jobs, int F, int b, int L) {
-    const BinJob j = jobs[blockIdx.x];
+// Generic path: a wave per output bin, 2-byte loads.  Used when the fast path's alignment conditions do not hold
+// (pCRE files of odd length, odd bin sizes).
+__device__ __forceinline__ void bin_region_scalar(const BinJob& j, int F, int b, int L) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_full = j.ncols / b, tail = j.ncols - n_full * b;
     const int n_bins = min(n_full + (tail > 0 ? 1 : 0), L);
@@ -51,6 +51,81 @@ __global__ __launch_bounds__(256) void k_bin_regions(const BinJob* __restrict__ 
         }
         if (lane < F) j.out[(size_t)p * F + lane] = val;
         if (lane == 0 && j.mask) j.mask[p] = real ? 0 : 1;
+    }
+}
+
+// Fast path (rows, window start and bin size multiples of 4 samples: every promoter file and the default bin sizes):
+// a feature row is streamed in tiles of 4,096 samples, 8 bytes (4 samples) per lane and load, so a chunk never
+// straddles a bin; chunk sums go through LDS, then a wave per bin of the tile adds the bin's chunks (strided over
+// lanes, fixed-order wave reduction) into the bin's accumulator.  5x fewer load instructions than the generic path;
+// wide bins (> 1,024 samples) stay on the generic path, where a wave already reads long contiguous runs.  (Requesting the
+// next tile before reducing the current one was measured 15 % slower and is not done.)
+constexpr int kBinTile = 1024;          // chunks of 4 samples per tile
+constexpr int kBinMaxBins = 1024;       // n_bins_out limit of the library
+__global__ __launch_bounds__(256) void k_bin_regions(const BinJob* __restrict__ jobs, int F, int b, int L) {
+    __shared__ float part[kBinTile];
+    __shared__ float acc[kBinMaxBins];           // per-bin sums of the feature row being streamed
+    const BinJob j = jobs[blockIdx.x];
+    // measured (tools/bin_bench.py, TB/s, generic / fast): 2000-sample bins 4.28 / 4.05, 500: 3.0 / 3.75, 100: 1.4 / 2.6
+    const bool fast = ((j.ld | j.col0 | b) & 3) == 0 && b <= 1024 && (reinterpret_cast<uintptr_t>(j.raw) & 7) == 0 && L <= kBinMaxBins;
+    if (!fast) {
+        bin_region_scalar(j, F, b, L);
+        return;
+    }
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int n_full = j.ncols / b, tail = j.ncols - n_full * b;
+    const int n_bins = min(n_full + (tail > 0 ? 1 : 0), L);
+    const int left = (L - n_bins + 1) / 2;
+    const int nchunk = (min(j.ncols, n_bins * b) + 3) >> 2, cpb = b >> 2;      // chunks in the window, chunks per bin
+    const _Float16* raw = reinterpret_cast<const _Float16*>(j.raw);
+    for (int f = 0; f < F; ++f) {
+        const _Float16* row = raw + (size_t)f * j.ld + j.col0;
+        for (int i = tid; i < n_bins; i += 256) acc[i] = 0.f;
+        float v[kBinTile / 256];
+        auto fetch = [&](int c0) {
+#pragma unroll
+            for (int k = 0; k < kBinTile / 256; ++k) {
+                const int c = c0 + tid + 256 * k;
+                float s = 0.f;
+                if (c < nchunk) {
+                    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+                    const v2u u = *(const CF_GLOBAL v2u*)(row + 4 * c);
+                    const _Float16* hp = reinterpret_cast<const _Float16*>(&u);
+                    const int rem = j.ncols - 4 * c;          // samples of the window left from this chunk on
+                    s = (float)hp[0];
+                    if (rem > 1) s += (float)hp[1];
+                    if (rem > 2) s += (float)hp[2];
+                    if (rem > 3) s += (float)hp[3];
+                }
+                v[k] = s;
+            }
+        };
+        for (int c0 = 0; c0 < nchunk; c0 += kBinTile) {
+            fetch(c0);
+            __syncthreads();                                   // the previous tile's partials have been consumed
+#pragma unroll
+            for (int k = 0; k < kBinTile / 256; ++k) part[tid + 256 * k] = v[k];
+            __syncthreads();
+            const int c1 = min(c0 + kBinTile, nchunk);        // chunks [c0, c1) are in `part`
+            const int bin0 = c0 / cpb, bin1 = (c1 - 1) / cpb;
+            for (int bin = bin0 + w; bin <= bin1; bin += 4) {
+                const int lo = max(bin * cpb, c0), hi = min((bin + 1) * cpb, c1);
+                float s = 0.f;
+                for (int c = lo + lane; c < hi; c += 64) s += part[c - c0];
+                s = wave_sum(s);
+                if (lane == 0) acc[bin] += s;                  // one writer per (tile, bin); tiles are sequential
+            }
+        }
+        __syncthreads();
+        for (int p = tid; p < L; p += 256) {
+            const int q = j.flip ? L - 1 - p : p, bin = q - left;
+            const bool real = bin >= 0 && bin < n_bins;
+            float val = 0.f;
+            if (real) val = logf(1.0f + acc[bin] / (float)(bin < n_full ? b : tail));
+            j.out[(size_t)p * F + f] = val;
+            if (f == 0 && j.mask) j.mask[p] = real ? 0 : 1;
+        }
+        __syncthreads();
     }
 }
 
