@@ -1820,3 +1820,119 @@ extern "C" int cf_bin_regions(const cf_bin_job* jobs, int n_jobs, int n_feats, i
     LAUNCH_CHECK("k_bin_regions");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------
+// dense (all rows) layer, forward: projections -> attention core -> out-projection / LN / FFN / LN chain
+// ------------------------------------------------------------------------------------
+static long long dense_ws_layout(int N, int Lq, int Lk, int dff, long long off[8]) {
+    const long long rq = (long long)N * Lq, rk = (long long)N * Lk;
+    long long o = 0;
+    auto take = [&](int i, long long n) {
+        off[i] = o;
+        o += (n + 3) / 4 * 4;
+    };
+    take(0, 128 * 128);                 // wq tiled
+    take(1, 256 * 128);                 // wkv tiled
+    take(2, 128 * 128);                 // wo tiled
+    take(3, (long long)dff * 128);      // w1 tiled
+    take(4, (long long)128 * dff);      // w2 tiled
+    take(5, rq * 128);                  // q, then the attention output in place of it? no: separate
+    take(6, rk * 256);                  // k | v
+    take(7, rq * 128);                  // attention output
+    return o + 1024;                    // + retile unit table
+}
+extern "C" long long cf_op_dense_layer_workspace(int N, int Lq, int Lk, int d_ff) {
+    long long off[8];
+    return dense_ws_layout(N, Lq, Lk, d_ff, off);
+}
+extern "C" int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
+                                     const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk, float* y, float* ws,
+                                     void* stream) {
+    if (!w || !x_q || !x_kv || !y || !ws) return fail("cf_op_dense_layer_fwd: null argument");
+    if (w->d_ff != 128 && w->d_ff != 256) return fail("cf_op_dense_layer_fwd: d_ff must be 128 or 256");
+    if (N < 1 || Lq < 1 || Lk < 1 || N > 65535) return fail("cf_op_dense_layer_fwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int dff = w->d_ff;
+    long long off[8];
+    const long long total = dense_ws_layout(N, Lq, Lk, dff, off);
+    float *wq_t = ws + off[0], *wkv_t = ws + off[1], *wo_t = ws + off[2], *w1_t = ws + off[3], *w2_t = ws + off[4];
+    float *q = ws + off[5], *kv = ws + off[6], *o = ws + off[7];
+    RetileUnit* units_d = reinterpret_cast<RetileUnit*>(ws + total - 1024);
+    // tiled copies of the five weights: the sources are separate tensors, so each gets its own launch (src = dst base)
+    struct Job { const float* src; float* dst; int rows, K; } jobs[5] = {{w->wq, wq_t, 128, 128}, {w->wkv, wkv_t, 256, 128}, {w->wo, wo_t, 128, 128},
+                                                                         {w->w1, w1_t, dff, 128}, {w->w2, w2_t, 128, dff}};
+    std::vector<RetileUnit> units;
+    int first[6] = {0};
+    for (int j = 0; j < 5; ++j) {
+        for (int n0 = 0; n0 < jobs[j].rows; n0 += 16) units.push_back(RetileUnit{(long long)n0 * jobs[j].K, jobs[j].K});
+        first[j + 1] = (int)units.size();
+    }
+    if (units.size() * sizeof(RetileUnit) > 1024 * sizeof(float)) return fail("cf_op_dense_layer_fwd: unit table overflow");
+    HIP_TRY(hipMemcpyAsync(units_d, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));      // `units` is a host temporary
+    for (int j = 0; j < 5; ++j) {
+        hipLaunchKernelGGL(k_retile, dim3(first[j + 1] - first[j]), dim3(256), 0, st, jobs[j].src, jobs[j].dst, (const RetileUnit*)(units_d + first[j]));
+        LAUNCH_CHECK("k_retile<dense layer>");
+    }
+    auto linear = [&](const float* x, const float* wt, float* out, long long rows, int nout) {
+        LinArgs a;
+        memset(&a, 0, sizeof a);
+        a.x[0] = x;
+        a.w[0] = wt;
+        a.b[0] = nullptr;
+        a.y[0] = out;
+        a.xmap = identity_map();
+        a.ldx = 128;
+        a.ldy = nout;
+        a.N = (int)rows;
+        a.K = 128;
+        a.Nout = nout;
+        a.relu = 0;
+        hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of((int)rows), (nout + 127) / 128, 1), dim3(256), 0, st, a);
+    };
+    const long long rq = (long long)N * Lq, rk = (long long)N * Lk;
+    if (rq > 0x7fffffffLL / 256 || rk > 0x7fffffffLL / 256) return fail("cf_op_dense_layer_fwd: too many rows");
+    linear(x_q, wq_t, q, rq, 128);
+    LAUNCH_CHECK("k_linear_fwd<q>");
+    linear(x_kv, wkv_t, kv, rk, 256);
+    LAUNCH_CHECK("k_linear_fwd<kv>");
+    {
+        AttnArgs a;
+        cf_attn_shape sh = {N, 2, Lq, Lk, 128, 256, 256, 128};
+        if (attn_args(&sh, a)) return -1;
+        a.q = q;
+        a.k = kv;
+        a.v = kv + 128;
+        a.qvalid = qvalid;
+        a.kvalid = kvalid;
+        a.mask = mask;
+        a.o = o;
+        a.stats = nullptr;
+        hipLaunchKernelGGL(k_attn_fwd, dim3((Lq + kABq - 1) / kABq, 2, N), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_attn_fwd<dense layer>");
+    }
+    {
+        PostArgs p;
+        memset(&p, 0, sizeof p);
+        p.x[0] = x_q;
+        p.xmap = identity_map();
+        p.ain[0] = o;
+        p.wo[0] = wo_t;
+        p.bo[0] = w->bo;
+        p.g1[0] = w->ln1_g;
+        p.be1[0] = w->ln1_b;
+        p.w1[0] = w1_t;
+        p.b1[0] = w->b1;
+        p.w2[0] = w2_t;
+        p.b2[0] = w->b2;
+        p.g2[0] = w->ln2_g;
+        p.be2[0] = w->ln2_b;
+        p.out[0] = y;
+        p.omap = identity_map();
+        p.N = (int)rq;
+        p.save = 0;
+        launch_post_fwd<false, 128>(dff, dim3(tiles_of((int)rq), 1), st, p);
+        LAUNCH_CHECK("k_post_fwd<dense layer>");
+    }
+    return 0;
+}

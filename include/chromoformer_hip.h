@@ -205,6 +205,24 @@ int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, int N, int K,
 /* dX[M,K] = dY[M,N] . W[N,K]                         -- its input gradient            */
 int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream);
 
+/* ---- dense (all rows) transformer layer, forward --------------------------------------- */
+/* One AttentionBlock / PairwiseAttentionBlock over ALL query rows (modules.py:104-112, 198-208), d_emb = d_model =
+ * 128, 2 heads of 64:   a = Attn(x_q Wq^T, x_kv Wk^T, x_kv Wv^T);  y1 = LN(x_q + a Wo^T + bo);
+ * y = LN(y1 + relu(y1 W1^T + b1) W2^T + b2).  Self-attention: x_q = x_kv and (wq, wkv) are the row blocks
+ * [0,128) and [128,384) of `att.weight`; pairwise: wq = p_att.weight, wkv = c_att.weight.  Inference only (the
+ * training path never needs all rows; the backward pass of the core is cf_op_attention_bwd).  `ws` is a device
+ * workspace of cf_op_dense_layer_workspace(...) floats; masks as in cf_op_attention_fwd. */
+typedef struct cf_dense_layer {
+    const float *wq, *wkv;            /* [128,128], [256,128] */
+    const float *wo, *bo, *ln1_g, *ln1_b;
+    const float *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+    int d_ff;                         /* 128 or 256 */
+} cf_dense_layer;
+long long cf_op_dense_layer_workspace(int N, int Lq, int Lk, int d_ff);
+int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
+                          const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk, float* y,
+                          float* ws, void* stream);
+
 /* ---- input pipeline ------------------------------------------------------------------ */
 /* ChromoformerDataset._bin_and_pad + strand flip (data.py:68-113) on the device: per region, the window
  * [col0, col0 + ncols) of the raw fp16 signal [n_feats, ld] is averaged over bins of `bin_size` samples (short last

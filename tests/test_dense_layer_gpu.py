@@ -1,0 +1,79 @@
+"""cf_op_dense_layer_fwd: one AttentionBlock / PairwiseAttentionBlock over ALL rows against the oracle's
+self_attention_block / pairwise_attention_block + feed_forward (modules.py:104-112, 198-208 restated), seeded
+reference-initialised weights, ragged lengths, a dummy (fully masked) pCRE.  Tolerance 2e-5 on O(1) outputs."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import chromoformer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(P, pre, wq, wkv, dev):
+    from chromoformer_amd import _lib
+    keep = {k: P[pre + k].to(dev).contiguous() for k in ("self_att.ff.weight", "self_att.ff.bias", "self_att.ln.weight", "self_att.ln.bias",
+                                                       "ff.l1.weight", "ff.l1.bias", "ff.l2.weight", "ff.l2.bias", "ff.ln.weight", "ff.ln.bias")}
+    keep["wq"], keep["wkv"] = wq.to(dev).contiguous(), wkv.to(dev).contiguous()
+    w = _lib.cf_dense_layer()
+    for f, k in (("wq", "wq"), ("wkv", "wkv"), ("wo", "self_att.ff.weight"), ("bo", "self_att.ff.bias"), ("ln1_g", "self_att.ln.weight"),
+                 ("ln1_b", "self_att.ln.bias"), ("w1", "ff.l1.weight"), ("b1", "ff.l1.bias"), ("w2", "ff.l2.weight"), ("b2", "ff.l2.bias"),
+                 ("ln2_g", "ff.ln.weight"), ("ln2_b", "ff.ln.bias")):
+        setattr(w, f, keep[k].data_ptr())
+    w.d_ff = keep["ff.l1.weight"].shape[0]
+    return w, keep
+
+
+def _run(w, x_q, x_kv, qv, kv, N, Lq, Lk):
+    from chromoformer_amd import _lib
+    L = _lib.lib()
+    ws = torch.empty(L.cf_op_dense_layer_workspace(N, Lq, Lk, w.d_ff), device=x_q.device)
+    y = torch.empty(N, Lq, 128, device=x_q.device)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(L.cf_op_dense_layer_fwd(C.byref(w), p(x_q), p(x_kv), p(qv), p(kv), None, N, Lq, Lk, p(y), p(ws),
+                                       torch.cuda.current_stream().cuda_stream), "cf_op_dense_layer_fwd")
+    return y
+
+
+@pytest.mark.parametrize("res,L", [(2000, 20), (500, 80), (100, 400)])
+def test_embedding_layer_all_rows(res, L):
+    dev = torch.device("cuda", 0)
+    P = orc.init_params(None, 5, False)
+    pre = "embed.%d.transformer.layers.0." % res
+    att = P[pre + "self_att.att.weight"]
+    w, keep = _layer(P, pre, att[:128], att[128:], dev)
+    g = torch.Generator().manual_seed(L)
+    N = 3
+    x = torch.randn(N, L, 128, generator=g)
+    valid = torch.zeros(N, L, dtype=torch.uint8)
+    for n, nv in enumerate((L, max(1, L // 3), L - 1)):
+        lo = (L - nv + 1) // 2
+        valid[n, lo:lo + nv] = 1
+    mask4 = ~(valid.bool()[:, None, :, None] & valid.bool()[:, None, None, :])
+    with torch.no_grad():
+        ref = orc.feed_forward(P, pre + "ff.", orc.self_attention_block(P, pre + "self_att.", x, mask4, None, 2, False))
+    xd, vd = x.to(dev), valid.to(dev)
+    got = _run(w, xd, xd, vd, vd, N, L, L).cpu()
+    assert (got - ref).abs().max() < 2e-5
+
+
+def test_pairwise_layer_all_rows():
+    dev = torch.device("cuda", 0)
+    P = orc.init_params(None, 6, False)
+    pre = "pairwise_interaction.500.transformer.layers.1."
+    w, keep = _layer(P, pre, P[pre + "self_att.p_att.weight"], P[pre + "self_att.c_att.weight"], dev)
+    assert w.d_ff == 256
+    g = torch.Generator().manual_seed(1)
+    N, L = 4, 80
+    x_p, x_c = torch.randn(N, L, 128, generator=g), torch.randn(N, L, 128, generator=g)
+    pv = torch.ones(N, L, dtype=torch.uint8)
+    cv = torch.zeros(N, L, dtype=torch.uint8)
+    cv[0, 30:50] = 1
+    cv[1, :] = 1
+    cv[2, 39:41] = 1                                   # cv[3] stays all zero: a dummy pCRE, uniform attention
+    mask4 = ~(pv.bool()[:, None, :, None] & cv.bool()[:, None, None, :])
+    with torch.no_grad():
+        ref = orc.feed_forward(P, pre + "ff.", orc.pairwise_attention_block(P, pre + "self_att.", x_p, x_c, mask4, 2))
+    got = _run(w, x_p.to(dev), x_c.to(dev), pv.to(dev), cv.to(dev), N, L, L).cpu()
+    assert torch.isfinite(got).all() and (got - ref).abs().max() < 2e-5

@@ -3,7 +3,8 @@ sequences, all L x L rows, forward + backward, timed with HIP (torch) events on 
     python tools/stress_bench.py [--n-seq 2176] [--reps 5]
 i_max = 16, bsz = 128 -> N = 128 * (1 + 16) = 2176 sequences, h = 2, dh = 64, L = 800.
 Algorithmic flops: forward 4 N H L^2 dh (QK^T and PV), backward 10 N H L^2 dh (dV, dP, dS.K, dS^T.Q + the recomputed
-QK^T is NOT counted: it is re-execution, not algorithmic work)."""
+QK^T is NOT counted: it is re-execution, not algorithmic work).  Also timed: whole dense layers, forward
+(cf_op_dense_layer_fwd: projections, attention, out-projection, LN, FFN, LN over all rows)."""
 import argparse, ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -52,10 +53,33 @@ def timed(fn):
     return e0.elapsed_time(e1) / args.reps
 
 
+# whole dense layers, forward: the Embedding layer on 128 promoters, the Pairwise layer on 128 x 16 (promoter, pCRE) pairs
+def layer_bench(n_seq, dff):
+    wts = {k: torch.randn(*shape, device=dev, generator=g) * 0.05 for k, shape in
+           dict(wq=(128, 128), wkv=(256, 128), wo=(128, 128), bo=(128,), g1=(128,), b1n=(128,), w1=(dff, 128), b1=(dff,), w2=(128, dff), b2=(128,),
+                g2=(128,), b2n=(128,)).items()}
+    w = _lib.cf_dense_layer()
+    for f, k in (("wq", "wq"), ("wkv", "wkv"), ("wo", "wo"), ("bo", "bo"), ("ln1_g", "g1"), ("ln1_b", "b1n"), ("w1", "w1"), ("b1", "b1"), ("w2", "w2"),
+                 ("b2", "b2"), ("ln2_g", "g2"), ("ln2_b", "b2n")):
+        setattr(w, f, wts[k].data_ptr())
+    w.d_ff = dff
+    xq = torch.randn(n_seq, L, 128, device=dev, generator=g)
+    xk = torch.randn(n_seq, L, 128, device=dev, generator=g)
+    y = torch.empty_like(xq)
+    ws_l = torch.empty(lib.cf_op_dense_layer_workspace(n_seq, L, L, dff), device=dev)
+    vl = torch.ones(n_seq, L, dtype=torch.uint8, device=dev)
+    run = lambda: _lib.check(lib.cf_op_dense_layer_fwd(C.byref(w), p(xq), p(xk), p(vl), p(vl), None, n_seq, L, L, p(y), p(ws_l), st), "layer")
+    ms = timed(run)
+    flops = n_seq * (2.0 * L * 128 * 384 + 4.0 * L * L * 128 + 2.0 * L * 128 * 128 + 4.0 * L * 128 * dff)
+    return {"ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}
+
+
 tf, tb = timed(fwd), timed(bwd)
 ff, fb = 4.0 * N * H * L * L * 64, 10.0 * N * H * L * L * 64
 print(json.dumps({"workload": "dense attention core, N=%d sequences x %d heads, L=%d, dh=64, f32" % (N, H, L),
                   "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
                   "fwd_tflops": round(ff / tf / 1e9, 2), "bwd_tflops": round(fb / tb / 1e9, 2),
                   "fwd_bwd_tflops": round((ff + fb) / (tf + tb) / 1e9, 2), "peak_tflops_f32_mfma": 157.3,
-                  "frac": round((ff + fb) / (tf + tb) / 1e9 / 157.3, 4)}))
+                  "frac": round((ff + fb) / (tf + tb) / 1e9 / 157.3, 4),
+                  "embedding_layer_fwd (N=%d, d_ff 128)" % max(1, N // 17): layer_bench(max(1, N // 17), 128),
+                  "pairwise_layer_fwd (N=%d, d_ff 256)" % (N - max(1, N // 17)): layer_bench(N - max(1, N // 17), 256)}))
