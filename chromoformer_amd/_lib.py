@@ -45,6 +45,10 @@ class cf_dense_layer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wq", "wkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")] + [("d_ff", C.c_int)]
 
 
+class cf_dense_layer_grads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "wkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")]
+
+
 class cf_batch(C.Structure):
     _fields_ = [
         ("B", C.c_int),
@@ -92,6 +96,10 @@ SYMBOLS = {
     "cf_bin_regions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_dense_layer_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "cf_op_dense_layer_fwd": (C.c_int, [C.POINTER(cf_dense_layer)] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 3),
+    "cf_op_dense_layer_train_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cf_op_dense_layer_fwd_train": (C.c_int, [C.POINTER(cf_dense_layer)] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 3),
+    "cf_op_dense_layer_bwd": (C.c_int, [C.POINTER(cf_dense_layer)] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 3
+                              + [C.POINTER(cf_dense_layer_grads)] + [C.c_void_p] * 3),
     "cf_op_attention_fwd": (C.c_int, [C.POINTER(cf_attn_shape)] + [C.c_void_p] * 9),
     "cf_op_attention_bwd": (C.c_int, [C.POINTER(cf_attn_shape)] + [C.c_void_p] * 14),
 }

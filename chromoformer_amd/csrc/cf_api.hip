@@ -1822,56 +1822,91 @@ extern "C" int cf_bin_regions(const cf_bin_job* jobs, int n_jobs, int n_feats, i
 }
 
 // ------------------------------------------------------------------------------------
-// dense (all rows) layer, forward: projections -> attention core -> out-projection / LN / FFN / LN chain
+// dense (all rows) layer: projections -> attention core -> out-projection / LN / FFN / LN chain, and its backward
 // ------------------------------------------------------------------------------------
-static long long dense_ws_layout(int N, int Lq, int Lk, int dff, long long off[8]) {
+namespace {
+struct DenseWs {       // workspace layout in floats; `train` adds what the backward pass needs
+    long long wq_t, wkv_t, wo_t, w1_t, w2_t, q, kv, o, tab;                                  // forward
+    long long stats, xh1, rs1, y1, hdn, xh2, rs2;                                             // saved
+    long long dt2, dpre1, dt1, da, dq, dkv, delta, partial, wpart;                           // backward
+    long long total;
+    int splits;
+};
+constexpr int kDenseTab = 16384;        // floats reserved for the unit / tile tables
+constexpr int kDenseSplitRows = 4096;   // reduction rows per split-K chunk of the weight gradients
+DenseWs dense_ws(int N, int Lq, int Lk, int dff, bool train) {
     const long long rq = (long long)N * Lq, rk = (long long)N * Lk;
+    DenseWs w;
     long long o = 0;
-    auto take = [&](int i, long long n) {
-        off[i] = o;
+    auto take = [&](long long n) {
+        const long long at = o;
         o += (n + 3) / 4 * 4;
+        return at;
     };
-    take(0, 128 * 128);                 // wq tiled
-    take(1, 256 * 128);                 // wkv tiled
-    take(2, 128 * 128);                 // wo tiled
-    take(3, (long long)dff * 128);      // w1 tiled
-    take(4, (long long)128 * dff);      // w2 tiled
-    take(5, rq * 128);                  // q, then the attention output in place of it? no: separate
-    take(6, rk * 256);                  // k | v
-    take(7, rq * 128);                  // attention output
-    return o + 1024;                    // + retile unit table
+    w.wq_t = take(128 * 128);
+    w.wkv_t = take(256 * 128);
+    w.wo_t = take(128 * 128);
+    w.w1_t = take((long long)dff * 128);
+    w.w2_t = take((long long)128 * dff);
+    w.q = take(rq * 128);
+    w.kv = take(rk * 256);
+    w.o = take(rq * 128);
+    w.tab = take(kDenseTab);
+    w.splits = 0;
+    if (train) {
+        const long long tiles = (rq + kTile - 1) / kTile;
+        w.stats = take((long long)N * 2 * Lq * 2);
+        w.xh1 = take(rq * 128);
+        w.rs1 = take(rq);
+        w.y1 = take(rq * 128);
+        w.hdn = take(rq * dff);
+        w.xh2 = take(rq * 128);
+        w.rs2 = take(rq);
+        w.dt2 = take(rq * 128);
+        w.dpre1 = take(rq * dff);
+        w.dt1 = take(rq * 128);
+        w.da = take(rq * 128);
+        w.dq = take(rq * 128);
+        w.dkv = take(rk * 256);
+        w.delta = take((long long)N * 2 * Lq);
+        w.partial = take(tiles * post_partial_width(dff));
+        w.splits = (int)((std::max(rq, rk) + kDenseSplitRows - 1) / kDenseSplitRows);
+        w.wpart = take((long long)w.splits * 256 * 128);        // the largest weight is 256 x 128 (or 128 x 256)
+    }
+    w.total = o;
+    return w;
 }
-extern "C" long long cf_op_dense_layer_workspace(int N, int Lq, int Lk, int d_ff) {
-    long long off[8];
-    return dense_ws_layout(N, Lq, Lk, d_ff, off);
-}
-extern "C" int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
-                                     const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk, float* y, float* ws,
-                                     void* stream) {
+}  // namespace
+
+extern "C" long long cf_op_dense_layer_workspace(int N, int Lq, int Lk, int d_ff) { return dense_ws(N, Lq, Lk, d_ff, false).total; }
+extern "C" long long cf_op_dense_layer_train_workspace(int N, int Lq, int Lk, int d_ff) { return dense_ws(N, Lq, Lk, d_ff, true).total; }
+
+static int dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid, const unsigned char* kvalid,
+                           const unsigned char* mask, int N, int Lq, int Lk, float* y, float* ws, bool train, hipStream_t st) {
     if (!w || !x_q || !x_kv || !y || !ws) return fail("cf_op_dense_layer_fwd: null argument");
     if (w->d_ff != 128 && w->d_ff != 256) return fail("cf_op_dense_layer_fwd: d_ff must be 128 or 256");
     if (N < 1 || Lq < 1 || Lk < 1 || N > 65535) return fail("cf_op_dense_layer_fwd: bad shape");
-    hipStream_t st = (hipStream_t)stream;
     const int dff = w->d_ff;
-    long long off[8];
-    const long long total = dense_ws_layout(N, Lq, Lk, dff, off);
-    float *wq_t = ws + off[0], *wkv_t = ws + off[1], *wo_t = ws + off[2], *w1_t = ws + off[3], *w2_t = ws + off[4];
-    float *q = ws + off[5], *kv = ws + off[6], *o = ws + off[7];
-    RetileUnit* units_d = reinterpret_cast<RetileUnit*>(ws + total - 1024);
-    // tiled copies of the five weights: the sources are separate tensors, so each gets its own launch (src = dst base)
-    struct Job { const float* src; float* dst; int rows, K; } jobs[5] = {{w->wq, wq_t, 128, 128}, {w->wkv, wkv_t, 256, 128}, {w->wo, wo_t, 128, 128},
-                                                                         {w->w1, w1_t, dff, 128}, {w->w2, w2_t, 128, dff}};
+    const long long rq = (long long)N * Lq, rk = (long long)N * Lk;
+    if (rq > 0x7fffffffLL / 256 || rk > 0x7fffffffLL / 256) return fail("cf_op_dense_layer_fwd: too many rows");
+    const DenseWs L = dense_ws(N, Lq, Lk, dff, train);
+    RetileUnit* units_d = reinterpret_cast<RetileUnit*>(ws + L.tab);
+    // tiled copies of the five weights: the sources are separate tensors, so each gets its own launch
+    struct Job { const float* src; float* dst; int rows, K; } jobs[5] = {{w->wq, ws + L.wq_t, 128, 128}, {w->wkv, ws + L.wkv_t, 256, 128},
+                                                                         {w->wo, ws + L.wo_t, 128, 128}, {w->w1, ws + L.w1_t, dff, 128},
+                                                                         {w->w2, ws + L.w2_t, 128, dff}};
     std::vector<RetileUnit> units;
     int first[6] = {0};
     for (int j = 0; j < 5; ++j) {
         for (int n0 = 0; n0 < jobs[j].rows; n0 += 16) units.push_back(RetileUnit{(long long)n0 * jobs[j].K, jobs[j].K});
         first[j + 1] = (int)units.size();
     }
-    if (units.size() * sizeof(RetileUnit) > 1024 * sizeof(float)) return fail("cf_op_dense_layer_fwd: unit table overflow");
+    if (units.size() * sizeof(RetileUnit) > kDenseTab * sizeof(float)) return fail("cf_op_dense_layer_fwd: unit table overflow");
     HIP_TRY(hipMemcpyAsync(units_d, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));      // `units` is a host temporary
     for (int j = 0; j < 5; ++j) {
-        hipLaunchKernelGGL(k_retile, dim3(first[j + 1] - first[j]), dim3(256), 0, st, jobs[j].src, jobs[j].dst, (const RetileUnit*)(units_d + first[j]));
+        hipLaunchKernelGGL(k_retile, dim3(first[j + 1] - first[j]), dim3(256), 0, st, jobs[j].src, jobs[j].dst,
+                           (const RetileUnit*)(units_d + first[j]));
         LAUNCH_CHECK("k_retile<dense layer>");
     }
     auto linear = [&](const float* x, const float* wt, float* out, long long rows, int nout) {
@@ -1879,7 +1914,6 @@ extern "C" int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, 
         memset(&a, 0, sizeof a);
         a.x[0] = x;
         a.w[0] = wt;
-        a.b[0] = nullptr;
         a.y[0] = out;
         a.xmap = identity_map();
         a.ldx = 128;
@@ -1887,27 +1921,24 @@ extern "C" int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, 
         a.N = (int)rows;
         a.K = 128;
         a.Nout = nout;
-        a.relu = 0;
         hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of((int)rows), (nout + 127) / 128, 1), dim3(256), 0, st, a);
     };
-    const long long rq = (long long)N * Lq, rk = (long long)N * Lk;
-    if (rq > 0x7fffffffLL / 256 || rk > 0x7fffffffLL / 256) return fail("cf_op_dense_layer_fwd: too many rows");
-    linear(x_q, wq_t, q, rq, 128);
+    linear(x_q, ws + L.wq_t, ws + L.q, rq, 128);
     LAUNCH_CHECK("k_linear_fwd<q>");
-    linear(x_kv, wkv_t, kv, rk, 256);
+    linear(x_kv, ws + L.wkv_t, ws + L.kv, rk, 256);
     LAUNCH_CHECK("k_linear_fwd<kv>");
     {
         AttnArgs a;
         cf_attn_shape sh = {N, 2, Lq, Lk, 128, 256, 256, 128};
         if (attn_args(&sh, a)) return -1;
-        a.q = q;
-        a.k = kv;
-        a.v = kv + 128;
+        a.q = ws + L.q;
+        a.k = ws + L.kv;
+        a.v = ws + L.kv + 128;
         a.qvalid = qvalid;
         a.kvalid = kvalid;
         a.mask = mask;
-        a.o = o;
-        a.stats = nullptr;
+        a.o = ws + L.o;
+        a.stats = train ? ws + L.stats : nullptr;
         hipLaunchKernelGGL(k_attn_fwd, dim3((Lq + kABq - 1) / kABq, 2, N), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_attn_fwd<dense layer>");
     }
@@ -1916,23 +1947,183 @@ extern "C" int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, 
         memset(&p, 0, sizeof p);
         p.x[0] = x_q;
         p.xmap = identity_map();
-        p.ain[0] = o;
-        p.wo[0] = wo_t;
+        p.ain[0] = ws + L.o;
+        p.wo[0] = ws + L.wo_t;
         p.bo[0] = w->bo;
         p.g1[0] = w->ln1_g;
         p.be1[0] = w->ln1_b;
-        p.w1[0] = w1_t;
+        p.w1[0] = ws + L.w1_t;
         p.b1[0] = w->b1;
-        p.w2[0] = w2_t;
+        p.w2[0] = ws + L.w2_t;
         p.b2[0] = w->b2;
         p.g2[0] = w->ln2_g;
         p.be2[0] = w->ln2_b;
+        if (train) {
+            p.xh1[0] = ws + L.xh1;
+            p.rs1[0] = ws + L.rs1;
+            p.y1[0] = ws + L.y1;
+            p.hdn[0] = ws + L.hdn;
+            p.xh2[0] = ws + L.xh2;
+            p.rs2[0] = ws + L.rs2;
+        }
         p.out[0] = y;
         p.omap = identity_map();
         p.N = (int)rq;
-        p.save = 0;
+        p.save = train ? 1 : 0;
         launch_post_fwd<false, 128>(dff, dim3(tiles_of((int)rq), 1), st, p);
         LAUNCH_CHECK("k_post_fwd<dense layer>");
+    }
+    return 0;
+}
+extern "C" int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
+                                     const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk, float* y, float* ws,
+                                     void* stream) {
+    return dense_layer_fwd(w, x_q, x_kv, qvalid, kvalid, mask, N, Lq, Lk, y, ws, false, (hipStream_t)stream);
+}
+extern "C" int cf_op_dense_layer_fwd_train(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
+                                           const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk, float* y, float* ws,
+                                           void* stream) {
+    return dense_layer_fwd(w, x_q, x_kv, qvalid, kvalid, mask, N, Lq, Lk, y, ws, true, (hipStream_t)stream);
+}
+
+// dW[N_, K_] = dY^T X over `rows` rows: split-K over chunks of kDenseSplitRows rows (one k_wgrad tile per (n0, k0, chunk), partial
+// results in `part`), then a column sum over the chunks.  Fixed order: deterministic.
+static int dense_wgrad(const float* dY, int lddy, const float* X, int ldx, long long rows, float* dW, int N_, int K_, float* part,
+                       WgTile* tiles_d, CsTile* cs_d, hipStream_t st) {
+    const int splits = (int)((rows + kDenseSplitRows - 1) / kDenseSplitRows);
+    std::vector<WgTile> tiles;
+    for (int s = 0; s < splits; ++s) {
+        const long long r0 = (long long)s * kDenseSplitRows;
+        const int m = (int)std::min<long long>(kDenseSplitRows, rows - r0);
+        push_wg(tiles, wg1(dY + r0 * lddy, lddy, X + r0 * ldx, ldx, m, part + (size_t)s * N_ * K_, K_, N_, K_));
+    }
+    std::vector<CsTile> cs;
+    push_cs(cs, part, N_ * K_, N_ * K_, splits, 1, dW);
+    if (tiles.size() * sizeof(WgTile) + cs.size() * sizeof(CsTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64)
+        return fail("cf_op_dense_layer_bwd: tile table overflow");
+    HIP_TRY(hipMemcpyAsync(tiles_d, tiles.data(), tiles.size() * sizeof(WgTile), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(cs_d, cs.data(), cs.size() * sizeof(CsTile), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_wgrad, dim3((int)tiles.size()), dim3(256), 0, st, (const WgTile*)tiles_d, 1);
+    LAUNCH_CHECK("k_wgrad<dense layer>");
+    hipLaunchKernelGGL(k_colsum, dim3((int)cs.size()), dim3(256), 0, st, (const CsTile*)cs_d, 1);
+    LAUNCH_CHECK("k_colsum<dense layer>");
+    return 0;
+}
+
+extern "C" int cf_op_dense_layer_bwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
+                                     const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk, const float* dy,
+                                     float* dx_q, float* dx_kv, const cf_dense_layer_grads* g, float* ws, float* tables, void* stream) {
+    if (!w || !x_q || !x_kv || !dy || !dx_q || !dx_kv || !g || !ws || !tables) return fail("cf_op_dense_layer_bwd: null argument");
+    if (w->d_ff != 128 && w->d_ff != 256) return fail("cf_op_dense_layer_bwd: d_ff must be 128 or 256");
+    hipStream_t st = (hipStream_t)stream;
+    const int dff = w->d_ff;
+    const long long rq = (long long)N * Lq, rk = (long long)N * Lk;
+    const DenseWs L = dense_ws(N, Lq, Lk, dff, true);
+    const int tiles_q = tiles_of((int)rq);
+    {   // out-projection / LN / FFN / LN chain
+        PostBwdArgs p;
+        memset(&p, 0, sizeof p);
+        p.dout[0] = dy;
+        p.dmap = identity_map();
+        p.xh2[0] = ws + L.xh2;
+        p.rs2[0] = ws + L.rs2;
+        p.g2[0] = w->ln2_g;
+        p.hdn[0] = ws + L.hdn;
+        p.w2[0] = w->w2;
+        p.w1[0] = w->w1;
+        p.xh1[0] = ws + L.xh1;
+        p.rs1[0] = ws + L.rs1;
+        p.g1[0] = w->ln1_g;
+        p.wo[0] = w->wo;
+        p.dt2[0] = ws + L.dt2;
+        p.dpre1[0] = ws + L.dpre1;
+        p.dt1[0] = ws + L.dt1;
+        p.da[0] = ws + L.da;
+        p.partial[0] = ws + L.partial;
+        p.N = (int)rq;
+        launch_post_bwd<false, 128>(dff, dim3(tiles_q, 1), st, p);
+        LAUNCH_CHECK("k_post_bwd<dense layer>");
+    }
+    {   // attention core
+        AttnArgs a;
+        cf_attn_shape sh = {N, 2, Lq, Lk, 128, 256, 256, 128};
+        if (attn_args(&sh, a)) return -1;
+        a.q = ws + L.q;
+        a.k = ws + L.kv;
+        a.v = ws + L.kv + 128;
+        a.qvalid = qvalid;
+        a.kvalid = kvalid;
+        a.mask = mask;
+        a.o = ws + L.o;
+        a.stats = ws + L.stats;
+        a.d_o = ws + L.da;
+        a.dq = ws + L.dq;
+        a.dk = ws + L.dkv;
+        a.dv = ws + L.dkv + 128;
+        a.delta = ws + L.delta;
+        hipLaunchKernelGGL(k_attn_delta, dim3((Lq + 15) / 16, 2, N), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_attn_delta");
+        hipLaunchKernelGGL(k_attn_bwd_kv, dim3((Lk + kABk - 1) / kABk, 2, N), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_attn_bwd_kv");
+        hipLaunchKernelGGL(k_attn_bwd_q, dim3((Lq + kABq - 1) / kABq, 2, N), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_attn_bwd_q");
+    }
+    {   // input gradients: dx_q = dt1 (residual) + dq Wq;  dx_kv = dkv Wkv
+        DgradArgs d;
+        memset(&d, 0, sizeof d);
+        d.dy[0] = ws + L.dq;
+        d.lddy = 128;
+        d.w[0] = w->wq;
+        d.ldw = 128;
+        d.res[0] = ws + L.dt1;
+        d.rmap = identity_map();
+        d.ldres = 128;
+        d.dx[0] = dx_q;
+        d.lddx = 128;
+        d.N = (int)rq;
+        d.K = 128;
+        d.Ncols = 128;
+        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_q, 128 / 32, 1), dim3(256), 0, st, d);
+        LAUNCH_CHECK("k_dgrad<q>");
+        memset(&d, 0, sizeof d);
+        d.dy[0] = ws + L.dkv;
+        d.lddy = 256;
+        d.w[0] = w->wkv;
+        d.ldw = 128;
+        d.rmap = identity_map();
+        d.dx[0] = dx_kv;
+        d.lddx = 128;
+        d.N = (int)rk;
+        d.K = 256;
+        d.Ncols = 128;
+        hipLaunchKernelGGL((k_dgrad<4>), dim3(tiles_of((int)rk), 128 / 32, 1), dim3(256), 0, st, d);
+        LAUNCH_CHECK("k_dgrad<kv>");
+    }
+    // weight gradients (split-K), bias / LayerNorm gradients (column sums of the per-tile partials)
+    WgTile* tiles_d = reinterpret_cast<WgTile*>(tables);
+    CsTile* cs_d = reinterpret_cast<CsTile*>(tables + (size_t)(kDenseTab / 2) * 64);
+    float* part = ws + L.wpart;
+    if (dense_wgrad(ws + L.dq, 128, x_q, 128, rq, g->wq, 128, 128, part, tiles_d, cs_d, st)) return -1;
+    if (dense_wgrad(ws + L.dkv, 256, x_kv, 128, rk, g->wkv, 256, 128, part, tiles_d, cs_d, st)) return -1;
+    if (dense_wgrad(ws + L.dt1, 128, ws + L.o, 128, rq, g->wo, 128, 128, part, tiles_d, cs_d, st)) return -1;
+    if (dense_wgrad(ws + L.dpre1, dff, ws + L.y1, 128, rq, g->w1, dff, 128, part, tiles_d, cs_d, st)) return -1;
+    if (dense_wgrad(ws + L.dt2, 128, ws + L.hdn, dff, rq, g->w2, 128, dff, part, tiles_d, cs_d, st)) return -1;
+    {
+        const int pw = post_partial_width(dff);
+        const float* pp = ws + L.partial;
+        std::vector<CsTile> cs;
+        push_cs(cs, pp + 0, pw, kD, tiles_q, 1, g->ln2_g);
+        push_cs(cs, pp + 128, pw, kD, tiles_q, 1, g->ln2_b);
+        push_cs(cs, pp + 256, pw, kD, tiles_q, 1, g->b2);
+        push_cs(cs, pp + 384, pw, dff, tiles_q, 1, g->b1);
+        push_cs(cs, pp + 384 + dff, pw, kD, tiles_q, 1, g->ln1_g);
+        push_cs(cs, pp + 512 + dff, pw, kD, tiles_q, 1, g->ln1_b);
+        push_cs(cs, pp + 640 + dff, pw, kD, tiles_q, 1, g->bo);
+        HIP_TRY(hipMemcpyAsync(cs_d, cs.data(), cs.size() * sizeof(CsTile), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_colsum, dim3((int)cs.size()), dim3(256), 0, st, (const CsTile*)cs_d, 1);
+        LAUNCH_CHECK("k_colsum<dense layer bias>");
     }
     return 0;
 }

@@ -209,8 +209,8 @@ int cf_op_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K,
 /* One AttentionBlock / PairwiseAttentionBlock over ALL query rows (modules.py:104-112, 198-208), d_emb = d_model =
  * 128, 2 heads of 64:   a = Attn(x_q Wq^T, x_kv Wk^T, x_kv Wv^T);  y1 = LN(x_q + a Wo^T + bo);
  * y = LN(y1 + relu(y1 W1^T + b1) W2^T + b2).  Self-attention: x_q = x_kv and (wq, wkv) are the row blocks
- * [0,128) and [128,384) of `att.weight`; pairwise: wq = p_att.weight, wkv = c_att.weight.  Inference only (the
- * training path never needs all rows; the backward pass of the core is cf_op_attention_bwd).  `ws` is a device
+ * [0,128) and [128,384) of `att.weight`; pairwise: wq = p_att.weight, wkv = c_att.weight.  (The training path of the
+ * model never needs all rows; these operators serve the stress configuration and consumers of full embeddings.)  `ws` is a device
  * workspace of cf_op_dense_layer_workspace(...) floats; masks as in cf_op_attention_fwd. */
 typedef struct cf_dense_layer {
     const float *wq, *wkv;            /* [128,128], [256,128] */
@@ -222,6 +222,22 @@ long long cf_op_dense_layer_workspace(int N, int Lq, int Lk, int d_ff);
 int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
                           const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk, float* y,
                           float* ws, void* stream);
+/* Training form: cf_op_dense_layer_fwd_train keeps the activations the backward pass needs in `ws`
+ * (cf_op_dense_layer_train_workspace floats); cf_op_dense_layer_bwd turns dy [N*Lq, 128] into dx_q [N*Lq, 128],
+ * dx_kv [N*Lk, 128] (a self-attention caller adds the two) and the gradients of all twelve tensors (`grads`, same
+ * shapes as the weights, overwritten).  `tables`: device scratch of 4 MiB for the tile tables.  Weight gradients
+ * are split-K sums in a fixed order: bit-reproducible.  Synchronises the stream while it uploads the tables. */
+typedef struct cf_dense_layer_grads {
+    float *wq, *wkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+} cf_dense_layer_grads;
+long long cf_op_dense_layer_train_workspace(int N, int Lq, int Lk, int d_ff);
+int cf_op_dense_layer_fwd_train(const cf_dense_layer* w, const float* x_q, const float* x_kv,
+                                const unsigned char* qvalid, const unsigned char* kvalid, const unsigned char* mask,
+                                int N, int Lq, int Lk, float* y, float* ws, void* stream);
+int cf_op_dense_layer_bwd(const cf_dense_layer* w, const float* x_q, const float* x_kv, const unsigned char* qvalid,
+                          const unsigned char* kvalid, const unsigned char* mask, int N, int Lq, int Lk,
+                          const float* dy, float* dx_q, float* dx_kv, const cf_dense_layer_grads* grads, float* ws,
+                          float* tables, void* stream);
 
 /* ---- input pipeline ------------------------------------------------------------------ */
 /* ChromoformerDataset._bin_and_pad + strand flip (data.py:68-113) on the device: per region, the window

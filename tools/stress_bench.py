@@ -66,12 +66,30 @@ def layer_bench(n_seq, dff):
     xq = torch.randn(n_seq, L, 128, device=dev, generator=g)
     xk = torch.randn(n_seq, L, 128, device=dev, generator=g)
     y = torch.empty_like(xq)
-    ws_l = torch.empty(lib.cf_op_dense_layer_workspace(n_seq, L, L, dff), device=dev)
+    ws_l = torch.empty(lib.cf_op_dense_layer_train_workspace(n_seq, L, L, dff), device=dev)
     vl = torch.ones(n_seq, L, dtype=torch.uint8, device=dev)
     run = lambda: _lib.check(lib.cf_op_dense_layer_fwd(C.byref(w), p(xq), p(xk), p(vl), p(vl), None, n_seq, L, L, p(y), p(ws_l), st), "layer")
     ms = timed(run)
-    flops = n_seq * (2.0 * L * 128 * 384 + 4.0 * L * L * 128 + 2.0 * L * 128 * 128 + 4.0 * L * 128 * dff)
-    return {"ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}
+    lin = n_seq * (2.0 * L * 128 * 384 + 2.0 * L * 128 * 128 + 4.0 * L * 128 * dff)
+    att = n_seq * 4.0 * L * L * 128
+    out = {"fwd_ms": round(ms, 3), "fwd_tflops": round((lin + att) / ms / 1e9, 2)}
+    # training: forward with saves + backward (input gradients, split-K weight gradients, bias / LayerNorm gradients)
+    grads = {k: torch.empty_like(v) for k, v in wts.items()}
+    gs = _lib.cf_dense_layer_grads()
+    for f, k in (("wq", "wq"), ("wkv", "wkv"), ("wo", "wo"), ("bo", "bo"), ("ln1_g", "g1"), ("ln1_b", "b1n"), ("w1", "w1"), ("b1", "b1"), ("w2", "w2"),
+                 ("b2", "b2"), ("ln2_g", "g2"), ("ln2_b", "b2n")):
+        setattr(gs, f, grads[k].data_ptr())
+    dyl, dxq, dxk = torch.randn_like(xq), torch.empty_like(xq), torch.empty_like(xk)
+    tables = torch.empty(1 << 20, device=dev)
+
+    def train():
+        _lib.check(lib.cf_op_dense_layer_fwd_train(C.byref(w), p(xq), p(xk), p(vl), p(vl), None, n_seq, L, L, p(y), p(ws_l), st), "fwd_train")
+        _lib.check(lib.cf_op_dense_layer_bwd(C.byref(w), p(xq), p(xk), p(vl), p(vl), None, n_seq, L, L, p(dyl), p(dxq), p(dxk), C.byref(gs),
+                                             p(ws_l), p(tables), st), "bwd")
+    mt = timed(train)
+    out.update({"fwd_bwd_ms": round(mt, 3), "fwd_bwd_tflops": round((3.0 * lin + 3.5 * att) / mt / 1e9, 2),
+                "fwd_bwd_frac": round((3.0 * lin + 3.5 * att) / mt / 1e9 / 157.3, 4)})
+    return out
 
 
 tf, tb = timed(fwd), timed(bwd)
