@@ -299,10 +299,10 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
             for (int k = 0; k < KMAX; ++k)
                 if (k < nk) {
                     const int j = 4 * sub + 4 * LPR * k;
-                    xv[k].x = j < L ? expf(xv[k].x - mx) : 0.f;
-                    xv[k].y = j + 1 < L ? expf(xv[k].y - mx) : 0.f;
-                    xv[k].z = j + 2 < L ? expf(xv[k].z - mx) : 0.f;
-                    xv[k].w = j + 3 < L ? expf(xv[k].w - mx) : 0.f;
+                    xv[k].x = j < L ? __expf(xv[k].x - mx) : 0.f;
+                    xv[k].y = j + 1 < L ? __expf(xv[k].y - mx) : 0.f;
+                    xv[k].z = j + 2 < L ? __expf(xv[k].z - mx) : 0.f;
+                    xv[k].w = j + 3 < L ? __expf(xv[k].w - mx) : 0.f;
                     z += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
                 }
             z = sum32(z);
