@@ -428,9 +428,20 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         }
         __syncthreads();
         if (kh == 0) {
+            // Wlp rows of this lane's four output columns: 8 sixteen-byte reads instead of 32 scalar ones per row
+            float wl[4][8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wlp_s + (cg * 64 + 4 * lr + t) * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(wlp_s + (cg * 64 + 4 * lr + t) * 8 + 4);
+                wl[t][0] = w0.x, wl[t][1] = w0.y, wl[t][2] = w0.z, wl[t][3] = w0.w;
+                wl[t][4] = w1.x, wl[t][5] = w1.y, wl[t][6] = w1.z, wl[t][7] = w1.w;
+            }
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int m = lq * 4 + ii, e0 = cg * 64 + 4 * lr;
+                const float4 wa = *reinterpret_cast<const float4*>(w_s + m * 8), wb = *reinterpret_cast<const float4*>(w_s + m * 8 + 4);
+                const float wm[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
                 const float4 r1 = *reinterpret_cast<const float4*>(red_s + m * LD + e0);
                 const float4 r2 = *reinterpret_cast<const float4*>(vin_s + m * LD + e0);
                 const float4 r3 = *reinterpret_cast<const float4*>(sc_s + m * LD + e0);
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int f = 0; f < 8; ++f) v[t] = fmaf(w_s[m * 8 + f], wlp_s[(e0 + t) * 8 + f], v[t]);
+                    for (int f = 0; f < 8; ++f) v[t] = fmaf(wm[f], wl[t][f], v[t]);
                 if ((m >> 1) < nreg) stg4(a.vout[r] + ((size_t)n0 * 2 + m) * kD + e0, make_float4(v[0], v[1], v[2], v[3]));
             }
         }
