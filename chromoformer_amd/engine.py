@@ -54,20 +54,34 @@ class Slot:
         self.graph = None
 
     def fill(self, model, d, non_blocking=True):
-        """Copy a reference-layout batch dict (host or device) into the slot."""
+        """Copy a reference-layout batch dict (host or device) into the slot.
+
+        The copies are asynchronous on the current stream, so the sources must outlive them: the slot keeps a reference
+        to everything it was filled from until the next fill (callers routinely pass temporaries -- a gathered batch, a
+        sliced dict -- and a freed pageable host block that is reused before hipMemcpyAsync has read it shows up as a
+        silently wrong batch)."""
+        self._hold = hold = []
+
+        def put(dst, src):
+            src = src.reshape(dst.shape)         # may materialise a temporary (a strided mask row, say): it is held as well
+            if src.dtype != dst.dtype and not src.is_cuda:
+                src = src.to(dst.dtype)          # bool -> uint8 on the host, explicitly, so that this temporary is held too
+            hold.append(src)
+            dst.copy_(src, non_blocking=non_blocking)
+
         for r, b in enumerate(model.binsizes):
             L = model.n_bins[r]
-            self.pf[r].copy_(d["promoter_feats"][b].reshape(self.pf[r].shape), non_blocking=non_blocking)
-            self.cf[r].copy_(d["pcre_feats"][b].reshape(self.cf[r].shape), non_blocking=non_blocking)
+            put(self.pf[r], d["promoter_feats"][b])
+            put(self.cf[r], d["pcre_feats"][b])
             pm, cm = d["promoter_pad_masks"][b], d["pcre_pad_masks"][b]
             if pm.dim() == 5:
                 pm, cm = pm[:, 0, 0, L // 2, :], cm[:, :, 0, L // 2, :]
-            self.pm[r].copy_(pm.reshape(self.pm[r].shape), non_blocking=non_blocking)
-            self.cm[r].copy_(cm.reshape(self.cm[r].shape), non_blocking=non_blocking)
-            self.im[r].copy_(d["interaction_masks"][b].reshape(self.im[r].shape), non_blocking=non_blocking)
-        self.freq.copy_(d["interaction_freq"], non_blocking=non_blocking)
+            put(self.pm[r], pm)
+            put(self.cm[r], cm)
+            put(self.im[r], d["interaction_masks"][b])
+        put(self.freq, d["interaction_freq"])
         if "label" in d:
-            self.label.copy_(d["label"].reshape(-1), non_blocking=non_blocking)
+            put(self.label, d["label"].reshape(-1))
         return self
 
 
