@@ -52,6 +52,9 @@ class Slot:
         bs.interaction_freq = self.freq.data_ptr()
         self.struct = bs
         self.graph = None
+        # The zero fills above ran on the CURRENT stream; the slot is filled and consumed on other (non-blocking) streams,
+        # which do not wait for it.  Without this a late fill kernel wipes a batch that has already been copied in.
+        torch.cuda.current_stream(dev).synchronize()
 
     def fill(self, model, d, non_blocking=True):
         """Copy a reference-layout batch dict (host or device) into the slot.
@@ -109,6 +112,7 @@ class Trainer:
         # hipGraph capture needs a non-default stream; all work of the trainer runs on it
         self.stream = torch.cuda.Stream(device=model._device)
         self.side = torch.cuda.Stream(device=model._device)       # all-reduce of the early gradient bucket
+        torch.cuda.synchronize(model._device)      # parameter upload / buffer fills of the model ran on the default stream
         self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         self._buckets = {}
         for b in (_lib.BUCKET_REG, _lib.BUCKET_PE):
