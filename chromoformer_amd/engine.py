@@ -233,13 +233,29 @@ class Trainer:
                 self._launch(slot.graph["late"], st)
             else:
                 self._seq_late(slot, st)
-            torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
             if oig:
+                torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
                 self._opt(_lib.BUCKET_PE, st)
-            self.stream.wait_event(self._ev_join)
-            if oig and not self.overlap_opt:
-                self._opt(_lib.BUCKET_REG, st)
-        if not oig:
+                self.stream.wait_event(self._ev_join)
+                if not self.overlap_opt:
+                    self._opt(_lib.BUCKET_REG, st)
+            else:
+                # the late bucket's all-reduce goes to the side stream as well (behind the early one) and the main stream
+                # steps the early bucket meanwhile: only the late bucket's 6 us of AdamW wait for the second all-reduce
+                ev_late = torch.cuda.Event()
+                ev_late.record(self.stream)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev_late)
+                    torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
+                    ev_done = torch.cuda.Event()
+                    ev_done.record(self.side)
+                self.stream.wait_event(self._ev_join)            # early bucket reduced
+                m._step += 1
+                hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
+                _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_REG, st), "cf_adamw_step_part")
+                self.stream.wait_event(ev_done)                  # late bucket reduced
+                _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_PE, st), "cf_adamw_step_part")
+        if not oig and not self.dp:
             m.adamw_step(self.lr, self.betas, self.eps, self.wd)
         self._last = slot
         return slot.logits, slot.loss
