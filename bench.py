@@ -105,10 +105,10 @@ def main():
 
     from chromoformer_amd import ChromoformerClassifier
     from chromoformer_amd.engine import Trainer
-    from oracle import chromoformer_oracle as orc  # synthetic workload generator only (inputs, not compute)
+    from chromoformer_amd.synth import synthetic_batch
 
     model = ChromoformerClassifier(seed=42, max_batch=BSZ).cuda(local)
-    batch = orc.synthetic_batch(BSZ, seed=1234 + rank, regime=args.regime)
+    batch = synthetic_batch(BSZ, seed=1234 + rank, regime=args.regime)
     trainer = Trainer(model, lr=3e-5, world_size=world, process_group=pg, use_graph=not args.no_graph,
                       timed_kernel=args.roofline_kernel)
     slot = trainer.stage(batch)            # inputs resident in HBM before the timed region

@@ -4,10 +4,10 @@ os.environ["CF_STAMP_ATTC"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from chromoformer_amd import ChromoformerClassifier
-from oracle import chromoformer_oracle as orc
+from chromoformer_amd.synth import synthetic_batch
 B = 64
 m = ChromoformerClassifier(max_batch=B).cuda(0)
-packed = m.pack_batch(orc.synthetic_batch(B, seed=1, regime="dense"))
+packed = m.pack_batch(synthetic_batch(B, seed=1, regime="dense"))
 for _ in range(3):
     m.forward_backward(packed, torch.zeros(B, dtype=torch.long))
 torch.cuda.synchronize()

@@ -4,9 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from chromoformer_amd import ChromoformerClassifier
 from chromoformer_amd.engine import Trainer
-from oracle import chromoformer_oracle as orc
+from chromoformer_amd.synth import synthetic_batch
 B = 64
-batch = orc.synthetic_batch(B, seed=1234, regime="dense")
+batch = synthetic_batch(B, seed=1234, regime="dense")
 for name, kw in (("one graph", dict(use_graph=True)), ("split graph (k_reg_bwd timed)", dict(use_graph=True, timed_kernel="k_reg_bwd")),
                  ("eager", dict(use_graph=False))):
     res = []
