@@ -2110,16 +2110,34 @@ extern "C" int cf_op_dense_layer_bwd(const cf_dense_layer* w, const float* x_q, 
     if (dense_wgrad(ws + L.dpre1, dff, ws + L.y1, 128, rq, g->w1, dff, 128, part, tiles_d, cs_d, st)) return -1;
     if (dense_wgrad(ws + L.dt2, 128, ws + L.hdn, dff, rq, g->w2, 128, dff, part, tiles_d, cs_d, st)) return -1;
     {
+        // two stages: the per-tile partial rows (one per 16 input rows: 100,000 of them at the stress shape) are first summed in
+        // chunks of 512 rows by many workgroups, then the chunk sums per quantity -- one workgroup walking 100,000 rows took 11 ms
         const int pw = post_partial_width(dff);
         const float* pp = ws + L.partial;
+        constexpr int kChunkRows = 512;
+        const int nchunks = (tiles_q + kChunkRows - 1) / kChunkRows;
+        float* part2 = ws + L.wpart;                 // free again: the weight gradients above are done with it
+        if ((long long)nchunks * pw > (long long)L.splits * 256 * 128) return fail("cf_op_dense_layer_bwd: chunk buffer too small");
+        {
+            std::vector<CsTile> cs1;
+            for (int ch = 0; ch < nchunks; ++ch) {
+                const int rows = std::min(kChunkRows, tiles_q - ch * kChunkRows);
+                push_cs(cs1, pp + (size_t)ch * kChunkRows * pw, pw, pw, rows, 1, part2 + (size_t)ch * pw);
+            }
+            if (cs1.size() * sizeof(CsTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64) return fail("cf_op_dense_layer_bwd: tile table overflow");
+            HIP_TRY(hipMemcpyAsync(tiles_d, cs1.data(), cs1.size() * sizeof(CsTile), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            hipLaunchKernelGGL(k_colsum, dim3((int)cs1.size()), dim3(256), 0, st, (const CsTile*)tiles_d, 1);
+            LAUNCH_CHECK("k_colsum<dense layer bias, stage 1>");
+        }
         std::vector<CsTile> cs;
-        push_cs(cs, pp + 0, pw, kD, tiles_q, 1, g->ln2_g);
-        push_cs(cs, pp + 128, pw, kD, tiles_q, 1, g->ln2_b);
-        push_cs(cs, pp + 256, pw, kD, tiles_q, 1, g->b2);
-        push_cs(cs, pp + 384, pw, dff, tiles_q, 1, g->b1);
-        push_cs(cs, pp + 384 + dff, pw, kD, tiles_q, 1, g->ln1_g);
-        push_cs(cs, pp + 512 + dff, pw, kD, tiles_q, 1, g->ln1_b);
-        push_cs(cs, pp + 640 + dff, pw, kD, tiles_q, 1, g->bo);
+        push_cs(cs, part2 + 0, pw, kD, nchunks, 1, g->ln2_g);
+        push_cs(cs, part2 + 128, pw, kD, nchunks, 1, g->ln2_b);
+        push_cs(cs, part2 + 256, pw, kD, nchunks, 1, g->b2);
+        push_cs(cs, part2 + 384, pw, dff, nchunks, 1, g->b1);
+        push_cs(cs, part2 + 384 + dff, pw, kD, nchunks, 1, g->ln1_g);
+        push_cs(cs, part2 + 512 + dff, pw, kD, nchunks, 1, g->ln1_b);
+        push_cs(cs, part2 + 640 + dff, pw, kD, nchunks, 1, g->bo);
         HIP_TRY(hipMemcpyAsync(cs_d, cs.data(), cs.size() * sizeof(CsTile), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         hipLaunchKernelGGL(k_colsum, dim3((int)cs.size()), dim3(256), 0, st, (const CsTile*)cs_d, 1);

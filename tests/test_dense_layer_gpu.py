@@ -108,7 +108,7 @@ def _close(got, ref, name, tol=2e-4):
     assert err <= tol * max(ref.abs().max().item(), 1e-3), (name, err, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("L,N", [(80, 3), (400, 2), (96, 70)])      # the last one spans several split-K chunks (6,720 rows)
+@pytest.mark.parametrize("L,N", [(80, 3), (400, 2), (96, 70), (96, 140)])      # the last ones span several split-K chunks (6,720 / 13,440 rows; the largest also two chunks of bias partials)
 def test_embedding_layer_backward(L, N):
     dev = torch.device("cuda", 0)
     P = {k: v.clone().requires_grad_(True) for k, v in orc.init_params(None, 5, False).items()}
