@@ -1358,11 +1358,12 @@ constexpr int kWgLdB = 64 + 4;
 __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) {
     // 64 x 64 output tile; wave w owns rows n0+16w..+15.  Both operands are staged through LDS (every element of dY
     // is used by one wave but every element of X by all four: reading X straight from L2 in each wave made the
-    // kernel L1-bound at 37 % of the MFMA peak), double-buffered, one barrier per 32 reduction rows; the global loads
-    // of stage i+1 are in flight while stage i is multiplied.  B is read 16 bytes per lane, so accumulator c holds
+    // kernel L1-bound at 37 % of the MFMA peak), one 19 KB stage of 32 reduction rows (single-buffered: seven workgroups
+    // per CU hide the two barriers better than a double buffer with four did); the global loads of stage i+1 are in
+    // flight while stage i is multiplied.  B is read 16 bytes per lane, so accumulator c holds
     // the strided columns k0 + 4r + c.
-    __shared__ __attribute__((aligned(16))) float As[2][kWgM * kWgLdA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][kWgM * kWgLdB];
+    __shared__ __attribute__((aligned(16))) float As[1][kWgM * kWgLdA];
+    __shared__ __attribute__((aligned(16))) float Bs[1][kWgM * kWgLdB];
     const WgTile& t = tiles[blockIdx.x];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int kc = t.k0 + 4 * lr;
@@ -1395,15 +1396,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
                 *reinterpret_cast<float4*>(&Bs[buf][(sm + 16 * p) * kWgLdB + sc]) = rb[p];
             }
         };
-        __syncthreads();                                       // the previous segment's last stage has been consumed
         fetch(0);
-        put(0);
-        __syncthreads();
         for (int st = 0; st < nst; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nst) fetch(st + 1);
-            const float* ap = &As[buf][lq * kWgLdA + 16 * w + lr];
-            const float* bp = &Bs[buf][lq * kWgLdB + 4 * lr];
+            __syncthreads();                                   // the previous stage has been consumed
+            put(0);
+            __syncthreads();
+            if (st + 1 < nst) fetch(st + 1);                   // in flight during this stage's multiply
+            const float* ap = &As[0][lq * kWgLdA + 16 * w + lr];
+            const float* bp = &Bs[0][lq * kWgLdB + 4 * lr];
 #pragma unroll
             for (int i = 0; i < kWgM / 4; ++i) {
                 const float av = ap[4 * i * kWgLdA];
@@ -1413,8 +1413,6 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
                 acc[2] = mfma4(av, bv.z, acc[2]);
                 acc[3] = mfma4(av, bv.w, acc[3]);
             }
-            if (st + 1 < nst) put(buf ^ 1);
-            __syncthreads();
         }
     }
     if (!kv) return;
