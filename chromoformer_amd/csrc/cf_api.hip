@@ -181,6 +181,7 @@ struct CentreBuf {   // one centre-row attention layer of one resolution
 struct RegBuf {
     float *qkvg, *p, *a, *xh1, *rs1, *y1, *hdn, *xh2, *rs2;
     float *dt2, *dpre1, *dt1, *da, *dqkvg, *partial, *dgam;
+    float *hq, *dy1;
 };
 struct WsEntry {
     std::string name;
@@ -194,6 +195,8 @@ struct cf_handle {
     cf_layout lay;
     float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
     float* tiled = nullptr;              // tiled copy of the Linear weights (forward products), same offsets
+    float* tiledT = nullptr;             // tiled copy of the transposed Regulation weights (backward products), same offsets
+    bool reg8 = false;                   // Regulation stack on the 512-thread kernels of cf_reg8.h
     RetileUnit* retile_units = nullptr;
     int n_retile = 0;
     // workspace
@@ -283,6 +286,7 @@ struct cf_handle {
     }
     const float* P_(const std::string& name, long long extra = 0) const { return params + table[index.at(name)].offset + extra; }
     const float* T_(const std::string& name, long long extra = 0) const { return tiled + table[index.at(name)].offset + extra; }
+    const float* TT_(const std::string& name) const { return tiledT + table[index.at(name)].offset; }
     float* G_(const std::string& name, long long extra = 0) const { return grads + table[index.at(name)].offset + extra; }
 };
 
@@ -365,6 +369,8 @@ static void plan_workspace(cf_handle* h) {
             b.dqkvg = h->ws_get(d + "qkvg", NR * kRW);
             b.partial = h->ws_get(d + "partial", std::max((NR + kTile - 1) / kTile, MB) * post_partial_width(dff));
             b.dgam = h->ws_get(d + "gam", MB * kRH);
+            b.hq = h->ws_get(pre + "hq", MB * kRH * kHqFloats);
+            b.dy1 = h->ws_get(d + "y1", NR * kD);
         }
     }
     h->hin = h->ws_get("H.in", MB * 3 * kD);
@@ -414,8 +420,8 @@ static WgJob wg1(const float* A, int lda, const float* B, int ldb, int rpg, floa
     j.Kk = Kk;
     return j;
 }
-static void push_cs(std::vector<CsTile>& out, const float* src, int ld, int ncols, int rpg, int div, float* dst) {
-    for (int c0 = 0; c0 < ncols; c0 += 64) out.push_back(CsTile{src, dst, ld, ncols, c0, rpg, div});
+static void push_cs(std::vector<CsTile>& out, const float* src, int ld, int ncols, int rpg, int div, float* dst, const float* src2 = nullptr) {
+    for (int c0 = 0; c0 < ncols; c0 += 64) out.push_back(CsTile{src, dst, ld, ncols, c0, rpg, div, src2});
 }
 // the bias / LayerNorm gradients carried by one post-chain partial buffer
 static void push_post_cs(std::vector<CsTile>& out, const cf_handle* h, const float* part, int dff, int rpg,
@@ -445,7 +451,14 @@ static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const C
 
 // the fused Regulation kernels are instantiated for the default token count (T = 9, loops over tokens
 // unrolled) and once with a run-time T
-static const void* reg_kernel(bool bwd, int dff, int T) {
+static const void* reg_kernel(bool bwd, int dff, int T, bool reg8, bool save = true) {
+    if (reg8) {
+        if (!bwd) {
+            if (save) return dff == 128 ? (const void*)k_reg8_fwd<128, true> : (const void*)k_reg8_fwd<256, true>;
+            return dff == 128 ? (const void*)k_reg8_fwd<128, false> : (const void*)k_reg8_fwd<256, false>;
+        }
+        return dff == 128 ? (const void*)k_reg8_bwd<128> : (const void*)k_reg8_bwd<256>;
+    }
     const bool t9 = T == 9;
     if (!bwd) {
         if (dff == 128) return t9 ? (const void*)k_reg_fwd<128, 9> : (const void*)k_reg_fwd<128, 0>;
@@ -469,6 +482,10 @@ static int build_reg_table(cf_handle* h) {
                 d.wo_t = h->T_(lp + "self_att.ff.weight");
                 d.w1_t = h->T_(lp + "ff.l1.weight");
                 d.w2_t = h->T_(lp + "ff.l2.weight");
+                d.watt_tt = h->TT_(lp + "self_att.att.weight");
+                d.wo_tt = h->TT_(lp + "self_att.ff.weight");
+                d.w1_tt = h->TT_(lp + "ff.l1.weight");
+                d.w2_tt = h->TT_(lp + "ff.l2.weight");
                 d.gamma = h->P_(lp + "self_att.gamma_f");
                 d.wo = h->P_(lp + "self_att.ff.weight");
                 d.bo = h->P_(lp + "self_att.ff.bias");
@@ -500,6 +517,8 @@ static int build_reg_table(cf_handle* h) {
                 d.dxin = h->dRx[r][l];
                 d.partial = b.partial;
                 d.dgam = b.dgam;
+                d.hq = b.hq;
+                d.dy1 = b.dy1;
                 rt.push_back(d);
             }
         if (h->reg_tab) (void)hipFree(h->reg_tab);
@@ -571,7 +590,16 @@ static int build_tables(cf_handle* h) {
             push_wg(wgR, wg1(b.dt1, kD, b.a, kRDm, T, h->G_(lp + "self_att.ff.weight"), kRDm, kD, kRDm));
             push_wg(wgR, wg1(b.dpre1, dff, b.y1, kD, T, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
             push_wg(wgR, wg1(b.dt2, kD, b.hdn, dff, T, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
-            if (h->reg_fused) {       // one partial row per gene instead of per 16-row tile
+            if (h->reg8) {            // column sums straight from the row-level arrays the backward kernel writes anyway
+                const std::string ap = lp + "self_att.", fp = lp + "ff.";
+                push_cs(csR, h->dRx[r][l + 1], kD, kD, T, 1, h->G_(fp + "ln.weight"), b.xh2);
+                push_cs(csR, h->dRx[r][l + 1], kD, kD, T, 1, h->G_(fp + "ln.bias"));
+                push_cs(csR, b.dt2, kD, kD, T, 1, h->G_(fp + "l2.bias"));
+                push_cs(csR, b.dpre1, dff, dff, T, 1, h->G_(fp + "l1.bias"));
+                push_cs(csR, b.dy1, kD, kD, T, 1, h->G_(ap + "ln.weight"), b.xh1);
+                push_cs(csR, b.dy1, kD, kD, T, 1, h->G_(ap + "ln.bias"));
+                push_cs(csR, b.dt1, kD, kD, T, 1, h->G_(ap + "ff.bias"));
+            } else if (h->reg_fused) {       // one partial row per gene instead of per 16-row tile
                 const int pw = post_partial_width(dff);
                 const std::string ap = lp + "self_att.", fp = lp + "ff.";
                 push_cs(csR, b.partial + 0, pw, kD, 1, 1, h->G_(fp + "ln.weight"));
@@ -676,9 +704,11 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         std::vector<RetileUnit> units;
         for (const PDesc& p : h->table)
             if (p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable)
-                for (int n0 = 0; n0 < p.shape[0]; n0 += 16) units.push_back(RetileUnit{p.offset + (long long)n0 * p.shape[1], p.shape[1]});
+                for (int n0 = 0; n0 < p.shape[0]; n0 += 16) units.push_back(RetileUnit{p.offset + (long long)n0 * p.shape[1], p.offset, p.shape[1], p.shape[0], n0,
+                                                p.name.rfind("regulation.", 0) == 0 ? 1 : 0});
         h->n_retile = (int)units.size();
         if (hipMalloc(&h->hyper, sizeof(AdamHyper)) != hipSuccess || hipMalloc(&h->tiled, h->lay.n_total * sizeof(float)) != hipSuccess ||
+            hipMalloc(&h->tiledT, h->lay.n_total * sizeof(float)) != hipSuccess ||
             hipMalloc(&h->retile_units, units.size() * sizeof(RetileUnit)) != hipSuccess ||
             hipMemcpy(h->retile_units, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice) != hipSuccess) {
             delete h;
@@ -717,14 +747,19 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     const cf_config& c = h->cfg;
     {   // the fused Regulation kernels need up to ~150 KB of dynamic LDS
         const int T = c.i_max + 1;
-        const size_t need = std::max(reg_fwd_smem(T), reg_bwd_smem(T));
+        h->reg8 = T <= kTile;                  // 512-thread kernels (cf_reg8.h); CF_REG8=0 selects the 256-thread ones (A/B runs)
+        if (const char* e = getenv("CF_REG8")) h->reg8 = h->reg8 && atoi(e) != 0;
+        const size_t need = h->reg8 ? std::max(reg8_fwd_smem(c.reg_dff), reg8_bwd_smem(c.reg_dff)) : std::max(reg_fwd_smem(T), reg_bwd_smem(T));
         h->reg_fused = T <= kTile && need <= 160 * 1024;
         if (h->reg_fused) {
-            hipError_t e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, T), hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_fwd_smem(T));
-            hipError_t e2 = hipFuncSetAttribute(reg_kernel(true, c.reg_dff, T), hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_bwd_smem(T));
-            hipError_t e3 = hipSuccess, e4 = hipSuccess;
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) h->reg_fused = false;
+            const size_t sf = h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), sb = h->reg8 ? reg8_bwd_smem(c.reg_dff) : reg_bwd_smem(T);
+            hipError_t e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, T, h->reg8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
+            if (h->reg8 && e1 == hipSuccess)
+                e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, T, true, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
+            hipError_t e2 = hipFuncSetAttribute(reg_kernel(true, c.reg_dff, T, h->reg8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb);
+            if (e1 != hipSuccess || e2 != hipSuccess) h->reg_fused = false;
         }
+        if (!h->reg_fused) h->reg8 = false;
     }
     {   // gene-batched attention kernel when its LDS image (8 regions of features + 16 score rows) fits
         size_t need = 0;
@@ -758,6 +793,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
     if (h->reg_tab) (void)hipFree(h->reg_tab);
     if (h->tiled) (void)hipFree(h->tiled);
+    if (h->tiledT) (void)hipFree(h->tiledT);
     if (h->retile_units) (void)hipFree(h->retile_units);
     for (cf_handle::Replay& rp : h->replays) {
         if (rp.first) (void)hipGraphExecDestroy(rp.first);
@@ -867,7 +903,7 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
         h->cap.has_hole = true;
         h->cap.hole.func = fn;
         h->cap.hole.grid = grid;
-        h->cap.hole.block = dim3(256);
+        h->cap.hole.block = dim3(h->reg8 ? 512 : 256);
         h->cap.hole.smem = smem;
         h->cap.hole.args = ra;
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
@@ -875,7 +911,7 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
     }
     void* kargs[] = {&ra};
     h->time_mark(name, st);
-    HIP_TRY(hipLaunchKernel(fn, grid, dim3(256), kargs, smem, st));
+    HIP_TRY(hipLaunchKernel(fn, grid, dim3(h->reg8 ? 512 : 256), kargs, smem, st));
     h->time_mark(name, st);
     LAUNCH_CHECK(name);
     return 0;
@@ -894,7 +930,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
     CentreParams ep[kMaxRes], pp[kMaxRes];
     for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
     // refresh the tiled weight copy (the parameters may have been changed by anyone since the last call)
-    hipLaunchKernelGGL(k_retile, dim3(h->n_retile), dim3(256), 0, st, (const float*)h->params, h->tiled, (const RetileUnit*)h->retile_units);
+    hipLaunchKernelGGL(k_retile, dim3(h->n_retile), dim3(256), 0, st, (const float*)h->params, h->tiled, h->reg8 ? h->tiledT : (float*)nullptr,
+                       (const RetileUnit*)h->retile_units);
     LAUNCH_CHECK("k_retile");
 
     {   // Embedding centre-row input
@@ -1068,7 +1105,9 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         ra.freq = bt->interaction_freq;
         ra.save = save;
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T), dim3(8 * ((B * nres + 7) / 8)), reg_fwd_smem(T), ra, st)) return -1;
+        if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T, h->reg8, save != 0), dim3(8 * ((B * nres + 7) / 8)),
+                       h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), ra, st))
+            return -1;
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
         LinArgs la;
@@ -1199,7 +1238,9 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         ra.freq = bt->interaction_freq;
         ra.save = 1;
         ra.tdbg = getenv("CF_STAMP_BWD") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
-        if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T), dim3(8 * ((B * nres + 7) / 8)), reg_bwd_smem(T), ra, st)) return -1;
+        if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T, h->reg8), dim3(8 * ((B * nres + 7) / 8)),
+                       h->reg8 ? reg8_bwd_smem(c.reg_dff) : reg_bwd_smem(T), ra, st))
+            return -1;
     }
     for (int l = ((h->reg_fused || !(parts & 2)) ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback
         PostBwdArgs pb;
@@ -1683,13 +1724,13 @@ extern "C" int cf_op_linear(const float* A, const float* W, const float* bias, f
     if (K % 128 || N % 32) return fail("cf_op_linear: K %% 128 == 0 and N %% 32 == 0 required");
     // standalone use: build the tiled copy of W on the fly (test / micro-benchmark helper, synchronous)
     std::vector<RetileUnit> units;
-    for (int n0 = 0; n0 < N; n0 += 16) units.push_back(RetileUnit{(long long)n0 * K, K});
+    for (int n0 = 0; n0 < N; n0 += 16) units.push_back(RetileUnit{(long long)n0 * K, 0, K, N, n0, 0});
     float* Wt = nullptr;
     RetileUnit* du = nullptr;
     HIP_TRY(hipMalloc(&Wt, (size_t)N * K * sizeof(float)));
     HIP_TRY(hipMalloc(&du, units.size() * sizeof(RetileUnit)));
     HIP_TRY(hipMemcpy(du, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_retile, dim3((int)units.size()), dim3(256), 0, (hipStream_t)stream, W, Wt, (const RetileUnit*)du);
+    hipLaunchKernelGGL(k_retile, dim3((int)units.size()), dim3(256), 0, (hipStream_t)stream, W, Wt, (float*)nullptr, (const RetileUnit*)du);
     LinArgs a;
     memset(&a, 0, sizeof a);
     a.x[0] = A;
@@ -1898,14 +1939,14 @@ static int dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const floa
     std::vector<RetileUnit> units;
     int first[6] = {0};
     for (int j = 0; j < 5; ++j) {
-        for (int n0 = 0; n0 < jobs[j].rows; n0 += 16) units.push_back(RetileUnit{(long long)n0 * jobs[j].K, jobs[j].K});
+        for (int n0 = 0; n0 < jobs[j].rows; n0 += 16) units.push_back(RetileUnit{(long long)n0 * jobs[j].K, 0, jobs[j].K, jobs[j].rows, n0, 0});
         first[j + 1] = (int)units.size();
     }
     if (units.size() * sizeof(RetileUnit) > kDenseTab * sizeof(float)) return fail("cf_op_dense_layer_fwd: unit table overflow");
     HIP_TRY(hipMemcpyAsync(units_d, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));      // `units` is a host temporary
     for (int j = 0; j < 5; ++j) {
-        hipLaunchKernelGGL(k_retile, dim3(first[j + 1] - first[j]), dim3(256), 0, st, jobs[j].src, jobs[j].dst,
+        hipLaunchKernelGGL(k_retile, dim3(first[j + 1] - first[j]), dim3(256), 0, st, jobs[j].src, jobs[j].dst, (float*)nullptr,
                            (const RetileUnit*)(units_d + first[j]));
         LAUNCH_CHECK("k_retile<dense layer>");
     }

@@ -1458,12 +1458,13 @@ __global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs
         if (fh * 4 + k < j.F) out[fh * 4 + k] = acc[k];
 }
 
-// Deferred column sums (bias / LayerNorm / gamma gradients): out[c] = sum_m src[m][c]
+// Deferred column sums (bias / LayerNorm / gamma gradients): out[c] = sum_m src[m][c] (* src2[m][c])
 struct CsTile {
     const float* src;
     float* out;
     int ld, ncols, c0;
     int rows_per_gene, div;      // M = ceil(rows_per_gene * batch / div)
+    const float* src2;           // optional elementwise factor (same leading dimension): LayerNorm weight gradients
 };
 __global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles, int batch) {
     __shared__ float red[4][64];
@@ -1471,8 +1472,17 @@ __global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles
     const int M = (t.rows_per_gene * batch + t.div - 1) / t.div;
     const int c = t.c0 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     float s = 0.f;
-    if (c < t.ncols)
-        for (int m = ph; m < M; m += 4) s += t.src[(size_t)m * t.ld + c];
+    if (c < t.ncols) {
+        const float* p1 = t.src + c;
+        if (t.src2) {
+            const float* p2 = t.src2 + c;
+#pragma unroll 8
+            for (int m = ph; m < M; m += 4) s += ldg(p1 + (size_t)m * t.ld) * ldg(p2 + (size_t)m * t.ld);
+        } else {
+#pragma unroll 8
+            for (int m = ph; m < M; m += 4) s += ldg(p1 + (size_t)m * t.ld);
+        }
+    }
     red[ph][threadIdx.x & 63] = s;
     __syncthreads();
     if (ph == 0 && c < t.ncols) t.out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -1544,25 +1554,46 @@ __global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const 
 }
 
 // =======================================================================================
-// Tiled copy of the Linear weights for the forward ("NT") products -- see FragNT.
-// One workgroup per 16-row unit of a tensor.
+// Tiled copies of the Linear weights -- see FragNT.  One workgroup per 16-row unit of a tensor W[N][K]:
+//   tiled:  block (n / 16, k / 16) at (n/16 * K/16 + k/16) * 256, element [q][r][m] = W[n0 + r][k0 + 4q + m]
+//           (B operand of the forward products  y = x W^T)
+//   tiledT: the same tiling of W^T[K][N]: block (k / 16, n / 16) at (k/16 * N/16 + n/16) * 256, element
+//           [q][r][m] = W[n0 + 4q + m][k0 + r]   (B operand of the backward products  dx = dy W; Regulation only)
 // =======================================================================================
 struct RetileUnit {
     long long off;     // float offset of the unit's first row in the flat parameter buffer
-    int K;             // row length of the tensor
+    long long toff;    // float offset of the tensor
+    int K, N, n0, tr;  // row length, rows of the tensor, first row of the unit, emit the transposed tiling too
 };
-__global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params, float* __restrict__ tiled,
+__global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
                                                 const RetileUnit* __restrict__ units) {
+    __shared__ __attribute__((aligned(16))) float tp[4][16][20];
     const RetileUnit u = units[blockIdx.x];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* src = params + u.off + (size_t)r * u.K + q * 4;
     float* dst = tiled + u.off + lane * 4;
-    for (int kt = w; kt < u.K / 16; kt += 4)
-        *reinterpret_cast<float4*>(dst + (size_t)kt * 256) = *reinterpret_cast<const float4*>(src + kt * 16);
+    const bool tr = u.tr && tiledT;
+    float* dstT = tiledT + u.toff + (size_t)(u.n0 / 16) * 256 + lane * 4;
+    for (int kt = w; kt < u.K / 16; kt += 4) {
+        const float4 vv = ldg4(src + kt * 16);
+        stg4(dst + (size_t)kt * 256, vv);
+        if (tr) {      // 16 x 16 transpose through a wave-private LDS patch (LDS operations of a wave execute in order)
+            *reinterpret_cast<float4*>(&tp[w][r][q * 4]) = vv;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 o = make_float4(tp[w][q * 4][r], tp[w][q * 4 + 1][r], tp[w][q * 4 + 2][r], tp[w][q * 4 + 3][r]);
+            stg4(dstT + (size_t)kt * (u.N / 16) * 256, o);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
 }
 }  // namespace cf
 
 #include "cf_reg_fused.h"
+#include "cf_reg8.h"
 #include "cf_attc2.h"
 #include "cf_head.h"
 #include "cf_attn.h"

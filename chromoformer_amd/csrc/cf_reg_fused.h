@@ -12,8 +12,10 @@ namespace cf {
 struct RegLayerDev {
     const float *watt, *gamma, *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
     const float *watt_t, *wo_t, *w1_t, *w2_t;      // tiled copies (forward products)
+    const float *watt_tt, *wo_tt, *w1_tt, *w2_tt;  // tiled copies of the transposes (backward products of cf_reg8.h)
     float *xin, *qkvg, *p, *a, *xh1, *rs1, *y1, *hdn, *xh2, *rs2, *xout;
     float *dxout, *dt2, *dpre1, *dt1, *da, *dqkvg, *dxin, *partial, *dgam;
+    float *hq, *dy1;                               // cf_reg8.h: per-(gene, head) attention operands; d(LayerNorm 1 output)
 };
 struct RegArgs {
     const RegLayerDev* tab;          // [n_res][n_layers]

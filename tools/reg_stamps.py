@@ -13,6 +13,17 @@ for _ in range(3):
     m.forward_backward(packed, torch.zeros(B, dtype=torch.long))
 torch.cuda.synchronize()
 t = m.debug_buffer("reg_tdbg").cpu().numpy().view(np.uint64)[: 16 * 6].reshape(6, 16).astype(np.int64)
+import ctypes
+if os.environ.get("CF_REG8", "1") != "0":      # 512-thread kernels (cf_reg8.h)
+    if BWD:
+        names = ["start", "ln2 bwd", "dpre1 (W2)", "dy1 (W1)", "ln1 bwd", "da (Wo) + attention", "dgrad K=1024"]
+    else:
+        names = ["start", "q|k|v|g", "attention", "barrier", "Wo+res", "LN1", "W1", "W2", "LN2"]
+    n = len(names)
+    for l in range(6):
+        d = np.diff(t[l, :n])
+        print("layer %d total %6d cyc: " % (l, t[l, n - 1] - t[l, 0]) + "  ".join("%s %d" % (names[i + 1], d[i]) for i in range(n - 1)))
+    sys.exit(0)
 if BWD:
     names = ["start", "ln2 prep", "ln2 bwd", "dpre1 (W2)", "dy1 (W1)", "ln1 bwd", "da (Wo)+loads", "barrier", "gate/do", "dp", "softmax bwd", "dq dk dv", "dgrad K=1024"]
     for l in range(6):
