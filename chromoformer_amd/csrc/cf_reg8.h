@@ -14,7 +14,8 @@
 //     the two long products (K = 128 x 4 chunks forward, K = 1024 backward) run an 8-unit ring 7 units ahead.
 //   * what the backward needs of the attention is saved per (gene, head) in the layouts its operands want: q^T, k^T,
 //     gate^T as [32][16] tiles (= the forward's accumulator registers, one float4 per lane), v as [16][32] rows, p^T
-//     as a [16][16] tile.
+//     as a [16][16] tile.  Only row quarters that hold a token are written (the arena is zero-filled once): the forward
+//     is sensitive to its store volume -- 37 MB more per launch cost 10 us (measured: 3.7 TB/s at the margin).
 //   * bias / LayerNorm gradients are column sums of arrays the weight-gradient launch needs anyway (dt2, dpre1, dt1,
 //     dy1, d(layer output)): k_colsum takes them from there, nothing is reduced inside this kernel.
 //
@@ -22,7 +23,7 @@
 // 121-124 (layer stack).  Six workgroup barriers per layer and direction.
 #pragma once
 #ifndef CF_QPRE
-#define CF_QPRE 5
+#define CF_QPRE 7
 #endif
 
 namespace cf {
@@ -116,11 +117,21 @@ __device__ __forceinline__ void b_issue(BBuf<NU, R>& b, const float* base, unsig
     }
     __builtin_amdgcn_sched_barrier(0);
 }
+template <int NU, int R, class IDX>
+__device__ __forceinline__ void b_issue1(BBuf<NU, R>& b, const float* base, unsigned vb, IDX idx, int u) {      // u: compile-time after unrolling
+    b.s[u % R][0] = ldg_blk(base, vb, idx(u, 0));
+    b.s[u % R][1] = ldg_blk(base, vb, idx(u, 1));
+}
 // TWO = true: a unit is one 16-deep k-block of two column tiles (acc[0], acc[1] = the two tiles);
 // TWO = false: two consecutive k-blocks of one column tile (acc[0] + acc[1] (+ acc[2] + acc[3]) = the tile).
-// Units [0, PRE) were requested by the caller; ap = A tile + r * lda + 4 q.
-template <int PRE, bool TWO, int NACC, int NU, int R, class IDX>
-__device__ __forceinline__ void b_run(BBuf<NU, R>& b, const float* base, unsigned vb, IDX idx, const float* ap, f32x4 (&acc)[NACC]) {
+// Units [0, PRE) were requested by the caller; ap = A tile + r * lda + 4 q.  co(u) runs before the MFMAs of unit u: the
+// requests of the NEXT product's operand stream are spread over this product's units (a burst of 16 one-KB loads per wave
+// keeps the CU's 64 B/clk load path -- and every wave queued behind it -- busy for 2 K cycles).
+struct NoCo {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int PRE, bool TWO, int NACC, int NU, int R, class IDX, class CO = NoCo>
+__device__ __forceinline__ void b_run(BBuf<NU, R>& b, const float* base, unsigned vb, IDX idx, const float* ap, f32x4 (&acc)[NACC], CO co = CO()) {
     static_assert(PRE <= R && (PRE == NU || PRE < R), "ring too small for the prefetch distance");
     float4 a0n = lds4(ap), a1n = TWO ? a0n : lds4(ap + 16);
 #pragma unroll
@@ -129,6 +140,7 @@ __device__ __forceinline__ void b_run(BBuf<NU, R>& b, const float* base, unsigne
             b.s[(u + PRE) % R][0] = ldg_blk(base, vb, idx(u + PRE, 0));
             b.s[(u + PRE) % R][1] = ldg_blk(base, vb, idx(u + PRE, 1));
         }
+        co(u);
         __builtin_amdgcn_sched_barrier(0);      // keep the request ahead of this unit's MFMAs (the scheduler would sink it)
         const float4 a0 = a0n, a1 = TWO ? a0n : a1n;
         if (u + 1 < NU) {
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         float* hg = P.hdn + row0 * DFF + w * HW;
         // ---- q | k | v | gate of head w: 4 chunks x (2 tiles x K = 128), one ring over all 32 units
         f32x4 vacc[2], gacc[2];
+        BBuf<8, 8> bwo;
         {
             const float* qb = P.watt_t + wq;
             const float* ap = xs + oALD;
@@ -258,6 +271,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                     rq.s[(u + kQPre) % 8][0] = ldg_blk(qb, wl, qidx(u + kQPre, 0));
                     rq.s[(u + kQPre) % 8][1] = ldg_blk(qb, wl, qidx(u + kQPre, 1));
                 }
+                if (u >= 24) b_issue1(bwo, P.wo_t + wo16, wl, idx_one, u - 24);      // out-projection weights, spread over the gate chunk
                 __builtin_amdgcn_sched_barrier(0);
                 if ((u & 7) == 0) zero_acc(acc);
                 const float4 av = an;
@@ -271,29 +285,31 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                         for (int t = 0; t < 2; ++t) {
 #pragma unroll
                             for (int ii = 0; ii < 4; ++ii) dst[ii * 36 + t * 16] = acc[t][ii];
-                            if (SAVE) stg4(lane_at(sbase(hq, (c == 0 ? kHqQ : kHqK) + t * 256), bT), acc4(acc[t]));
+                            float* tp_ = lane_at(sbase(hq, (c == 0 ? kHqQ : kHqK) + t * 256), bT);      // (scalar bases are formed outside the conditionals)
+                            if (SAVE && rok[0]) stg4(tp_, acc4(acc[t]));
                         }
                     } else if (c == 2) {    // v: stays in registers (B operand of p v); rows to global for the backward
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             vacc[t] = acc[t];
                             if (SAVE) {
+                                float* vp_ = lane_at(sbase(hq, kHqV), bV);
 #pragma unroll
-                                for (int ii = 0; ii < 4; ++ii) stg(lane_at(sbase(hq, kHqV), bV) + ii * 32 + t * 16, acc[t][ii]);
+                                for (int ii = 0; ii < 4; ++ii)
+                                    if (rok[ii]) stg(vp_ + ii * 32 + t * 16, acc[t][ii]);
                             }
                         }
                     } else {                // gate
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             gacc[t] = acc[t];
-                            if (SAVE) stg4(lane_at(sbase(hq, kHqG + t * 256), bT), acc4(acc[t]));
+                            float* tp_ = lane_at(sbase(hq, kHqG + t * 256), bT);
+                            if (SAVE && rok[0]) stg4(tp_, acc4(acc[t]));
                         }
                     }
                 }
             }
         }
-        BBuf<8, 8> bwo;       // out-projection weights: in flight during the attention
-        b_issue<0, 8>(bwo, P.wo_t + wo16, wl, idx_one);
         CF_STAMP8(1);
         // ---- attention of head w (modules.py:58-81), wave-local
         wave_lds_sync();
@@ -308,27 +324,31 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                 if (mkv[ii]) sv = kMaskFill;
                 if (lr >= T) sv = -INFINITY;
                 const float m = group16_max(sv);
-                const float e = lr < T ? expf(sv - m) : 0.f;
+                const float e = lr < T ? __expf(sv - m) : 0.f;      // v_exp_f32: 1 ulp; the logits keep two orders of headroom to 1e-4
                 const float z = group16_sum(e);
-                p[ii] = rok[ii] ? e / z : 0.f;
+                p[ii] = rok[ii] ? e * __builtin_amdgcn_rcpf(z) : 0.f;
                 ps[oD20 + ii * 20] = p[ii];
             }
-            if (SAVE) stg4(lane_at(sbase(hq, kHqP), bT), make_float4(p[0], p[1], p[2], p[3]));      // p^T tile
+            float* pp_ = lane_at(sbase(hq, kHqP), bT);
+            if (SAVE && rok[0] && lr < T) stg4(pp_, make_float4(p[0], p[1], p[2], p[3]));      // p^T tile
             wave_lds_sync();
             const float4 pa = lds4(ps + oA20);      // A[i = lr][j = 4 lq + m]; B[j = 4 lq + m][d] = the v accumulators
             f32x4 o[2];
             zero_acc(o);
             mma_unit(pa, pa, acc4(vacc[0]), acc4(vacc[1]), o[0], o[1]);
+            float* ap_ = lane_at(sbase(ag, 0), zA);      // (scalar bases are formed outside the per-row conditionals)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
+                float val[4];
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    const float val = o[t][ii] * fast_sigmoid(gacc[t][ii]);
+                    val[ii] = o[t][ii] * fast_sigmoid(gacc[t][ii]);
                     if (rok[ii]) {
-                        as_[oDLW + ii * LW + t * 16] = val;
-                        if (SAVE) stg(lane_at(sbase(ag, 0), zA) + ii * kRDm + t * 16, val);
+                        as_[oDLW + ii * LW + t * 16] = val[ii];
+                        if (SAVE) stg(ap_ + ii * kRDm + t * 16, val[ii]);
                     }
                 }
+            }
         }
         LnParams ln1, ln2;
         if (w < 4) ln1 = ln_params_load(P.g1, P.be1);
@@ -338,13 +358,16 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         CF_STAMP8(3);
         // ---- out-projection + residual, LayerNorm
         {
-            if (DFF == 256)
-                b_issue<0, NU1>(bw1, P.w1_t + w1o, wl, idx_two);
-            else
-                b_issue<0, NU1>(bw1, P.w1_t + w1o, wl, idx_one);
             f32x4 acc[2];
             zero_acc(acc);
-            b_run<8, false, 2>(bwo, P.wo_t + wo16, wl, idx_one, as_ + oALW, acc);
+            b_run<8, false, 2>(bwo, P.wo_t + wo16, wl, idx_one, as_ + oALW, acc, [&](int u) {      // FFN weights 1, one unit per unit
+                if (u < NU1) {
+                    if (DFF == 256)
+                        b_issue1(bw1, P.w1_t + w1o, wl, idx_two, u);
+                    else
+                        b_issue1(bw1, P.w1_t + w1o, wl, idx_one, u);
+                }
+            });
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) ts[oDLD + ii * LD] = (acc[0][ii] + acc[1][ii]) + bov + xs[oDLD + ii * LD];
         }
@@ -355,38 +378,50 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         __syncthreads();
         // ---- FFN (modules.py:100-101)
         BBuf<NU2, NU2> bw2;
-        b_issue<0, NU2>(bw2, P.w2_t + w2o, wl, idx_one);
+        const auto co_w2 = [&](int u) {
+            if (u < NU2) b_issue1(bw2, P.w2_t + w2o, wl, idx_one, u);
+        };
         {
             f32x4 acc[2];
             zero_acc(acc);
             if (DFF == 256) {
-                b_run<NU1, true, 2>(bw1, P.w1_t + w1o, wl, idx_two, ts + oALD, acc);
+                b_run<NU1, true, 2>(bw1, P.w1_t + w1o, wl, idx_two, ts + oALD, acc, co_w2);
+                float* hp = lane_at(sbase(hg, 0), zH);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
+                    float hv[4];
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
-                        const float hv = fmaxf(acc[t][ii] + b1v[t], 0.f);
-                        hs[oDLH + ii * LH + t * 16] = hv;
-                        if (SAVE && rok[ii]) stg(lane_at(sbase(hg, 0), zH) + ii * DFF + t * 16, hv);
+                        hv[ii] = fmaxf(acc[t][ii] + b1v[t], 0.f);
+                        hs[oDLH + ii * LH + t * 16] = hv[ii];
+                        if (SAVE && rok[ii]) stg(hp + ii * DFF + t * 16, hv[ii]);
                     }
+                }
             } else {
-                b_run<NU1, false, 2>(bw1, P.w1_t + w1o, wl, idx_one, ts + oALD, acc);
+                b_run<NU1, false, 2>(bw1, P.w1_t + w1o, wl, idx_one, ts + oALD, acc, co_w2);
+                if (NU2 > NU1) b_issue<NU1, NU2>(bw2, P.w2_t + w2o, wl, idx_one);
+                float* hp = lane_at(sbase(hg, 0), zH);
+                float hv[4];
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    const float hv = fmaxf((acc[0][ii] + acc[1][ii]) + b1v[0], 0.f);
-                    hs[oDLH + ii * LH] = hv;
-                    if (SAVE && rok[ii]) stg(lane_at(sbase(hg, 0), zH) + ii * DFF, hv);
+                    hv[ii] = fmaxf((acc[0][ii] + acc[1][ii]) + b1v[0], 0.f);
+                    hs[oDLH + ii * LH] = hv[ii];
+                    if (SAVE && rok[ii]) stg(hp + ii * DFF, hv[ii]);
                 }
             }
         }
         if (w < 4) ln2 = ln_params_load(P.g2, P.be2);
         CF_STAMP8(6);
         __syncthreads();
-        if (l + 1 < a.n_layers) b_issue<0, kQPre>(rq, load_layer(tab + l + 1).watt_t + wq, wl, qidx);      // next layer's projection
         {
             f32x4 acc[2];
             zero_acc(acc);
-            b_run<NU2, false, 2>(bw2, P.w2_t + w2o, wl, idx_one, hs + oALH, acc);
+            const bool more = l + 1 < a.n_layers;
+            const float* nq = load_layer(tab + (more ? l + 1 : l)).watt_t + wq;
+            b_run<NU2, false, 2>(bw2, P.w2_t + w2o, wl, idx_one, hs + oALH, acc, [&](int u) {      // next layer's projection ring
+                if (u < kQPre && more) b_issue1(rq, nq, wl, qidx, u);
+            });
+            if (kQPre > NU2 && more) b_issue<NU2, kQPre>(rq, nq, wl, qidx);
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) xs[oDLD + ii * LD] = (acc[0][ii] + acc[1][ii]) + b2v + ts[oDLD + ii * LD];
         }
@@ -441,6 +476,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
     bool rok[4];
     float fqv[4];
     bool mkv[4];
+    unsigned zAc[4], zHc[4];      // byte offsets of the lane's rows of a / hdn, clamped into the gene's rows (branch-free loads)
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
         const int i = lq * 4 + ii;
@@ -448,65 +484,80 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         const bool in = i < T && lr < T;
         fqv[ii] = in ? ldg(a.freq + (size_t)g * TT + i * T + lr) : 0.f;
         mkv[ii] = in ? *(const CF_GLOBAL uint8_t*)(a.mask[r] + (size_t)g * TT + i * T + lr) != 0 : true;      // outside the block: no gradient
+        zAc[ii] = (min(i, T - 1) * kRDm + lr) * 4;
+        zHc[ii] = (min(i, T - 1) * DFF + lr) * 4;
     }
     const auto idx_two = [](int u, int j) { return j * 8 + u; };
     const auto idx_one = [](int u, int j) { return 2 * u + j; };
     const int lrow = (w & 3) * 4 + lq;               // LayerNorm row of this lane (waves 0..3)
     const bool llive = w < 4 && lrow < T;
     const unsigned bL = (lrow * kD + lr * 8) * 4, bR = lrow * 4;      // LayerNorm lane: 8 columns of row lrow
+    // operands of a layer's first phase (LayerNorm 2 backward on waves 0..3, the W2^T stream for everybody), requested one
+    // phase ahead: during the input-gradient product of the layer above, or here for the top layer
+    BBuf<NUA, NUA> bA;
+    float4 l2ga = f4z(), l2gb = f4z(), l2x0 = f4z(), l2x1 = f4z();
+    float l2rs = 0.f;
+    auto request_stream = [&](const RegLayerDev& Q) {
+        if (DFF == 256)
+            b_issue<0, NUA>(bA, Q.w2_tt + wAo, wl, idx_two);
+        else
+            b_issue<0, NUA>(bA, Q.w2_tt + wAo, wl, idx_one);
+    };
+    auto request_ln2 = [&](const RegLayerDev& Q) {
+        if (w < 4) {
+            l2ga = ldg4(lane_at(Q.g2, lr * 32));
+            l2gb = ldg4(lane_at(Q.g2, lr * 32) + 4);
+            const float* xp = lane_at(sbase(Q.xh2, row0 * kD), bL);
+            const float* rp = lane_at(sbase(Q.rs2, row0), bR);
+            if (llive) {
+                l2x0 = ldg4(xp);
+                l2x1 = ldg4(xp + 4);
+                l2rs = ldg(rp);
+            }
+        }
+    };
+    request_ln2(load_layer(tab + a.n_layers - 1));
     __syncthreads();
     for (int l = a.n_layers - 1; l >= 0; --l) {
         const RegLayerDev P = load_layer(tab + l);
         CF_STAMP8(0);
-        // ---- LayerNorm 2 backward (waves 0..3, operands straight from global); everybody requests the W2^T stream
-        BBuf<NUA, NUA> bA;
-        if (DFF == 256)
-            b_issue<0, NUA>(bA, P.w2_tt + wAo, wl, idx_two);
-        else
-            b_issue<0, NUA>(bA, P.w2_tt + wAo, wl, idx_one);
-        const float* hg = P.hdn + row0 * DFF + w * HW;
-        float hm[2][4];      // FFN hidden of this lane's outputs (ReLU mask)
+        // ---- LayerNorm 2 backward (waves 0..3) first, then everybody's requests for the next phase
+        if (w < 4) ln_bwd_tile16_r(ds, t2, LD, l2x0, l2x1, l2ga, l2gb, l2rs, llive, lane_at(sbase(P.dt2, row0 * kD), bL));
+        request_stream(P);
+        float hm[2][4];      // FFN hidden of this lane's outputs (ReLU mask of the next phase); rows >= T read row T - 1 (their gradient is zero)
 #pragma unroll
         for (int t = 0; t < (DFF == 256 ? 2 : 1); ++t)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) hm[t][ii] = rok[ii] ? ldg(lane_at(sbase(hg, 0), zH) + ii * DFF + t * 16) : 0.f;
-        if (w < 4) {
-            const float4 ga = ldg4(lane_at(P.g2, lr * 32)), gb = ldg4(lane_at(P.g2, lr * 32) + 4);
-            float4 x0 = f4z(), x1 = f4z();
-            float rs = 0.f;
-            if (llive) {
-                x0 = ldg4(lane_at(sbase(P.xh2, row0 * kD), bL));
-                x1 = ldg4(lane_at(sbase(P.xh2, row0 * kD), bL) + 4);
-                rs = ldg(lane_at(sbase(P.rs2, row0), bR));
-            }
-            ln_bwd_tile16_r(ds, t2, LD, x0, x1, ga, gb, rs, llive, lane_at(sbase(P.dt2, row0 * kD), bL));
-        }
+            for (int ii = 0; ii < 4; ++ii) hm[t][ii] = ldg(lane_at(sbase(P.hdn, row0 * DFF + w * HW), zHc[ii]) + t * 16);
         CF_STAMP8(1);
         __syncthreads();
         // ---- dpre1 = (dt2 W2) . relu'
         BBuf<NUB, NUB> bB;
-        b_issue<0, NUB>(bB, P.w1_tt + wBo, wl, idx_one);
-        float* dpg = P.dpre1 + row0 * DFF + w * HW;
+        const auto co_B = [&](int u) {
+            if (u < NUB) b_issue1(bB, P.w1_tt + wBo, wl, idx_one, u);
+        };
+        float* dpp = lane_at(sbase(P.dpre1, row0 * DFF + w * HW), zH);
         {
             f32x4 acc[2];
             zero_acc(acc);
             if (DFF == 256) {
-                b_run<NUA, true, 2>(bA, P.w2_tt + wAo, wl, idx_two, t2 + oALD, acc);
+                b_run<NUA, true, 2>(bA, P.w2_tt + wAo, wl, idx_two, t2 + oALD, acc, co_B);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         const float vv = hm[t][ii] > 0.f ? acc[t][ii] : 0.f;
                         wide[oDLH + ii * LH + t * 16] = vv;
-                        if (rok[ii]) stg(lane_at(sbase(dpg, 0), zH) + ii * DFF + t * 16, vv);
+                        if (rok[ii]) stg(dpp + ii * DFF + t * 16, vv);
                     }
+                }
             } else {
-                b_run<NUA, false, 2>(bA, P.w2_tt + wAo, wl, idx_one, t2 + oALD, acc);
+                b_run<NUA, false, 2>(bA, P.w2_tt + wAo, wl, idx_one, t2 + oALD, acc, co_B);
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const float vv = hm[0][ii] > 0.f ? acc[0][ii] + acc[1][ii] : 0.f;
                     wide[oDLH + ii * LH] = vv;
-                    if (rok[ii]) stg(lane_at(sbase(dpg, 0), zH) + ii * DFF, vv);
+                    if (rok[ii]) stg(dpp + ii * DFF, vv);
                 }
             }
         }
@@ -514,7 +565,6 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         __syncthreads();
         // ---- dy1 = dpre1 W1 + dt2
         BBuf<8, 8> bC;
-        b_issue<0, 8>(bC, P.wo_tt + wCo, wl, idx_two);
         float4 l1ga = f4z(), l1gb = f4z(), l1x0 = f4z(), l1x1 = f4z();
         float l1rs = 0.f;
         if (w < 4) {
@@ -529,7 +579,8 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         {
             f32x4 acc[2];
             zero_acc(acc);
-            b_run<NUB, false, 2>(bB, P.w1_tt + wBo, wl, idx_one, wide + oALH, acc);
+            b_run<NUB, false, 2>(bB, P.w1_tt + wBo, wl, idx_one, wide + oALH, acc, [&](int u) { b_issue1(bC, P.wo_tt + wCo, wl, idx_two, u); });
+            if (NUB < 8) b_issue<NUB, 8>(bC, P.wo_tt + wCo, wl, idx_two);
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const float vv = (acc[0][ii] + acc[1][ii]) + t2[oDLD + ii * LD];
@@ -539,7 +590,8 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         }
         CF_STAMP8(3);
         __syncthreads();
-        // ---- LayerNorm 1 backward (in place); everybody requests the operands of its head's attention backward
+        // ---- LayerNorm 1 backward (in place, waves 0..3) first; then everybody requests the operands of its head's attention backward
+        if (w < 4) ln_bwd_tile16_r(ds, ds, LD, l1x0, l1x1, l1ga, l1gb, l1rs, llive, lane_at(sbase(P.dt1, row0 * kD), bL));
         float4 gT[2], kT[2], qT[2], vr[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -549,12 +601,11 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             vr[t] = ldg4(lane_at(sbase(P.hq, hq0 + kHqV), bVr) + t * 16);
         }
         const float4 pT = ldg4(lane_at(sbase(P.hq, hq0 + kHqP), bT));      // lane (j = lr, lq): p[4 lq + ii][j]
-        float av[2][4];
+        float av[2][4];      // gated attention output of the head (forward); rows >= T read row T - 1
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) av[t][ii] = rok[ii] ? ldg(lane_at(sbase(P.a, row0 * kRDm + w * 32), zA) + ii * kRDm + t * 16) : 0.f;
-        if (w < 4) ln_bwd_tile16_r(ds, ds, LD, l1x0, l1x1, l1ga, l1gb, l1rs, llive, lane_at(sbase(P.dt1, row0 * kD), bL));
+            for (int ii = 0; ii < 4; ++ii) av[t][ii] = ldg(lane_at(sbase(P.a, row0 * kRDm + w * 32), zAc[ii]) + t * 16);
         CF_STAMP8(4);
         __syncthreads();
         // ---- da = dt1 Wo (the 32 columns of head w), then the attention backward of the head, wave-local
@@ -562,8 +613,9 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         {
             f32x4 da[2];
             zero_acc(da);
-            b_run<8, true, 2>(bC, P.wo_tt + wCo, wl, idx_two, ds + oALD, da);
-            b_issue<0, 7>(bD, P.watt_tt + wDo, wl, idx_one);
+            b_run<8, true, 2>(bC, P.wo_tt + wCo, wl, idx_two, ds + oALD, da, [&](int u) {
+                if (u < 7) b_issue1(bD, P.watt_tt + wDo, wl, idx_one, u);
+            });
             float* dg = P.dqkvg + row0 * kRW + w * 32;
             f32x4 dov[2];      // do = da . sigmoid(gate): D layout = B operand of dv
 #pragma unroll
@@ -627,10 +679,12 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         CF_STAMP8(5);
         __syncthreads();
         // ---- d(layer input) = dt1 + d(q|k|v|gate) Watt   (K = 1024: 32 units, four accumulators)
+        if (l > 0) request_ln2(load_layer(tab + l - 1));
         {
             f32x4 acc[4];
             zero_acc(acc);
             b_run<7, false, 4>(bD, P.watt_tt + wDo, wl, idx_one, dqk + oAQ, acc);
+
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const float vv = ((acc[0][ii] + acc[1][ii]) + (acc[2][ii] + acc[3][ii])) + ds[oDLD + ii * LD];
