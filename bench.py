@@ -70,6 +70,36 @@ def cpu_baseline(budget_s=15.0):
                       "(host: %d logical CPUs, %s), warm-up %.1f s" % (n, b, el, cores, os.cpu_count() or 0, cpu, warm)}
 
 
+def train_loop_rate(model, lr, steps, store_genes, regime, dev):
+    """Steady-state genes/s of the SHIPPED training loop (chromoformer_amd.train.train_epoch: epoch permutation, in-graph
+    batch gather from a resident split, step, AdamW, lagged metric windows with the reference's sklearn metrics every
+    tenth step) over a synthetic resident store -- what `python -m chromoformer_amd.train` runs between validations."""
+    from chromoformer_amd.engine import EpochFeed, Trainer
+    from chromoformer_amd.synth import synthetic_store
+    from chromoformer_amd.train import _report_train, epoch_permutation, train_epoch
+    from chromoformer_amd.data import shard_indices
+    store = synthetic_store(store_genes, dev, seed=4321, regime=regime)
+    trainer = Trainer(model, lr=lr)
+    feed = EpochFeed(model, store, BSZ)
+    quiet = lambda *a, **k: None
+    wb = type("W", (), {"log": staticmethod(quiet)})
+    report = lambda lo, la, ls: _report_train(quiet, wb, 1, float(ls.mean().item()), trainer.lr, lo, la, False)
+    torch.manual_seed(7)
+    train_epoch(trainer, feed, shard_indices(epoch_permutation(len(store)), 0, 1, BSZ)[:30], report)      # warm-up (captures the graph)
+    torch.cuda.synchronize()
+    done, t0 = 0, time.perf_counter()
+    while done < steps:
+        batches = shard_indices(epoch_permutation(len(store)), 0, 1, BSZ)[: steps - done]
+        train_epoch(trainer, feed, batches, report)
+        done += len(batches)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": round(BSZ * done / el, 1), "unit": "genes/s", "ms_per_step": round(1e3 * el / done, 4), "steps": done,
+            "store_genes": store_genes, "host_calls_per_step": 2,
+            "what": "chromoformer_amd.train.train_epoch over a resident synthetic split: cf_gather_batch + cf_record_step inside "
+                    "the step graph, running metrics (train.py:205-232) on every 10-step window"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +108,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regime", default="dense", choices=["dense", "realistic"])
+    ap.add_argument("--train-loop-steps", type=int, default=2000, help="steps of the shipped training loop timed for the `train_loop` key (0 = skip)")
+    ap.add_argument("--train-loop-genes", type=int, default=16384, help="genes in the synthetic resident split of the `train_loop` leg")
     ap.add_argument("--roofline-kernel", default="k_reg_bwd", help="kernel timed with HIP events: k_reg_bwd (dominant), k_reg_fwd (needs --no-graph), k_wgrad, k_adamw")
     args = ap.parse_args()
 
@@ -147,6 +179,8 @@ def main():
             "roofline": roof,
             "loss": round(float(trainer.last_loss()), 6),
         }
+        if world == 1 and args.train_loop_steps > 0:
+            out["train_loop"] = train_loop_rate(model, 3e-5, args.train_loop_steps, args.train_loop_genes, args.regime, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -59,6 +59,15 @@ class cf_batch(C.Structure):
     ]
 
 
+class cf_store(C.Structure):
+    _fields_ = [
+        ("n_genes", C.c_longlong),
+        ("promoter_feats", C.c_void_p * MAX_RES), ("pcre_feats", C.c_void_p * MAX_RES),
+        ("promoter_mask", C.c_void_p * MAX_RES), ("pcre_mask", C.c_void_p * MAX_RES),
+        ("interaction_mask", C.c_void_p), ("interaction_freq", C.c_void_p), ("labels", C.c_void_p),
+    ]
+
+
 #: every symbol include/chromoformer_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "cf_abi_version": (C.c_int, []),
@@ -94,6 +103,8 @@ SYMBOLS = {
     "cf_op_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_bin_regions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cf_gather_batch": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
+    "cf_record_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_op_dense_layer_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "cf_op_dense_layer_fwd": (C.c_int, [C.POINTER(cf_dense_layer)] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 3),
     "cf_op_dense_layer_train_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1718,6 +1718,63 @@ extern "C" int cf_launch_counts(cf_handle* h, int* fwd, int* bwd, int* opt) {
 }
 
 // ------------------------------------------------------------------------------------
+// resident split: batch gather / step log inside the graph
+// ------------------------------------------------------------------------------------
+extern "C" int cf_gather_batch(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst,
+                               void* stream) {
+    if (!h || !st_ || !order || !cursor || !dst) return fail("cf_gather_batch: null argument");
+    const cf_config& c = h->cfg;
+    const int B = dst->B, S = c.i_max, T = S + 1, F = c.n_feats;
+    if (B < 1 || B > c.max_batch) return fail("cf_gather_batch: B = %d outside [1, max_batch = %d]", B, c.max_batch);
+    GatherArgs ga;
+    memset(&ga, 0, sizeof ga);
+    int n = 0;
+    bool overflow = false;
+    auto push = [&](const void* src, const void* d, long long gene_bytes) {
+        const int chunk = kGatherChunk;
+        for (long long off = 0; off < gene_bytes; off += chunk) {
+            if (n >= kGatherMaxSeg) {
+                overflow = true;
+                return;
+            }
+            ga.seg[n++] = GatherSeg{(const char*)src, (char*)const_cast<void*>(d), (int)gene_bytes, (int)off, (int)std::min<long long>(chunk, gene_bytes - off), 0};
+        }
+    };
+    for (int r = 0; r < c.n_res; ++r) {
+        const long long L = c.n_bins[r];
+        if (dst->promoter_mask_stride[r] != L || dst->pcre_mask_stride[r] != L)
+            return fail("cf_gather_batch: the destination batch must use compact mask rows (stride = n_bins)");
+        push(st_->promoter_feats[r], dst->promoter_feats[r], L * F * 4);
+        push(st_->pcre_feats[r], dst->pcre_feats[r], (long long)S * L * F * 4);
+        push(st_->promoter_mask[r], dst->promoter_mask_row[r], L);
+        push(st_->pcre_mask[r], dst->pcre_mask_row[r], (long long)S * L);
+        push(st_->interaction_mask, dst->interaction_mask[r], (long long)T * T);
+    }
+    push(st_->interaction_freq, dst->interaction_freq, (long long)T * T * 4);
+    if (labels_dst) push(st_->labels, labels_dst, c.n_out == 1 ? 4 : 8);
+    if (overflow) return fail("cf_gather_batch: segment table overflow");
+    ga.order = order;
+    ga.cursor = cursor;
+    ga.B = B;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gather_batch, dim3(B, n), dim3(256), 0, st, ga);
+    LAUNCH_CHECK("k_gather_batch");
+    hipLaunchKernelGGL(k_gather_advance, dim3(1), dim3(1), 0, st, cursor);
+    LAUNCH_CHECK("k_gather_advance");
+    return 0;
+}
+
+extern "C" int cf_record_step(cf_handle* h, const int* cursor, const float* logits, const void* labels, const float* loss, int B,
+                              float* logits_log, void* labels_log, float* loss_log, void* stream) {
+    if (!h || !cursor || !logits || !labels || !loss || !logits_log || !labels_log || !loss_log) return fail("cf_record_step: null argument");
+    RecordArgs ra{cursor, logits, (const char*)labels, loss, logits_log, (char*)labels_log, loss_log, B, h->cfg.n_out, h->cfg.n_out == 1 ? 4 : 8};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_record_step, dim3(1), dim3(256), 0, st, ra);
+    LAUNCH_CHECK("k_record_step");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // standalone operators
 // ------------------------------------------------------------------------------------
 extern "C" int cf_op_linear(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int relu, void* stream) {

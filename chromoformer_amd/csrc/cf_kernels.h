@@ -1598,3 +1598,4 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
 #include "cf_head.h"
 #include "cf_attn.h"
 #include "cf_bin.h"
+#include "cf_gather.h"

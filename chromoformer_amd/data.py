@@ -259,8 +259,37 @@ class GeneStore:
             self.pf, self.cf, self.pm, self.cm = ([host(t) for t in x] for x in (pf, cf, pm, cm))
         self.device = dev if resident else None
 
+    @classmethod
+    def from_arrays(cls, binsizes, i_max, pf, cf, pm, cm, im, freq, label, regression=False):
+        """A store around arrays that are already binned and resident (compact layout of `_bin_on_device`): per
+        resolution pf [n,1,L,F], cf [n,S,L,F], pm [n,L], cm [n,S,L] (uint8, 1 = padding); im [n,T,T] uint8, freq
+        [n,T,T], label [n].  Used by the benchmark's synthetic split and by the packed-store loader."""
+        self = cls.__new__(cls)
+        self.binsizes, self.i_max, self.regression = list(binsizes), i_max, regression
+        self.n_bins = [t.shape[2] for t in pf]
+        self.n = int(freq.shape[0])
+        self.pf, self.cf, self.pm, self.cm, self.im, self.freq, self.label = pf, cf, pm, cm, im, freq, label
+        self.device = freq.device if freq.is_cuda else None
+        return self
+
     def __len__(self):
         return self.n
+
+    def struct(self):
+        """cf_store view of a device-resident store (include/chromoformer_hip.h), for cf_gather_batch."""
+        from . import _lib
+        if getattr(self, "device", None) is None:
+            raise RuntimeError("GeneStore.struct(): the store is not resident on a device")
+        st = _lib.cf_store()
+        st.n_genes = self.n
+        for r in range(len(self.binsizes)):
+            for t in (self.pf[r], self.cf[r], self.pm[r], self.cm[r]):
+                if not t.is_contiguous():
+                    raise RuntimeError("GeneStore arrays must be contiguous")
+            st.promoter_feats[r], st.pcre_feats[r] = self.pf[r].data_ptr(), self.cf[r].data_ptr()
+            st.promoter_mask[r], st.pcre_mask[r] = self.pm[r].data_ptr(), self.cm[r].data_ptr()
+        st.interaction_mask, st.interaction_freq, st.labels = self.im.data_ptr(), self.freq.data_ptr(), self.label.data_ptr()
+        return st
 
     def batch(self, idx):
         """Gather genes `idx` into a batch dict the device Slot understands (compact masks)."""

@@ -88,6 +88,51 @@ class Slot:
         return self
 
 
+class EpochFeed:
+    """The batches of an epoch taken from a device-resident GeneStore INSIDE the step graph (cf_gather_batch): the gene
+    order of the epoch is uploaded once, a device-side cursor walks it, and every step's logits / labels / loss are
+    appended to per-epoch logs (cf_record_step).  A training step is then two host calls -- graph replay and AdamW --
+    instead of the reference's DataLoader round trip plus per-tensor .cuda() copies (train.py:137-140, 171-177)."""
+
+    def __init__(self, model, store, bsz, max_batches=None):
+        dev = model._device
+        self.model, self.store, self.B = model, store, bsz
+        self.slot = Slot(model, bsz)
+        self.slot.feed = self
+        self.cap = max_batches or (len(store) // bsz + 1)
+        self.order = torch.zeros(self.cap * bsz, dtype=torch.int32, device=dev)
+        self.cursor = torch.zeros(2, dtype=torch.int32, device=dev)          # [next batch, arrival counter of the gather launch]
+        # the step logs live in pinned HOST memory (device-addressable): cf_record_step writes a KB per step straight into
+        # it, the loop reads it once an event says the window is complete -- no device-to-host copy, which would queue
+        # behind the replayed graphs (1.6 ms per copy on a busy GPU)
+        self.logits_log = torch.zeros(self.cap, bsz, model.n_out).pin_memory()
+        self.labels_log = torch.zeros(self.cap, bsz, dtype=self.slot.label.dtype).pin_memory()
+        self.loss_log = torch.zeros(self.cap).pin_memory()
+        self.struct = store.struct()
+        self.n_batches = 0
+        torch.cuda.current_stream(dev).synchronize()      # the fills above ran on the current stream (see Slot)
+
+    def begin_epoch(self, batches, stream):
+        """Upload the epoch's batches (equal-length lists of gene indices) and rewind the cursor, ordered on `stream`."""
+        if len(batches) > self.cap:
+            raise ValueError("epoch of %d batches exceeds the feed's capacity %d" % (len(batches), self.cap))
+        if any(len(b) != self.B for b in batches):
+            raise ValueError("every batch of an EpochFeed epoch must hold exactly %d genes" % self.B)
+        flat = torch.tensor([int(i) for b in batches for i in b], dtype=torch.int32)
+        self._hold = flat = flat.pin_memory() if flat.numel() else flat
+        with torch.cuda.stream(stream):
+            if flat.numel():
+                self.order[: flat.numel()].copy_(flat, non_blocking=True)
+            self.cursor.zero_()
+        self.n_batches = len(batches)
+
+    def window(self, lo, hi):
+        """(logits [n, n_out], labels [n], losses [hi - lo]) of steps lo .. hi - 1 of the epoch, on the host (the caller has
+        made sure those steps are complete)."""
+        return (self.logits_log[lo:hi].reshape(-1, self.model.n_out).clone(), self.labels_log[lo:hi].reshape(-1).clone(),
+                self.loss_log[lo:hi].clone())
+
+
 class Trainer:
     """One optimisation step = forward, loss, backward, gradient reductions, [all-reduce], AdamW.
 
@@ -148,10 +193,18 @@ class Trainer:
     def _reduce(self, slot, st, buckets):
         _lib.check(self._L.cf_backward_reduce_part(self.model._handle, slot.B, buckets, st), "cf_backward_reduce_part")
 
-    def _seq_early(self, slot, st):     # forward, loss, head + Regulation backward, Regulation + head gradient bucket
+    def _seq_early(self, slot, st):     # [batch gather,] forward, loss, head + Regulation backward, [step log,] Regulation + head gradient bucket
         m, L = self.model, self._L
+        feed = getattr(slot, "feed", None)
+        if feed is not None:
+            _lib.check(L.cf_gather_batch(m._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
+                                         C.byref(slot.struct), slot.label.data_ptr(), st), "cf_gather_batch")
         _lib.check(L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 1, st), "cf_forward")
         self._part(slot, st, 3)
+        if feed is not None:
+            _lib.check(L.cf_record_step(m._handle, feed.cursor.data_ptr(), slot.logits.data_ptr(), slot.label.data_ptr(),
+                                        slot.loss.data_ptr(), slot.B, feed.logits_log.data_ptr(), feed.labels_log.data_ptr(),
+                                        feed.loss_log.data_ptr(), st), "cf_record_step")
         self._reduce(slot, st, _lib.BUCKET_REG)
 
     def _seq_late(self, slot, st):      # Pairwise + Embedding backward and their gradient bucket
@@ -204,6 +257,8 @@ class Trainer:
         st = self._stream()
         if self.use_graph and slot.graph is None:
             self._seq_all(slot, st, opt=False)         # eager once (validates the arguments before anything is captured)
+            if getattr(slot, "feed", None) is not None:
+                slot.feed.cursor.zero_()               # the validation pass consumed a batch: rewind (no parameter was updated)
             torch.cuda.synchronize()
             first = self._seq_early if self.dp else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph))
             slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}

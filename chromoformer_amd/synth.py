@@ -59,3 +59,52 @@ def synthetic_batch(B, seed=1234, regime="dense", regression=False, *, n_feats=7
     else:
         batch["label"] = torch.from_numpy(rng.integers(0, 2, size=B).astype(np.int64))
     return batch
+
+
+def synthetic_store(n_genes, device, seed=1234, regime="dense", regression=False, *, n_feats=7, i_max=8, binsizes=(2000, 500, 100),
+                    w_max=40000, chunk=2048):
+    """A resident GeneStore of `n_genes` synthetic genes drawn ON the device (same distributions as synthetic_batch, torch's
+    generator instead of numpy's: 16,384 genes are 2 GB of features, too slow to draw on the host for a benchmark)."""
+    from .data import GeneStore
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    S, T, G = i_max, i_max + 1, n_genes
+    rnd = lambda *shape: torch.rand(*shape, device=device, generator=gen)
+    if regime == "dense":
+        n_part = torch.full((G,), S, device=device, dtype=torch.long)
+    else:
+        hist = torch.tensor(_DEMO_PARTNER_HIST if S == 8 else [1.0] * (S + 1), dtype=torch.float32, device=device)
+        n_part = torch.multinomial(hist / hist.sum(), G, replacement=True, generator=gen)
+    lens = torch.exp(math.log(5900.0) + 0.5 * torch.randn(G, S, device=device, generator=gen)).clamp(1800, w_max)
+    has = torch.arange(S, device=device)[None, :] < n_part[:, None]
+    pf, cf, pm, cm = [], [], [], []
+    for b in binsizes:
+        L = w_max // b
+
+        def draw(shape):
+            out = torch.empty(shape, device=device)
+            for g0 in range(0, shape[0], chunk):
+                sl = out[g0:g0 + chunk]
+                x = torch.log1p(torch._standard_gamma(torch.full(sl.shape, 0.6, device=device), generator=gen))
+                if L >= 400:
+                    x[rnd(*sl.shape) < 0.35] = 0.0
+                sl.copy_(x)
+            return out
+
+        n = torch.full((G, S), L, device=device, dtype=torch.long) if regime == "dense" else torch.ceil(lens / b).long()
+        lo = torch.ceil((L - n).float() / 2).long()
+        j = torch.arange(L, device=device)[None, None, :]
+        valid = has[:, :, None] & (j >= lo[:, :, None]) & (j < (lo + n)[:, :, None])
+        c = draw((G, S, L, n_feats))
+        c *= valid[..., None]
+        pf.append(draw((G, 1, L, n_feats)))
+        cf.append(c)
+        pm.append(torch.zeros(G, L, dtype=torch.uint8, device=device))
+        cm.append((~valid).to(torch.uint8).contiguous())
+    q = torch.arange(T, device=device)
+    im = (~((q[None, :, None] <= n_part[:, None, None]) & (q[None, None, :] <= n_part[:, None, None]))).to(torch.uint8).contiguous()
+    freq = torch.zeros(G, T, T, device=device)
+    sc = torch.sort(1.5 + 1.5 * rnd(G, S), dim=1, descending=True).values * has
+    freq[:, 0, 1:] = sc
+    label = (4.0 * rnd(G)) if regression else (rnd(G) < 0.5).long()
+    return GeneStore.from_arrays(binsizes, i_max, pf, cf, pm, cm, im, freq, label, regression=regression)

@@ -256,6 +256,33 @@ typedef struct cf_bin_job {
 } cf_bin_job;
 int cf_bin_regions(const cf_bin_job* jobs, int n_jobs, int n_feats, int bin_size, int n_bins_out, void* stream);
 
+/* ---- resident split, batch gather inside the step graph --------------------------------- */
+/* The binned genes of a split, resident in HBM (what chromoformer_amd.data.GeneStore builds with cf_bin_regions):
+ * the arrays of cf_batch with a leading gene dimension, pad masks as compact centre rows, one interaction mask per
+ * gene (it is the same at every resolution, data.py:200-203). */
+typedef struct cf_store {
+    long long n_genes;
+    const float*   promoter_feats[CF_MAX_RES];      /* [n,1,L,F]                       */
+    const float*   pcre_feats[CF_MAX_RES];          /* [n,S,L,F]                       */
+    const uint8_t* promoter_mask[CF_MAX_RES];       /* [n,L]    centre query row       */
+    const uint8_t* pcre_mask[CF_MAX_RES];           /* [n,S,L]  centre query row       */
+    const uint8_t* interaction_mask;                /* [n,T,T]                         */
+    const float*   interaction_freq;                /* [n,T,T]                         */
+    const void*    labels;                          /* int64 [n] (n_out = 2) or float [n] */
+} cf_store;
+/* The DataLoader and the per-tensor .cuda() copies of a step (train.py:137-140, 171-177) as ONE capturable launch:
+ * copies genes order[cursor[0] * B ... + B) of `store` into the batch buffers `dst` (which must use compact mask
+ * rows, stride L, and are written despite the const in cf_batch) and their labels into labels_dst, then advances
+ * cursor[0] (a second, one-thread launch).  `order` (int32, batch-major) and `cursor` (int32[2], second word
+ * reserved; zero it whenever a new order is uploaded) are device memory: a replayed graph walks the epoch without
+ * any host involvement. */
+int cf_gather_batch(cf_handle* h, const cf_store* store, const int* order, int* cursor, const cf_batch* dst,
+                    void* labels_dst, void* stream);
+/* Appends the step's logits [B, n_out], labels [B] and loss to per-epoch device logs at row cursor[0] - 1 (capturable;
+ * what the loop's running metrics, train.py:198-232, read every tenth step instead of cloning tensors every step). */
+int cf_record_step(cf_handle* h, const int* cursor, const float* logits, const void* labels, const float* loss, int B,
+                   float* logits_log, void* labels_log, float* loss_log, void* stream);
+
 /* Dense attention core with ALL query rows (MultiHeadAttention._attention, modules.py:58-77;
  * PairwiseMultiHeadAttention, modules.py:170-188), head width 64:
  *     O = softmax(masked_fill(Q K^T / sqrt(64), mask, -1e9)) V        per (sequence n, head h)

@@ -1,0 +1,68 @@
+"""cf_gather_batch / cf_record_step (the batch gather and the step log inside the graph) and the training loop built on them."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_genes=300, bsz=8, regime="realistic"):
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import EpochFeed, Trainer
+    from chromoformer_amd.synth import synthetic_store
+    dev = torch.device("cuda", 0)
+    model = ChromoformerClassifier(seed=42, max_batch=bsz).cuda(0)
+    store = synthetic_store(n_genes, dev, seed=5, regime=regime)
+    trainer = Trainer(model, lr=3e-5)
+    return model, store, trainer, EpochFeed(model, store, bsz)
+
+
+def test_gather_walks_the_epoch_order_bit_exactly():
+    import ctypes as C
+    from chromoformer_amd import _lib
+    model, store, trainer, feed = _setup()
+    rng = np.random.default_rng(0)
+    batches = [rng.choice(len(store), size=8, replace=False).tolist() for _ in range(5)]
+    feed.begin_epoch(batches, trainer.stream)
+    L, slot = _lib.lib(), feed.slot
+    for k, idx in enumerate(batches):
+        with torch.cuda.stream(trainer.stream):
+            _lib.check(L.cf_gather_batch(model._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
+                                         C.byref(slot.struct), slot.label.data_ptr(), trainer.stream.cuda_stream), "cf_gather_batch")
+        trainer.stream.synchronize()
+        assert feed.cursor.tolist() == [k + 1, 0]
+        ii = torch.tensor(idx, device=store.freq.device)
+        for r in range(3):
+            assert torch.equal(slot.pf[r], store.pf[r][ii]) and torch.equal(slot.cf[r], store.cf[r][ii])
+            assert torch.equal(slot.pm[r], store.pm[r][ii]) and torch.equal(slot.cm[r], store.cm[r][ii])
+            assert torch.equal(slot.im[r], store.im[ii])
+        assert torch.equal(slot.freq, store.freq[ii]) and torch.equal(slot.label, store.label[ii])
+
+
+def test_feed_steps_equal_staged_steps_and_log_every_step():
+    """Training through the feed (gather + record inside the graph) is bit-identical to staging the same batches by hand."""
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    from chromoformer_amd.train import train_epoch
+    model, store, trainer, feed = _setup()
+    rng = np.random.default_rng(1)
+    batches = [rng.choice(len(store), size=8, replace=False).tolist() for _ in range(12)]
+    windows = []
+    train_epoch(trainer, feed, batches, lambda lo, la, ls: windows.append((lo.clone(), la.clone(), ls.clone())), every=5)
+    torch.cuda.synchronize()
+    ref = ChromoformerClassifier(seed=42, max_batch=8).cuda(0)
+    tr2 = Trainer(ref, lr=3e-5)
+    logits, losses = [], []
+    for idx in batches:
+        slot = tr2.stage(store.batch(idx))
+        lo, ls = tr2.step(slot)
+        tr2.stream.synchronize()
+        logits.append(lo.cpu().clone())
+        losses.append(ls.cpu().clone())
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ref.state_dict()[k]), k
+    assert len(windows) == 2 and windows[0][0].shape == (40, 2)
+    assert torch.equal(torch.cat([w[0] for w in windows]), torch.cat(logits[:10]))
+    assert torch.equal(torch.cat([w[2] for w in windows]), torch.cat(losses[:10]))
+    want = torch.cat([store.label[torch.tensor(b, device=store.label.device)].cpu() for b in batches[:10]])
+    assert torch.equal(torch.cat([w[1] for w in windows]), want)
