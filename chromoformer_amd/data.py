@@ -243,6 +243,14 @@ class GeneStore:
             chrom, tss, strand = g["tss"]
             regions = [(-1, strand != "+", ds._load(chrom, tss - 20000, tss + 20000))] + [(s, False, ds._load(*p)) for s, p in enumerate(g["pcres"])]
             for s, flip, a in regions:
+                if a.dtype != np.float16:
+                    # the reference widens whatever dtype the file has (data.py:104); the device path ships fp16, which is
+                    # what preprocessing writes (extract_signals.py:66-71) -- refuse a lossy narrowing instead of training on inf
+                    h = a.astype(np.float16)
+                    if not np.array_equal(h.astype(a.dtype), a):
+                        raise ValueError("raw signal file is %s and does not fit float16 exactly: bin it on the host "
+                                         "(GeneStore(device=None)) or re-save it as float16" % a.dtype)
+                    a = h
                 a = np.ascontiguousarray(a, dtype=np.float16)
                 if a.shape[0] != F:
                     raise ValueError("expected %d feature rows, file has %d" % (F, a.shape[0]))

@@ -321,3 +321,52 @@ class ChromoformerClassifier(ChromoformerBase):
 
 class ChromoformerRegressor(ChromoformerBase):
     n_out = 1
+
+
+_LEGACY_PREFIX = (("embed.", "embed"), ("pairwise_interaction.", "pw_int"), ("regulation.", "reg"))
+
+
+class Chromoformer(ChromoformerClassifier):
+    """The reference's original class (net.py:156-270): flat constructor arguments, a 16-positional-argument ``forward``
+    (five tensors per resolution 2000 / 500 / 100, then the interaction frequencies) and modules named ``embed2000``,
+    ``pw_int2000``, ``reg2000`` ... in its ``state_dict``.  Same construction order, so the same seed gives the same
+    weights as ChromoformerClassifier (the reference's own smoke block checks that equality, net.py:431-568)."""
+
+    def __init__(self, n_feats=7, embed_n_layers=1, embed_n_heads=2, embed_d_model=128, embed_d_ff=128, pw_int_n_layers=2,
+                 pw_int_n_heads=2, pw_int_d_model=128, pw_int_d_ff=256, reg_n_layers=6, reg_n_heads=8, reg_d_model=256,
+                 reg_d_ff=256, head_n_feats=128, seed=42, **kwargs):
+        super().__init__(n_feats, embed_d_model, head_n_feats,
+                         dict(n_layers=embed_n_layers, n_heads=embed_n_heads, d_model=embed_d_model, d_ff=embed_d_ff),
+                         dict(n_layers=pw_int_n_layers, n_heads=pw_int_n_heads, d_model=pw_int_d_model, d_ff=pw_int_d_ff),
+                         dict(n_layers=reg_n_layers, n_heads=reg_n_heads, d_model=reg_d_model, d_ff=reg_d_ff),
+                         binsizes=(2000, 500, 100), seed=seed, **kwargs)
+
+    def forward(self, x_p_2000, pad_mask_p_2000, x_pcre_2000, pad_mask_pcre_2000, interaction_mask_2000,
+                x_p_500, pad_mask_p_500, x_pcre_500, pad_mask_pcre_500, interaction_mask_500,
+                x_p_100, pad_mask_p_100, x_pcre_100, pad_mask_pcre_100, interaction_mask_100, interaction_freq):
+        return super().forward({2000: x_p_2000, 500: x_p_500, 100: x_p_100},
+                               {2000: pad_mask_p_2000, 500: pad_mask_p_500, 100: pad_mask_p_100},
+                               {2000: x_pcre_2000, 500: x_pcre_500, 100: x_pcre_100},
+                               {2000: pad_mask_pcre_2000, 500: pad_mask_pcre_500, 100: pad_mask_pcre_100},
+                               {2000: interaction_mask_2000, 500: interaction_mask_500, 100: interaction_mask_100}, interaction_freq)
+
+    @staticmethod
+    def _legacy_key(k):
+        for new, old in _LEGACY_PREFIX:
+            if k.startswith(new):
+                return old + k[len(new):]
+        return k
+
+    @staticmethod
+    def _current_key(k):
+        for new, old in _LEGACY_PREFIX:
+            if k.startswith(old) and k[len(old):len(old) + 1].isdigit():
+                return new + k[len(old):]
+        return k
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        return type(sd)((self._legacy_key(k), v) for k, v in sd.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        return super().load_state_dict(type(state_dict)((self._current_key(k), v) for k, v in state_dict.items()), strict=strict)

@@ -67,7 +67,9 @@ def predict(meta_path, npy_dir, weights=None, regression=False, bsz=32, seed=123
     preds = []
     for s in range(0, len(store), bsz):
         idx = list(range(s, min(s + bsz, len(store))))
-        slot = slots.setdefault(len(idx), Slot(model, len(idx)))
+        slot = slots.get(len(idx))
+        if slot is None:
+            slot = slots[len(idx)] = Slot(model, len(idx))
         trainer.stage(store.batch(idx), slot)
         with torch.cuda.stream(trainer.stream):
             out = trainer.evaluate(slot).clone()

@@ -6,8 +6,11 @@ GPUs of a node is 44 jobs, 5-6 per GPU.
     python -m chromoformer_amd.sweep --meta-template data/{eid}/train.csv --npy-dir-template data/{eid}/npy \\
         --config configs/default.yaml --eids E003 E004 ... --folds 1 2 3 4 --gpus 8 [--regression] [--conf 1]
 
-Checkpoints go to `ckpts/{eid}/{exp_id}-{eid}-conf{conf}-fold{fold}.pt` (Snakefile:25,50,58); jobs whose checkpoint
-exists are skipped, so an interrupted sweep resumes.  `--fold` values are the Snakefile's 1..4; train.py's own fold
+Checkpoints go to `ckpts/{eid}/{exp_id}-{eid}-conf{conf}-fold{fold}.pt` (Snakefile:25,50,58).  A job counts as finished
+only when train.py has written its `<checkpoint>.done` marker after the last epoch (train.py rewrites the checkpoint
+every epoch, so the file alone proves nothing -- Snakemake deletes incomplete outputs, this is the equivalent); finished
+jobs are skipped, so an interrupted sweep resumes and crashed or killed jobs are run again.  A job that exits non-zero
+has its marker and checkpoint removed.  `--fold` values are the Snakefile's 1..4; train.py's own fold
 argument is 0-based modulo 4 (train.py:99-105), so fold f is passed as f % 4 -- the same validation quarter."""
 from __future__ import annotations
 
@@ -36,8 +39,9 @@ def command(eid, fold, ckpt, args):
 def run(jobs, args, launch=subprocess.Popen):
     """Greedy list scheduling: a GPU takes the next pending job as soon as its previous one exits.
     -> {checkpoint: return code}"""
-    pending = [j for j in jobs if not os.path.exists(j[2])]
-    done = {j[2]: 0 for j in jobs if os.path.exists(j[2])}
+    finished = lambda ckpt: os.path.exists(ckpt) and os.path.exists(ckpt + ".done")
+    pending = [j for j in jobs if not finished(j[2])]
+    done = {j[2]: 0 for j in jobs if finished(j[2])}
     running = {}                                    # gpu -> (process, checkpoint)
     while pending or running:
         for gpu in range(args.gpus):
@@ -51,6 +55,12 @@ def run(jobs, args, launch=subprocess.Popen):
         for gpu, (p, ckpt) in list(running.items()):
             rc = p.poll()
             if rc is not None:
+                if rc == 0 and not finished(ckpt):
+                    rc = -1                         # exited cleanly without reaching its last epoch
+                if rc != 0:
+                    for path in (ckpt, ckpt + ".done", ckpt + ".tmp"):
+                        if os.path.exists(path):
+                            os.remove(path)
                 done[ckpt] = rc
                 del running[gpu]
                 print("[sweep] gpu %d done rc=%d %s" % (gpu, rc, ckpt), flush=True)

@@ -63,13 +63,16 @@ def epoch_permutation(n):
     return torch.randperm(n, generator=g).tolist()
 
 
-def optimizer_state_dict(model, lr):
+def optimizer_state_dict(model, lr, initial_lr=None):
     """torch.optim.AdamW.state_dict() layout: entries only for parameters that ever had a gradient,
     `step` as a 0-dim float32 tensor (train.py:325, 336)."""
     named = list(model.named_parameters())
     ref = torch.optim.AdamW([nn.Parameter(torch.zeros(1)) for _ in named], lr=float(lr))
     sd = ref.state_dict()
     sd["param_groups"][0]["lr"] = float(lr)
+    # the reference's optimizer has a StepLR attached (train.py:157-158), which adds this key to the group: a consumer that
+    # loads the state and rebuilds the scheduler with last_epoch >= 0 needs it
+    sd["param_groups"][0]["initial_lr"] = float(initial_lr if initial_lr is not None else lr)
     state = {}
     if model._step > 0:
         for i, e in enumerate(model._table):
@@ -189,10 +192,16 @@ def main(argv=None):
         if rank == 0:
             torch.cuda.synchronize()
             ckpt["net"] = type(model.state_dict())((k, v.detach().cpu().clone()) for k, v in model.state_dict().items())
-            ckpt["optimizer"] = optimizer_state_dict(model, trainer.lr)
-            torch.save(ckpt, args.output)
+            ckpt["optimizer"] = optimizer_state_dict(model, trainer.lr, float(config["lr"]))
+            # written to a temporary name and renamed: a job killed mid-write never leaves a truncated file under the final
+            # name (torch.save is not atomic); `<output>.done` marks a run that reached its last epoch (what the sweep checks)
+            torch.save(ckpt, args.output + ".tmp")
+            os.replace(args.output + ".tmp", args.output)
         trainer.scheduler_step()
 
+    if rank == 0:
+        with open(args.output + ".done", "w") as f:
+            f.write("epochs %d\n" % max(0, num_epoch - 1))
     if val_loss is not None:
         key = "last_val_r2" if args.regression else "last_val_auc"
         wandb.summary.update({"last_val_loss": val_loss, key: ckpt[key]})

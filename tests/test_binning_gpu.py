@@ -46,3 +46,36 @@ def test_oversized_region_is_an_error_on_the_device_path_too(tmp_path):
     ds = ChromoformerDataset(meta, str(tmp_path / "npy"), genes, w_prom=4000, w_max=4000)      # promoters fit, most pCREs (median 5.9 kb) do not
     with pytest.raises(ValueError):
         GeneStore(ds, device="cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w_prom", [40000, 10000])
+def test_kernel_against_the_reference_items_of_golden_g5(tmp_path, w_prom):
+    """cf_bin_regions fed with the raw regions of tests/golden/dataset.npz against the tensors the REFERENCE's
+    ChromoformerDataset.__getitem__ produced from them (data.py:68-113, 124-212): '+' and '-' strand promoters, the narrowed
+    window, partial last bins (1,833 / 2,001 / 12,345 samples), a 100-sample and a 40-kb pCRE, a gene without partners."""
+    import os
+    from chromoformer_amd.data import ChromoformerDataset, GeneStore
+    from tests.helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "dataset.npz"))
+    d = tmp_path / "npy"
+    d.mkdir()
+    for k in z.files:
+        if k.startswith("raw."):
+            np.save(str(d / (k[4:] + ".npy")), z[k])
+    meta = str(d / "meta.csv")
+    open(meta, "w").write(str(z["meta_csv"]))
+    genes = pd.read_csv(meta).gene_id.tolist()
+    ds = ChromoformerDataset(meta, str(d), genes, w_prom=w_prom)
+    store = GeneStore(ds, device="cuda:0", resident=True)
+    for i, gene in enumerate(genes):
+        tag = "item.clf.w%d.%s" % (w_prom, gene)
+        for r, b in enumerate((2000, 500, 100)):
+            L = 40000 // b
+            assert np.abs(store.pf[r][i].cpu().numpy() - z["%s.promoter_feats.%d" % (tag, b)]).max() < 2e-6, (gene, b)
+            assert np.abs(store.cf[r][i].cpu().numpy() - z["%s.pcre_feats.%d" % (tag, b)]).max() < 2e-6, (gene, b)
+            assert np.array_equal(store.pm[r][i].cpu().numpy().astype(bool), z["%s.promoter_pad_masks.%d" % (tag, b)][0, 0, L // 2]), (gene, b)
+            assert np.array_equal(store.cm[r][i].cpu().numpy().astype(bool), z["%s.pcre_pad_masks.%d" % (tag, b)][:, 0, L // 2]), (gene, b)
+            assert np.array_equal(store.im[i].cpu().numpy().astype(bool), z["%s.interaction_masks.%d" % (tag, b)][0]), (gene, b)
+        assert np.allclose(store.freq[i].cpu().numpy(), z["%s.interaction_freq" % tag], atol=1e-6)
+        assert int(store.label[i]) == int(z["%s.label" % tag])

@@ -81,6 +81,28 @@ def test_g2_known_answers_fully_masked():
         assert abs(float(out.sum()) - (-0.1900 if reg else -3.1917)) < 1e-3    # net.py:558-568
 
 
+def test_legacy_class_equals_classifier():
+    """net.py:156-270 / the smoke block net.py:431-568: `Chromoformer()` (16 positional arguments, embed2000 / pw_int2000 /
+    reg2000 module names) and ChromoformerClassifier give the same output for the same seed."""
+    from chromoformer_amd import Chromoformer
+    batch, ex = load_npz_batch("kat.npz")
+    legacy = Chromoformer(seed=42, max_batch=16).cuda(0)
+    args = []
+    for b in (2000, 500, 100):
+        args += [batch["promoter_feats"][b], batch["promoter_pad_masks"][b], batch["pcre_feats"][b], batch["pcre_pad_masks"][b],
+                 batch["interaction_masks"][b]]
+    with torch.no_grad():
+        out = legacy(*args, batch["interaction_freq"]).cpu()
+    assert np.abs(out.numpy() - ex["logits_clf"]).max() < LOGIT_TOL and abs(float(out.sum()) - (-3.1917)) < 1e-3
+    sd = legacy.state_dict()
+    keys = list(sd)
+    assert keys[0] == "embed2000.lin_proj.weight" and "pw_int500.lin_proj_p.weight" in sd and "reg100.transformer.layers.5.ff.l2.bias" in sd
+    clf = _model(seed=7)
+    legacy.load_state_dict(type(sd)((k, v) for k, v in zip(keys, clf.state_dict().values())))
+    with torch.no_grad():
+        assert torch.equal(legacy(*args, batch["interaction_freq"]), _call(clf, batch))
+
+
 def test_compact_mask_rows_equal_full_masks():
     batch = orc.synthetic_batch(4, seed=9, regime="realistic")
     model = _model()

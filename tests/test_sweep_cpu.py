@@ -13,8 +13,12 @@ class _Proc:
         self.polls += 1
         if self.polls < 2:
             return None
-        open(self.cmd[self.cmd.index("-o") + 1], "w").write("ckpt")          # the training wrote its checkpoint
-        return 0
+        ckpt = self.cmd[self.cmd.index("-o") + 1]
+        open(ckpt, "w").write("ckpt")                                        # the training wrote its checkpoint ...
+        if not getattr(self, "crash", False):
+            open(ckpt + ".done", "w").write("epochs 9\n")                    # ... and reached its last epoch
+            return 0
+        return 1
 
 
 def test_plan_commands_and_gpu_assignment(tmp_path):
@@ -37,3 +41,29 @@ def test_plan_commands_and_gpu_assignment(tmp_path):
     # resume: everything exists now, nothing is launched again
     started.clear()
     assert sweep.run(jobs, args, launch=launch) == done and not started
+
+
+def test_unfinished_and_failed_jobs_are_run_again(tmp_path):
+    """A checkpoint without its `.done` marker (killed after an early epoch) is not a finished job; a job that exits
+    non-zero leaves nothing behind that a later sweep could mistake for a result (chromoformer/Snakefile semantics:
+    Snakemake removes incomplete outputs)."""
+    jobs = sweep.plan(["E003"], ["1", "2"], "exp", "1", str(tmp_path / "ckpts"))
+    args = argparse.Namespace(config="c.yaml", exp_id="exp", meta_template="d/{eid}/train.csv", npy_dir_template="d/{eid}/npy",
+                              binsizes=None, regression=False, gpus=2, poll=0.0)
+    os.makedirs(os.path.dirname(jobs[0][2]))
+    open(jobs[0][2], "w").write("partial: epoch 1 of 9")                     # left by a killed run
+    started = []
+
+    def launch(cmd, env, stdout, stderr):
+        p = _Proc(cmd, env, stdout)
+        p.crash = cmd[cmd.index("-o") + 1] == jobs[1][2]
+        started.append(p)
+        return p
+
+    done = sweep.run(jobs, args, launch=launch)
+    assert len(started) == 2                                                  # the partial checkpoint did not count
+    assert done[jobs[0][2]] == 0 and done[jobs[1][2]] == 1
+    assert os.path.exists(jobs[0][2] + ".done") and not os.path.exists(jobs[1][2])
+    started.clear()
+    done = sweep.run(jobs, args, launch=launch)                               # only the failed job runs again
+    assert [p.cmd[p.cmd.index("-o") + 1] for p in started] == [jobs[1][2]]

@@ -36,6 +36,12 @@ def test_training_run_matches_reference_checkpoint(tmp_path, reg):
     assert c["epoch"] == int(z[tag + ".epoch"])
     assert abs(c["optimizer"]["param_groups"][0]["lr"] - float(z[tag + ".lr"])) < 1e-12
     assert len(c["optimizer"]["state"]) == int(z[tag + ".opt_n_state"]) == 334
+    # the reference saves an AdamW that has a StepLR attached (train.py:157-158): same key set, initial_lr included
+    ref_opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3e-5)
+    torch.optim.lr_scheduler.StepLR(ref_opt, step_size=1, gamma=0.87)
+    assert set(c["optimizer"]["param_groups"][0]) == set(ref_opt.state_dict()["param_groups"][0])
+    assert c["optimizer"]["param_groups"][0]["initial_lr"] == 3e-5
+    assert os.path.exists(out + ".done") and not os.path.exists(out + ".tmp")
     st = next(iter(c["optimizer"]["state"].values()))
     assert float(st["step"]) == float(z[tag + ".opt_step"]) and st["step"].dtype == torch.float32 and st["step"].dim() == 0
     assert str(np.asarray(c["val_score"]).dtype) == str(z[tag + ".val_score_dtype"])
