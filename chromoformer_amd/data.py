@@ -332,3 +332,19 @@ def shard_indices(perm, rank, world, batch_size, drop_last=True):
         per = math.ceil(len(tail) / world)
         out.append(tail[rank * per:(rank + 1) * per])
     return out
+
+
+def static_shard(genes, rank, world):
+    """The genes a data-parallel rank owns (and loads): every world-th gene of the split, so that shards differ by at most
+    one gene and each is as mixed as the whole."""
+    return list(genes[rank::world])
+
+
+def static_epoch_batches(perm, rank, world, batch_size):
+    """Batches of a rank under static sharding, as row indices into ITS shard (static_shard): the epoch permutation of the
+    whole split -- the same on every rank -- is filtered to the rank's own genes (gene p is row p // world of shard
+    p % world), and the first floor(floor(n / world) / batch_size) batches are kept, a count every rank agrees on.
+    A global batch is then the union of one batch per rank: `batch_size` genes from each shard."""
+    own = [p // world for p in perm if p % world == rank]
+    n_b = (len(perm) // world) // batch_size
+    return [own[k * batch_size:(k + 1) * batch_size] for k in range(n_b)]

@@ -47,13 +47,18 @@ def modernise_keys(state):
 
 
 def predict(meta_path, npy_dir, weights=None, regression=False, bsz=32, seed=123, i_max=8, w_prom=40000, w_max=40000,
-            binsizes=(2000, 500, 100), progress=False):
+            binsizes=(2000, 500, 100), progress=False, store_path=None):
     """-> (meta DataFrame, predictions float32 [n_genes]) in the order of the metadata file."""
     seed_everything(seed)
     meta = pd.read_csv(meta_path)
     genes = meta.gene_id.tolist()
-    ds = ChromoformerDataset(meta_path, npy_dir, genes, 7, i_max, list(binsizes), w_prom, w_max, regression=regression)
-    store = GeneStore(ds, progress=progress)
+    from . import pack
+    packed = pack.find(npy_dir, store_path, list(binsizes), i_max, w_prom, w_max, 7, genes)
+    if packed is not None:
+        store = packed.store(genes, regression=False)          # labels are not used for prediction
+    else:
+        ds = ChromoformerDataset(meta_path, npy_dir, genes, 7, i_max, list(binsizes), w_prom, w_max, regression=regression)
+        store = GeneStore(ds, progress=progress)
     Model = ChromoformerRegressor if regression else ChromoformerClassifier
     model = Model(7, 128, 128, dict(n_layers=1, n_heads=2, d_model=128, d_ff=128), dict(n_layers=2, n_heads=2, d_model=128, d_ff=256),
                   dict(n_layers=6, n_heads=8, d_model=256, d_ff=256), binsizes=list(binsizes), seed=seed, i_max=i_max, w_max=w_max,
@@ -86,8 +91,9 @@ def main(argv=None):
     ap.add_argument("-o", "--output", required=True, help="Path to output expression prediction.")
     ap.add_argument("-w", "--weights", default=None, help="Path to pretrained Chromoformer weights in .pt format.")
     ap.add_argument("--regression", action="store_true", help="ChromoformerRegressor (run_demo_regression.py)")
+    ap.add_argument("--store", default=None, help="packed store of `python -m chromoformer_amd.pack` (default: <npy-dir>/chromoformer.cfstore if present)")
     args = ap.parse_args(argv)
-    meta, pred = predict(args.meta, args.npy_dir, args.weights, args.regression, progress=True)
+    meta, pred = predict(args.meta, args.npy_dir, args.weights, args.regression, progress=True, store_path=args.store)
     print("Predicting expressions for %d genes." % len(meta))
     meta["prediction"] = pred
     meta.to_csv(args.output, index=False)

@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 import yaml
 
-from .data import ChromoformerDataset, GeneStore, shard_indices
+from .data import ChromoformerDataset, GeneStore, shard_indices, static_epoch_batches, static_shard
 from .engine import EpochFeed, Slot, Trainer
 from .net import ChromoformerClassifier, ChromoformerRegressor
 from .util import seed_everything
@@ -97,6 +97,12 @@ def main(argv=None):
     parser.add_argument("--binsizes", nargs="+", type=int, default=[2000, 500, 100])
     parser.add_argument("--regression", action="store_true", default=False)
     parser.add_argument("--use-wandb", action="store_true", default=False)
+    parser.add_argument("--store", default=None, help="packed store written by `python -m chromoformer_amd.pack` "
+                        "(default: <npy-dir>/chromoformer.cfstore when it exists and matches the configuration)")
+    parser.add_argument("--dp-shard", choices=["static", "global"], default="static",
+                        help="data-parallel runs: `static` = every rank owns (and loads) 1/world of the training genes and draws its "
+                             "batches from them; `global` = every rank holds the whole split and takes its slice of each global batch "
+                             "of the epoch permutation (reproduces the single-process batch composition exactly)")
     args = parser.parse_args(argv)
 
     if args.use_wandb is False:
@@ -136,13 +142,28 @@ def main(argv=None):
     val_genes = qs[(args.fold + 3) % 4]
     say(len(train_genes), len(val_genes))
 
+    from . import pack
+    packed = pack.find(args.npy_dir, args.store, args.binsizes, i_max, w_prom, w_max, n_feats, train_genes + val_genes)
+    say("packed store:", packed.path if packed is not None else "none (binning the raw .npy files)")
+
     def store_of(genes):
+        if packed is not None:          # a row gather out of the memory-mapped store, resident in HBM afterwards
+            return packed.store(genes, device=torch.device("cuda", local), regression=args.regression)
         ds = ChromoformerDataset(args.meta, args.npy_dir, genes, n_feats, i_max, args.binsizes, w_prom, w_max,
                                  regression=args.regression)
         # raw fp16 signals are binned on the GPU (cf_bin_regions) and the split stays resident in HBM
         return GeneStore(ds, progress=(rank == 0), device=torch.device("cuda", local), resident=True)
 
-    train_store, val_store = store_of(train_genes), store_of(val_genes)
+    # Data parallel: a rank loads what it will touch.  Training genes: its static shard (every world-th gene), or the whole
+    # split when the single-process batch composition is to be reproduced; validation genes: its contiguous slice.
+    static = world > 1 and args.dp_shard == "static"
+    train_store = store_of(static_shard(train_genes, rank, world) if static else train_genes)
+    n_val = len(val_genes)
+    per_val = (n_val + world - 1) // world
+    val_lo, val_hi = min(n_val, rank * per_val), min(n_val, (rank + 1) * per_val)
+    val_store = store_of(val_genes[val_lo:val_hi])
+    label_of = {r["gene_id"]: (np.log2(r["expression"] + 1) if args.regression else r["label"]) for r in meta.to_dict("records")}
+    val_labels = torch.tensor([label_of[g] for g in val_genes], dtype=torch.float32 if args.regression else torch.int64)
 
     Model = ChromoformerRegressor if args.regression else ChromoformerClassifier
     model = Model(n_feats, d_emb, config["d_head"], config["embed"], config["pairwise_interaction"], config["regulation"],
@@ -154,14 +175,17 @@ def main(argv=None):
 
     val_score = val_label = val_loss = None
     for epoch in range(1, num_epoch):
-        perm = epoch_permutation(len(train_store))
-        batches = shard_indices(perm, rank, world, bsz, drop_last=True)
+        perm = epoch_permutation(len(train_genes))            # the same draws on every rank
+        if static:
+            batches = static_epoch_batches(perm, rank, world, bsz)
+        else:
+            batches = shard_indices(perm, rank, world, bsz, drop_last=True)
         train_epoch(trainer, feed, batches,
                     lambda lo, la, ls: _report_train(say, wandb, epoch, float(ls.mean().item()), trainer.lr, lo, la, args.regression))
 
         # validation (sharded over ranks, gathered on every rank)
         _draw_loader_seed()                                         # the val DataLoader's base seed draw
-        val_out, val_lab = _validate(model, trainer, val_store, bsz, rank, world)
+        val_out, val_lab = _validate(model, trainer, val_store, n_val, bsz, world), val_labels.clone()
         # NB: for the regressor the reference compares [n,1] outputs with [n] labels here (train.py:280-283),
         # i.e. a broadcast [n,n] MSE; `last_val_loss` in the checkpoint is that number, so it is kept.
         import warnings
@@ -274,16 +298,15 @@ def _report_train(say, wandb, epoch, batch_loss, lr, out, label, regression):
         wandb.log({"train/loss": batch_loss, "train/acc": acc, "train/auc": auc, "train/ap": ap})
 
 
-def _validate(model, trainer, store, bsz, rank, world):
-    """Forward over the validation genes (the tail batch is kept, train.py:140); returns CPU
-    (logits [n, n_out], labels [n]) in dataset order on every rank."""
-    n = len(store)
-    per = (n + world - 1) // world
-    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+def _validate(model, trainer, store, n_total, bsz, world):
+    """Forward over the rank's slice of the validation genes (`store` holds exactly that slice: ceil(n_total / world)
+    consecutive genes per rank; the tail batch is kept, train.py:140); returns the CPU logits [n_total, n_out] of ALL
+    validation genes in dataset order on every rank."""
+    per = (n_total + world - 1) // world
     outs = []
     slot_cache = {}
-    for s in range(lo, hi, bsz):
-        idx = list(range(s, min(hi, s + bsz)))
+    for s in range(0, len(store), bsz):
+        idx = list(range(s, min(len(store), s + bsz)))
         slot = slot_cache.get(len(idx)) or Slot(model, len(idx))
         slot_cache[len(idx)] = slot
         with torch.cuda.stream(trainer.stream):
@@ -296,8 +319,8 @@ def _validate(model, trainer, store, bsz, rank, world):
         pad[: mine.shape[0]] = mine
         parts = [torch.zeros_like(pad) for _ in range(world)]
         torch.distributed.all_gather(parts, pad)
-        mine = torch.cat([p[: max(0, min(n, (r + 1) * per) - min(n, r * per))] for r, p in enumerate(parts)])
-    return mine.cpu(), store.label.cpu().clone()
+        mine = torch.cat([p[: max(0, min(n_total, (r + 1) * per) - min(n_total, r * per))] for r, p in enumerate(parts)])
+    return mine.cpu()
 
 
 if __name__ == "__main__":
