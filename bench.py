@@ -106,6 +106,38 @@ def train_loop_rate(model, lr, steps, store_genes, regime, dev):
                     "the step graph, running metrics (train.py:205-232) on every 10-step window"}
 
 
+def dp_path_ms(model, batch, steps, warmup, dev):
+    """Fixed overhead of the data-parallel code path, measurable on ONE GPU: the same step through a one-rank RCCL group
+    (two graphs, two all-reduces of the 16.6 MB / 4.6 MB buckets -- in-place no-ops for RCCL at world 1 but launched --,
+    three event waits), overlapped and serialised schedule."""
+    import socket
+    import torch.distributed as dist
+    from chromoformer_amd.engine import Trainer
+    if dist.is_initialized():
+        return None
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    out = {}
+    try:
+        for key, overlap in (("overlapped", True), ("serialised", False)):
+            trainer = Trainer(model, lr=3e-5, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=overlap)
+            slot = trainer.stage(batch)
+            for _ in range(warmup):
+                trainer.step(slot)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                trainer.step(slot)
+            torch.cuda.synchronize()
+            out[key] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+    finally:
+        dist.destroy_process_group()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,8 +148,17 @@ def main():
     ap.add_argument("--regime", default="dense", choices=["dense", "realistic"])
     ap.add_argument("--train-loop-steps", type=int, default=2000, help="steps of the shipped training loop timed for the `train_loop` key (0 = skip)")
     ap.add_argument("--train-loop-genes", type=int, default=16384, help="genes in the synthetic resident split of the `train_loop` leg")
+    ap.add_argument("--dp-path", action="store_true", default=None, help="also time the data-parallel code path on a one-rank RCCL group "
+                    "(`dp_path_ms_per_step`; default: on for --gpus 1)")
+    ap.add_argument("--no-dp-path", dest="dp_path", action="store_false")
     ap.add_argument("--roofline-kernel", default="k_reg_bwd", help="kernel timed with HIP events: k_reg_bwd (dominant), k_reg_fwd (needs --no-graph), k_wgrad, k_adamw")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints a
+    # version banner there when a communicator is created, libraries print warnings) is sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -185,11 +226,14 @@ def main():
             "roofline": roof,
             "loss": round(float(trainer.last_loss()), 6),
         }
+        if world == 1 and args.dp_path is not False:
+            out["dp_path_ms_per_step"] = dp_path_ms(model, batch, args.steps, args.warmup, dev)
         if world == 1 and args.train_loop_steps > 0:
             out["train_loop"] = train_loop_rate(model, 3e-5, args.train_loop_steps, args.train_loop_genes, args.regime, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         torch.distributed.destroy_process_group()
 

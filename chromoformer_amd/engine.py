@@ -147,10 +147,20 @@ class Trainer:
     inside a graph cost ~60 us per replay with this runtime; an eager launch between two graphs costs nothing)."""
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
-                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False):
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
+                 overlap_allreduce=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
+        # Data parallel: the early (Regulation + head) bucket's all-reduce normally runs on the side stream UNDER the Pairwise +
+        # Embedding backward.  Those kernels are latency-bound and sensitive to co-running work (a weight-gradient launch
+        # beside them tripled k_attc2<bwd> once, DESIGN.md section 4), and RCCL's kernels occupy CUs too: with
+        # overlap_allreduce=False (or CF_DP_OVERLAP=0 in the environment) both all-reduces are issued behind the whole
+        # backward pass instead.  Same arithmetic, same bits; only the schedule differs.
+        if overlap_allreduce is None:
+            import os
+            overlap_allreduce = os.environ.get("CF_DP_OVERLAP", "1") != "0"
+        self.overlap_allreduce = bool(overlap_allreduce)
         self.betas, self.eps, self.wd = betas, eps, weight_decay
         self._L = _lib.lib()
         self._last = None
@@ -276,18 +286,23 @@ class Trainer:
                 self._launch(slot.graph["first"], st)
             else:
                 self._seq_early(slot, st)
-            # the early bucket is complete: all-reduce it on the side stream, under the rest of the backward pass
-            self._ev_fork.record(self.stream)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self._ev_fork)
-                torch.distributed.all_reduce(self._buckets[_lib.BUCKET_REG], group=self.pg)     # SUM; dloss carries 1/world
-                if self.overlap_opt:
-                    self._opt(_lib.BUCKET_REG, self.side.cuda_stream)
-                self._ev_join.record(self.side)
+            def early_allreduce():      # the early bucket is complete: all-reduce it on the side stream
+                self._ev_fork.record(self.stream)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self._ev_fork)
+                    torch.distributed.all_reduce(self._buckets[_lib.BUCKET_REG], group=self.pg)     # SUM; dloss carries 1/world
+                    if self.overlap_opt:
+                        self._opt(_lib.BUCKET_REG, self.side.cuda_stream)
+                    self._ev_join.record(self.side)
+
+            if self.overlap_allreduce:
+                early_allreduce()       # ... under the rest of the backward pass
             if self.use_graph:
                 self._launch(slot.graph["late"], st)
             else:
                 self._seq_late(slot, st)
+            if not self.overlap_allreduce:
+                early_allreduce()       # ... behind it (serialised schedule)
             if oig:
                 torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
                 self._opt(_lib.BUCKET_PE, st)

@@ -81,8 +81,12 @@ def test_one_rank_rccl_all_reduce_in_the_step():
         got, loss = _run(use_graph=True, world_size=1, process_group=dist.group.WORLD)
         got2, loss2 = _run(use_graph=False, world_size=1, process_group=dist.group.WORLD, timed_kernel="k_reg_bwd")
         got3, loss3 = _run(use_graph=True, world_size=1, process_group=dist.group.WORLD, opt_in_graph=True, overlap_opt=True)
+        # serialised schedule: both all-reduces behind the whole backward pass (Trainer(overlap_allreduce=False) / CF_DP_OVERLAP=0)
+        got4, loss4 = _run(use_graph=True, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=False)
+        got5, loss5 = _run(use_graph=False, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=False, opt_in_graph=True)
     finally:
         dist.destroy_process_group()
-    assert loss == ref_loss and loss2 == ref_loss and loss3 == ref_loss
+    assert loss == ref_loss and loss2 == ref_loss and loss3 == ref_loss and loss4 == ref_loss and loss5 == ref_loss
     for k in ref:
         assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], got2[k]) and torch.equal(ref[k], got3[k]), k
+        assert torch.equal(ref[k], got4[k]) and torch.equal(ref[k], got5[k]), k
