@@ -138,6 +138,67 @@ def dp_path_ms(model, batch, steps, warmup, dev):
     return out
 
 
+def stress_main(args, json_out):
+    """BASELINE.json configs[3] -- i_max = 16, one 100-bp resolution over 80 kb (800-bin sequences), bsz 128 -- as SURVEY.md
+    section 8-d defines it (the reference cannot run it): the roofline run of the DENSE attention core, all L x L rows,
+    forward + backward, on the N = 128 * 17 sequences of a batch (cf_op_attention_fwd / _bwd, csrc/cf_attn.h).  A step is
+    one forward + backward over the batch; `value` is genes/s of that core alone, `roofline` its algorithmic flops
+    (4 N H L^2 dh forward, 10 N H L^2 dh backward; the recomputed QK^T of the backward kernels is not counted) against the
+    f32 MFMA peak, from HIP events on the launch stream."""
+    import ctypes as C
+    from chromoformer_amd import _lib
+    B, S, H, L = 128, 16, 2, 800
+    N = B * (S + 1)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    proj = torch.randn(N, L, 3 * H * 64, device=dev, generator=g)
+    q, k, v = proj[:, :, :128], proj[:, :, 128:256], proj[:, :, 256:]
+    d_o = torch.randn(N, L, H * 64, device=dev, generator=g)
+    o = torch.empty(N, L, H * 64, device=dev)
+    stats = torch.empty(N, H, L, 2, device=dev)
+    dproj = torch.zeros_like(proj)
+    dq, dk, dv = dproj[:, :, :128], dproj[:, :, 128:256], dproj[:, :, 256:]
+    ws = torch.empty(N * H * L, device=dev)
+    valid = torch.ones(N, L, dtype=torch.uint8, device=dev)
+    lib = _lib.lib()
+    sh = _lib.cf_attn_shape(N, H, L, L, 3 * H * 64, 3 * H * 64, 3 * H * 64, H * 64)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def step():
+        _lib.check(lib.cf_op_attention_fwd(C.byref(sh), p(q), p(k), p(v), p(valid), p(valid), None, p(o), p(stats), st), "cf_op_attention_fwd")
+        _lib.check(lib.cf_op_attention_bwd(C.byref(sh), p(q), p(k), p(v), p(valid), p(valid), None, p(o), p(stats), p(d_o), p(dq), p(dk), p(dv),
+                                           p(ws), st), "cf_op_attention_bwd")
+
+    steps, warmup = min(args.steps, 20), min(args.warmup, 3)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / steps
+    flops = 14.0 * N * H * L * L * 64
+    ach = flops / (dev_ms * 1e-3) / 1e12
+    out = {"metric": "genes/sec training (bsz=64, default config)", "value": round(B * steps / el, 1), "unit": "genes/s", "n_gpus": 1,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * el / steps, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "stress config (BASELINE configs[3]): dense attention core forward + backward, all rows, "
+                                  "N = 128 x 17 = %d sequences x %d heads, L = %d, dh = 64 -- attention kernels only, not a training step" % (N, H, L),
+                      "parallelism": "dp1", "global_batch": B},
+           "roofline": {"kernel": "k_attn_fwd + k_attn_bwd_kv + k_attn_bwd_q", "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3,
+                        "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None, "avg_launch_us": round(dev_ms * 1e3, 1),
+                        "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}}
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +207,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regime", default="dense", choices=["dense", "realistic"])
+    ap.add_argument("--config", default="default", choices=["default", "stress"],
+                    help="default = the headline benchmark (BASELINE configs[1]); stress = the 800-bin dense attention roofline run (configs[3])")
     ap.add_argument("--train-loop-steps", type=int, default=2000, help="steps of the shipped training loop timed for the `train_loop` key (0 = skip)")
     ap.add_argument("--train-loop-genes", type=int, default=16384, help="genes in the synthetic resident split of the `train_loop` leg")
     ap.add_argument("--dp-path", action="store_true", default=None, help="also time the data-parallel code path on a one-rank RCCL group "
@@ -160,6 +223,8 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    if args.config == "stress":
+        return stress_main(args, json_out)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

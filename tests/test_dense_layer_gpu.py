@@ -36,7 +36,7 @@ def _run(w, x_q, x_kv, qv, kv, N, Lq, Lk):
     return y
 
 
-@pytest.mark.parametrize("res,L", [(2000, 20), (500, 80), (100, 400)])
+@pytest.mark.parametrize("res,L", [(2000, 20), (500, 80), (100, 400), (100, 800)])      # 800: the stress configuration's sequence length
 def test_embedding_layer_all_rows(res, L):
     dev = torch.device("cuda", 0)
     P = orc.init_params(None, 5, False)
@@ -108,7 +108,7 @@ def _close(got, ref, name, tol=2e-4):
     assert err <= tol * max(ref.abs().max().item(), 1e-3), (name, err, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("L,N", [(80, 3), (400, 2), (96, 70), (96, 140)])      # the last ones span several split-K chunks (6,720 / 13,440 rows; the largest also two chunks of bias partials)
+@pytest.mark.parametrize("L,N", [(80, 3), (400, 2), (800, 4), (96, 70), (96, 140)])      # (800, 4): the stress shape; the last ones span several split-K chunks (6,720 / 13,440 rows; the largest also two chunks of bias partials)
 def test_embedding_layer_backward(L, N):
     dev = torch.device("cuda", 0)
     P = {k: v.clone().requires_grad_(True) for k, v in orc.init_params(None, 5, False).items()}
@@ -135,14 +135,14 @@ def test_embedding_layer_backward(L, N):
         _close(grads[n], P[pre + k].grad, k)
 
 
-def test_pairwise_layer_backward():
+@pytest.mark.parametrize("N,Lq,Lk", [(3, 64, 150), (4, 800, 800)])      # (4, 800, 800): the stress shape
+def test_pairwise_layer_backward(N, Lq, Lk):
     dev = torch.device("cuda", 0)
     P = {k: v.clone().requires_grad_(True) for k, v in orc.init_params(None, 6, False).items()}
     pre = "pairwise_interaction.100.transformer.layers.0."
     Pd = {k: v.detach() for k, v in P.items()}
     w, keep = _layer(Pd, pre, Pd[pre + "self_att.p_att.weight"], Pd[pre + "self_att.c_att.weight"], dev)
     g = torch.Generator().manual_seed(3)
-    N, Lq, Lk = 3, 64, 150
     x_p = torch.randn(N, Lq, 128, generator=g).requires_grad_(True)
     x_c = torch.randn(N, Lk, 128, generator=g).requires_grad_(True)
     dy = torch.randn(N, Lq, 128, generator=g)
@@ -150,6 +150,8 @@ def test_pairwise_layer_backward():
     cv = torch.zeros(N, Lk, dtype=torch.uint8)
     cv[0, 40:90] = 1
     cv[1, :] = 1                                       # cv[2] all zero: dummy pCRE
+    if N > 3:
+        cv[3, Lk // 2 - 3: Lk // 2 + 4] = 1
     mask4 = ~(pv.bool()[:, None, :, None] & cv.bool()[:, None, None, :])
     ref = orc.feed_forward(P, pre + "ff.", orc.pairwise_attention_block(P, pre + "self_att.", x_p, x_c, mask4, 2))
     ref.backward(dy)
