@@ -43,6 +43,8 @@ static int fail(const char* fmt, ...) {
 // ------------------------------------------------------------------------------------
 // parameter layout (host only)
 // ------------------------------------------------------------------------------------
+constexpr int kMaxEmbedLayers = 8;
+
 struct PDesc {
     std::string name;
     int ndim;
@@ -96,7 +98,8 @@ static int check_config(const cf_config& c) {
     if (c.n_out != 1 && c.n_out != 2) return fail("n_out must be 1 or 2");
     if (c.n_res != 3) return fail("exactly 3 resolutions are supported (fc_head is Linear(3*d_emb, .), net.py:327)");
     if (c.i_max < 1 || c.i_max > 16) return fail("i_max must be in 1..16");
-    if (c.embed_layers != 1) return fail("centre-row evaluation needs embed.n_layers == 1 (got %d)", c.embed_layers);
+    if (c.embed_layers < 1 || c.embed_layers > kMaxEmbedLayers)
+        return fail("embed.n_layers must be in 1..%d (got %d); more than one layer runs the all-rows path", kMaxEmbedLayers, c.embed_layers);
     if (c.embed_heads != 2 || c.embed_dmodel != 128) return fail("embed: n_heads=2, d_model=128 required");
     if (c.pair_heads != 2 || c.pair_dmodel != 128) return fail("pairwise_interaction: n_heads=2, d_model=128 required");
     if (c.pair_layers < 1 || c.pair_layers > 2) return fail("pairwise_interaction.n_layers must be 1 or 2");
@@ -197,6 +200,20 @@ struct cf_handle {
     float* tiled = nullptr;              // tiled copy of the Linear weights (forward products), same offsets
     float* tiledT = nullptr;             // tiled copy of the transposed Regulation weights (backward products), same offsets
     bool reg8 = false;                   // Regulation stack on the 512-thread kernels of cf_reg8.h
+    // Embedding stack over ALL promoter bins (cf_embed_full.h + the dense transformer layer): used by the model path when
+    // embed.n_layers > 1 and by cf_embed_full; device buffers outside the arena, allocated on first need
+    struct EmbedDense {
+        bool ready = false;
+        int B = 0;
+        float* x[kMaxRes][kMaxEmbedLayers + 1] = {};      // token embeddings / layer outputs [B, L, 128]
+        float* ws[kMaxRes][kMaxEmbedLayers] = {};          // dense-layer workspaces (training size)
+        float* dy[kMaxRes][3] = {};                        // gradient ping-pong [B, L, 128]
+        float* lp_partial[kMaxRes] = {};
+        uint8_t* valid[kMaxRes] = {};
+        float* tables = nullptr;                           // 4 MiB of tile tables for the backward pass
+        std::vector<void*> owned;
+    } ed;
+    bool embed_dense = false;            // the training path goes through it (embed.n_layers > 1)
     RetileUnit* retile_units = nullptr;
     int n_retile = 0;
     // workspace
@@ -538,7 +555,7 @@ static int build_tables(cf_handle* h) {
     std::vector<LpJob> lpj;
     for (int r = 0; r < c.n_res; ++r) {
         const int bs = c.binsizes[r];
-        {   // Embedding
+        if (!h->embed_dense) {   // Embedding (the all-rows path writes its gradients itself)
             const std::string pre = fmt("embed.%d.", bs), lp = pre + "transformer.layers.0.";
             const CentreBuf& b = h->E[r];
             LpJob j;
@@ -715,6 +732,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             return fail("cf_create: allocation of the tiled weight copy failed");
         }
     }
+    h->embed_dense = h->cfg.embed_layers > 1;
     h->planning = true;
     plan_workspace(h);
     hipError_t e = hipMalloc(&h->arena, h->arena_floats * sizeof(float));
@@ -794,6 +812,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (h->reg_tab) (void)hipFree(h->reg_tab);
     if (h->tiled) (void)hipFree(h->tiled);
     if (h->tiledT) (void)hipFree(h->tiledT);
+    for (void* q : h->ed.owned) (void)hipFree(q);
     if (h->retile_units) (void)hipFree(h->retile_units);
     for (cf_handle::Replay& rp : h->replays) {
         if (rp.first) (void)hipGraphExecDestroy(rp.first);
@@ -815,6 +834,10 @@ extern "C" int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg
     if (grads) return build_tables(h);
     return 0;
 }
+
+// the all-rows Embedding path (defined behind the dense-layer operators at the end of this file)
+static int embed_dense_forward(cf_handle* h, const cf_batch* bt, bool train, hipStream_t st);
+static int embed_dense_backward(cf_handle* h, const cf_batch* bt, hipStream_t st);
 
 // ------------------------------------------------------------------------------------
 // launch helpers
@@ -1045,7 +1068,9 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         return 0;
     };
 
-    {   // Embedding
+    if (h->embed_dense) {   // Embedding with more than one layer: every row of every layer (cf_embed_full.h + dense layers)
+        if (embed_dense_forward(h, bt, save != 0, st)) return -1;
+    } else {   // Embedding
         CentreBuf* bufs[kMaxRes];
         const float* xin[kMaxRes];
         float* outp[kMaxRes];
@@ -1432,7 +1457,9 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_dgrad<lin_proj_p>");
     }
-    {   // Embedding
+    if (h->embed_dense) {
+        if (embed_dense_backward(h, bt, st)) return -1;      // writes the Embedding gradients directly (no deferred tiles)
+    } else {   // Embedding
         CentreBuf* bufs[kMaxRes];
         const float* dout[kMaxRes];
         for (int r = 0; r < nres; ++r) {
@@ -1535,6 +1562,7 @@ extern "C" int cf_backward_from(cf_handle* h, const cf_batch* bt, const float* d
 // hipGraph capture of launch sequences (the per-step sequence is static)
 // ------------------------------------------------------------------------------------
 extern "C" int cf_capture_begin(cf_handle* h, void* stream) {
+    if (h && h->embed_dense) return fail("cf_capture_begin: embed.n_layers > 1 runs the all-rows Embedding path, whose table uploads synchronise the stream: not capturable, launch eagerly");
     if (!h) return fail("null handle");
     if (h->capturing) return fail("cf_capture_begin: already capturing");
     h->cap = cf_handle::Replay();
@@ -2240,6 +2268,138 @@ extern "C" int cf_op_dense_layer_bwd(const cf_dense_layer* w, const float* x_q, 
         HIP_TRY(hipStreamSynchronize(st));
         hipLaunchKernelGGL(k_colsum, dim3((int)cs.size()), dim3(256), 0, st, (const CsTile*)cs_d, 1);
         LAUNCH_CHECK("k_colsum<dense layer bias>");
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Embedding over all promoter bins (embed.n_layers > 1, cf_embed_full): net.py:9-59 without the centre-row shortcut
+// ------------------------------------------------------------------------------------
+static int embed_dense_alloc(cf_handle* h) {
+    cf_handle::EmbedDense& e = h->ed;
+    if (e.ready) return 0;
+    const cf_config& c = h->cfg;
+    const int B = c.max_batch, E = c.embed_layers;
+    auto get = [&](size_t floats) -> float* {
+        void* q = nullptr;
+        if (hipMalloc(&q, floats * sizeof(float)) != hipSuccess) return nullptr;
+        (void)hipMemset(q, 0, floats * sizeof(float));
+        h->ed.owned.push_back(q);
+        return (float*)q;
+    };
+    for (int r = 0; r < c.n_res; ++r) {
+        const int L = c.n_bins[r];
+        const size_t rows = (size_t)B * L;
+        for (int l = 0; l <= E; ++l)
+            if (!(e.x[r][l] = get(rows * kD))) return fail("embed_dense_alloc: out of memory");
+        for (int l = 0; l < E; ++l)
+            if (!(e.ws[r][l] = get((size_t)dense_ws(B, L, L, c.embed_dff, true).total))) return fail("embed_dense_alloc: out of memory");
+        for (int k = 0; k < 3; ++k)
+            if (!(e.dy[r][k] = get(rows * kD))) return fail("embed_dense_alloc: out of memory");
+        if (!(e.lp_partial[r] = get(((rows + kEmbWgRows - 1) / kEmbWgRows) * kD * 8))) return fail("embed_dense_alloc: out of memory");
+        if (!(e.valid[r] = reinterpret_cast<uint8_t*>(get((rows + 3) / 4 + 4)))) return fail("embed_dense_alloc: out of memory");
+    }
+    if (!(e.tables = get((size_t)1 << 20))) return fail("embed_dense_alloc: out of memory");
+    e.B = B;
+    e.ready = true;
+    return 0;
+}
+static cf_dense_layer embed_dense_weights(const cf_handle* h, int r, int l, const float* base) {
+    const std::string lp = fmt("embed.%d.transformer.layers.%d.", h->cfg.binsizes[r], l);
+    auto at = [&](const std::string& n) { return base + h->table[h->index.at(lp + n)].offset; };
+    cf_dense_layer w;
+    const float* att = at("self_att.att.weight");      // rows [q | k | v] of the fused projection (modules.py:38)
+    w.wq = att;
+    w.wkv = att + (size_t)kD * kD;
+    w.wo = at("self_att.ff.weight");
+    w.bo = at("self_att.ff.bias");
+    w.ln1_g = at("self_att.ln.weight");
+    w.ln1_b = at("self_att.ln.bias");
+    w.w1 = at("ff.l1.weight");
+    w.b1 = at("ff.l1.bias");
+    w.w2 = at("ff.l2.weight");
+    w.b2 = at("ff.l2.bias");
+    w.ln2_g = at("ff.ln.weight");
+    w.ln2_b = at("ff.ln.bias");
+    w.d_ff = h->cfg.embed_dff;
+    return w;
+}
+// Pad mask of the promoters as the dense layer wants it: the full [B, L, L] byte mask when the caller passed the reference's
+// tensor (row stride L * L: the centre-row pointer is L/2 rows into it), else validity bytes from the compact centre row
+// -- exact for the dataset's structured masks  not(valid x valid)  with a real centre bin (data.py:156-161).
+static void embed_dense_mask(cf_handle* h, const cf_batch* bt, int r, const uint8_t** full, const uint8_t** valid, hipStream_t st) {
+    const int L = h->cfg.n_bins[r];
+    if (bt->promoter_mask_stride[r] == (long long)L * L) {
+        *full = bt->promoter_mask_row[r] - (size_t)(L / 2) * L;
+        *valid = nullptr;
+    } else {
+        hipLaunchKernelGGL(k_mask_to_valid, dim3(bt->B), dim3(256), 0, st, bt->promoter_mask_row[r], bt->promoter_mask_stride[r], L, h->ed.valid[r]);
+        *full = nullptr;
+        *valid = h->ed.valid[r];
+    }
+}
+static int embed_dense_forward(cf_handle* h, const cf_batch* bt, bool train, hipStream_t st) {
+    if (embed_dense_alloc(h)) return -1;
+    const cf_config& c = h->cfg;
+    const int B = bt->B, E = c.embed_layers, T = c.i_max + 1;
+    for (int r = 0; r < c.n_res; ++r) {
+        const int L = c.n_bins[r];
+        EmbTokArgs ta{bt->promoter_feats[r], h->pe[r], h->P_(fmt("embed.%d.lin_proj.weight", c.binsizes[r])), h->ed.x[r][0], B, L, c.n_feats};
+        hipLaunchKernelGGL(k_embed_tokens, dim3(std::min<long long>((long long)B * L, 4096)), dim3(128), 0, st, ta);
+        LAUNCH_CHECK("k_embed_tokens");
+        const uint8_t *full, *valid;
+        embed_dense_mask(h, bt, r, &full, &valid, st);
+        for (int l = 0; l < E; ++l) {
+            const cf_dense_layer w = embed_dense_weights(h, r, l, h->params);
+            if (dense_layer_fwd(&w, h->ed.x[r][l], h->ed.x[r][l], valid, valid, full, B, L, L, h->ed.x[r][l + 1], h->ed.ws[r][l], train, st)) return -1;
+        }
+        hipLaunchKernelGGL(k_rows_gather, dim3(B), dim3(128), 0, st, (const float*)h->ed.x[r][E], L, L / 2, h->Rx[r][0], T * kD);
+        LAUNCH_CHECK("k_rows_gather");
+    }
+    return 0;
+}
+static int embed_dense_backward(cf_handle* h, const cf_batch* bt, hipStream_t st) {
+    const cf_config& c = h->cfg;
+    const int B = bt->B, E = c.embed_layers;
+    for (int r = 0; r < c.n_res; ++r) {
+        const int L = c.n_bins[r];
+        const long long n = (long long)B * L * kD;
+        float *dy = h->ed.dy[r][0], *da = h->ed.dy[r][1], *db = h->ed.dy[r][2];
+        hipLaunchKernelGGL(k_rows_scatter, dim3(B * L), dim3(128), 0, st, (const float*)h->edout[r], L, L / 2, dy);      // only the centre row is consumed (net.py:59)
+        LAUNCH_CHECK("k_rows_scatter");
+        const uint8_t *full, *valid;
+        embed_dense_mask(h, bt, r, &full, &valid, st);
+        for (int l = E - 1; l >= 0; --l) {
+            const cf_dense_layer w = embed_dense_weights(h, r, l, h->params);
+            const cf_dense_layer gw = embed_dense_weights(h, r, l, h->grads);
+            cf_dense_layer_grads g{const_cast<float*>(gw.wq), const_cast<float*>(gw.wkv), const_cast<float*>(gw.wo), const_cast<float*>(gw.bo),
+                                   const_cast<float*>(gw.ln1_g), const_cast<float*>(gw.ln1_b), const_cast<float*>(gw.w1), const_cast<float*>(gw.b1),
+                                   const_cast<float*>(gw.w2), const_cast<float*>(gw.b2), const_cast<float*>(gw.ln2_g), const_cast<float*>(gw.ln2_b)};
+            if (cf_op_dense_layer_bwd(&w, h->ed.x[r][l], h->ed.x[r][l], valid, valid, full, B, L, L, dy, da, db, &g, h->ed.ws[r][l], h->ed.tables, st)) return -1;
+            hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, da, (const float*)db, n);      // self-attention: x is query and key/value input
+            LAUNCH_CHECK("k_add_inplace");
+            std::swap(dy, da);
+        }
+        const long long rows = (long long)B * L;
+        const int chunks = (int)((rows + kEmbWgRows - 1) / kEmbWgRows);
+        EmbTokWgArgs wa{dy, bt->promoter_feats[r], h->ed.lp_partial[r], rows, c.n_feats};
+        hipLaunchKernelGGL(k_embed_tokens_wgrad, dim3(chunks), dim3(128), 0, st, wa);
+        hipLaunchKernelGGL(k_embed_tokens_wgrad2, dim3(1), dim3(128), 0, st, (const float*)h->ed.lp_partial[r], chunks, c.n_feats,
+                           h->G_(fmt("embed.%d.lin_proj.weight", c.binsizes[r])));
+        LAUNCH_CHECK("k_embed_tokens_wgrad");
+    }
+    return 0;
+}
+
+// EmbeddingTransformer.forward's FIRST return value (net.py:57-59): the embeddings of every promoter bin, [B, 1, L, 128] per
+// resolution, for consumers that want more than the centre row.  Forward only; not capturable.
+extern "C" int cf_embed_full(cf_handle* h, const cf_batch* bt, float* const* out, void* stream) {
+    if (check_batch(h, bt) || !out) return fail("cf_embed_full: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (embed_dense_forward(h, bt, false, st)) return -1;
+    for (int r = 0; r < h->cfg.n_res; ++r) {
+        if (!out[r]) continue;
+        HIP_TRY(hipMemcpyAsync(out[r], h->ed.x[r][h->cfg.embed_layers], (size_t)bt->B * h->cfg.n_bins[r] * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     return 0;
 }

@@ -1599,3 +1599,4 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
 #include "cf_attn.h"
 #include "cf_bin.h"
 #include "cf_gather.h"
+#include "cf_embed_full.h"

@@ -272,6 +272,34 @@ class ChromoformerBase(nn.Module):
             return _BackwardHook.apply(self._anchor, self, bs, keep)
         return self._run_forward(bs, save=False)
 
+    def embed_full(self, promoter_feats, promoter_pad_masks):
+        """EmbeddingTransformer's first return value (net.py:57-59): {binsize: [B, 1, L, 128]}, the embedding of every
+        promoter bin (all rows of every Embedding layer through the dense transformer layer; forward only)."""
+        if self._handle is None:
+            raise RuntimeError("call .cuda() first: the Chromoformer HIP path needs device buffers")
+        bs = _lib.cf_batch()
+        keep, B = [], None
+        for r, b in enumerate(self.binsizes):
+            L = self.n_bins[r]
+            pf = promoter_feats[b].to(self._device, torch.float32).contiguous()
+            B = pf.shape[0] if B is None else B
+            if pf.numel() != B * L * self.n_feats:
+                raise ValueError("promoter feature shape does not match the configuration at binsize %d" % b)
+            m, ptr, stride = self._rows(promoter_pad_masks[b], L, B)
+            keep += [pf, m]
+            bs.promoter_feats[r], bs.promoter_mask_row[r], bs.promoter_mask_stride[r] = pf.data_ptr(), ptr, stride
+            # cf_embed_full touches the promoter side only; the other pointers just have to be non-null
+            bs.pcre_feats[r], bs.pcre_mask_row[r], bs.pcre_mask_stride[r], bs.interaction_mask[r] = pf.data_ptr(), ptr, stride, ptr
+        bs.interaction_freq = keep[0].data_ptr()
+        bs.B = B
+        if B > self._max_batch:
+            raise ValueError("batch of %d genes exceeds max_batch=%d given at construction" % (B, self._max_batch))
+        outs = [torch.empty(B, 1, L, self.d_emb, device=self._device) for L in self.n_bins]
+        ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        st = torch.cuda.current_stream(self._device).cuda_stream
+        _lib.check(_lib.lib().cf_embed_full(self._handle, C.byref(bs), ptrs, st), "cf_embed_full")
+        return {b: o for b, o in zip(self.binsizes, outs)}
+
     def forward_backward(self, packed, labels, loss_scale=1.0):
         """Fused forward + loss + backward.  Returns (logits, loss tensor on device)."""
         bs, _ = packed

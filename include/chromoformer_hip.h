@@ -166,6 +166,15 @@ int cf_adamw_step_dev(cf_handle* h, int buckets, void* stream);
  * other stream becomes a parallel branch of the graph (it has to be joined back before cf_capture_end). */
 int cf_stream_wait(cf_handle* h, void* waiter, void* signaller);
 
+/* EmbeddingTransformer.forward's first return value (net.py:57-59): the embedding of EVERY promoter bin, out[r] =
+ * [B, 1, L_r, 128] (a NULL entry is skipped).  The training path never needs it (only the centre row is consumed,
+ * net.py:59, 138); it is computed by the all-rows path -- token embeddings + the dense transformer layer of
+ * cf_op_dense_layer_fwd per Embedding layer -- which is also what cf_forward / cf_backward run for the whole Embedding
+ * stack when embed.n_layers > 1 (keys and values of a layer are then all rows of the previous one).  Pad masks: the full
+ * [B,1,1,L,L] tensor (mask stride L*L) is honoured entry by entry; a compact centre row is expanded as the dataset's
+ * structured mask not(valid x valid).  Forward only; synchronises the stream (not capturable). */
+int cf_embed_full(cf_handle* h, const cf_batch* batch, float* const* out, void* stream);
+
 /* ---- hipGraph capture ---------------------------------------------------------------- */
 /* The launch sequence of a step is static, so it can be captured once and replayed: every
  * library call issued on `stream` between begin and end is recorded (nothing executes);

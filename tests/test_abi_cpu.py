@@ -52,7 +52,7 @@ def test_param_table_matches_reference_state_dict():
 def test_unsupported_configs_are_rejected_loudly():
     import ctypes as C
     cfg = _cfg()
-    cfg.embed_layers = 2
+    cfg.embed_layers = 9            # up to 8 Embedding layers are supported (more than one runs the all-rows path)
     lay = _lib.cf_layout()
     assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
     assert b"embed.n_layers" in _lib.lib().cf_last_error()
