@@ -691,6 +691,9 @@ extern "C" int cf_param_layout(const cf_config* cfg, cf_layout* layout, cf_param
 // ------------------------------------------------------------------------------------
 // lifetime
 // ------------------------------------------------------------------------------------
+static int embed_dense_alloc(cf_handle* h);      // buffers of the all-rows Embedding path (end of this file)
+extern "C" void cf_destroy(cf_handle* h);
+
 extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_handle** out) {
     if (!cfg || !pe_host || !out) return fail("cf_create: null argument");
     int ndev = 0;
@@ -792,6 +795,10 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
                 if (e1 != hipSuccess || e2 != hipSuccess) h->attc2 = false;
             }
         }
+    }
+    if (h->embed_dense && embed_dense_alloc(h)) {      // the training path needs the all-rows buffers: allocate them now, not on the hot path
+        cf_destroy(h);
+        return -1;
     }
     if (const char* e = getenv("CF_XCD_MAP")) h->xcd_map = atoi(e) != 0;
     if (const char* e = getenv("CF_ATTC_CAP")) h->attc_cap = atoi(e);
@@ -1562,7 +1569,6 @@ extern "C" int cf_backward_from(cf_handle* h, const cf_batch* bt, const float* d
 // hipGraph capture of launch sequences (the per-step sequence is static)
 // ------------------------------------------------------------------------------------
 extern "C" int cf_capture_begin(cf_handle* h, void* stream) {
-    if (h && h->embed_dense) return fail("cf_capture_begin: embed.n_layers > 1 runs the all-rows Embedding path, whose table uploads synchronise the stream: not capturable, launch eagerly");
     if (!h) return fail("null handle");
     if (h->capturing) return fail("cf_capture_begin: already capturing");
     h->cap = cf_handle::Replay();
@@ -2016,24 +2022,13 @@ static int dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const floa
     const long long rq = (long long)N * Lq, rk = (long long)N * Lk;
     if (rq > 0x7fffffffLL / 256 || rk > 0x7fffffffLL / 256) return fail("cf_op_dense_layer_fwd: too many rows");
     const DenseWs L = dense_ws(N, Lq, Lk, dff, train);
-    RetileUnit* units_d = reinterpret_cast<RetileUnit*>(ws + L.tab);
-    // tiled copies of the five weights: the sources are separate tensors, so each gets its own launch
+    // tiled copies of the five weights (no table: workgroup b of a launch takes rows 16 b .. of its matrix)
     struct Job { const float* src; float* dst; int rows, K; } jobs[5] = {{w->wq, ws + L.wq_t, 128, 128}, {w->wkv, ws + L.wkv_t, 256, 128},
                                                                          {w->wo, ws + L.wo_t, 128, 128}, {w->w1, ws + L.w1_t, dff, 128},
                                                                          {w->w2, ws + L.w2_t, 128, dff}};
-    std::vector<RetileUnit> units;
-    int first[6] = {0};
     for (int j = 0; j < 5; ++j) {
-        for (int n0 = 0; n0 < jobs[j].rows; n0 += 16) units.push_back(RetileUnit{(long long)n0 * jobs[j].K, 0, jobs[j].K, jobs[j].rows, n0, 0});
-        first[j + 1] = (int)units.size();
-    }
-    if (units.size() * sizeof(RetileUnit) > kDenseTab * sizeof(float)) return fail("cf_op_dense_layer_fwd: unit table overflow");
-    HIP_TRY(hipMemcpyAsync(units_d, units.data(), units.size() * sizeof(RetileUnit), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));      // `units` is a host temporary
-    for (int j = 0; j < 5; ++j) {
-        hipLaunchKernelGGL(k_retile, dim3(first[j + 1] - first[j]), dim3(256), 0, st, jobs[j].src, jobs[j].dst, (float*)nullptr,
-                           (const RetileUnit*)(units_d + first[j]));
-        LAUNCH_CHECK("k_retile<dense layer>");
+        hipLaunchKernelGGL(k_retile_rows, dim3(jobs[j].rows / 16), dim3(256), 0, st, jobs[j].src, jobs[j].dst, jobs[j].K);
+        LAUNCH_CHECK("k_retile_rows<dense layer>");
     }
     auto linear = [&](const float* x, const float* wt, float* out, long long rows, int nout) {
         LinArgs a;
@@ -2117,22 +2112,15 @@ extern "C" int cf_op_dense_layer_fwd_train(const cf_dense_layer* w, const float*
 static int dense_wgrad(const float* dY, int lddy, const float* X, int ldx, long long rows, float* dW, int N_, int K_, float* part,
                        WgTile* tiles_d, CsTile* cs_d, hipStream_t st) {
     const int splits = (int)((rows + kDenseSplitRows - 1) / kDenseSplitRows);
-    std::vector<WgTile> tiles;
-    for (int s = 0; s < splits; ++s) {
-        const long long r0 = (long long)s * kDenseSplitRows;
-        const int m = (int)std::min<long long>(kDenseSplitRows, rows - r0);
-        push_wg(tiles, wg1(dY + r0 * lddy, lddy, X + r0 * ldx, ldx, m, part + (size_t)s * N_ * K_, K_, N_, K_));
-    }
-    std::vector<CsTile> cs;
-    push_cs(cs, part, N_ * K_, N_ * K_, splits, 1, dW);
-    if (tiles.size() * sizeof(WgTile) + cs.size() * sizeof(CsTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64)
+    const int ntiles = ((N_ + 63) / 64) * ((K_ + 63) / 64) * splits, ncs = (N_ * K_ + 63) / 64;
+    if ((size_t)ntiles * sizeof(WgTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64 || (size_t)ncs * sizeof(CsTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64)
         return fail("cf_op_dense_layer_bwd: tile table overflow");
-    HIP_TRY(hipMemcpyAsync(tiles_d, tiles.data(), tiles.size() * sizeof(WgTile), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(cs_d, cs.data(), cs.size() * sizeof(CsTile), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    hipLaunchKernelGGL(k_wgrad, dim3((int)tiles.size()), dim3(256), 0, st, (const WgTile*)tiles_d, 1);
+    DenseWgTab tb{dY, X, part, dW, tiles_d, cs_d, rows, lddy, ldx, N_, K_, splits, kDenseSplitRows};
+    hipLaunchKernelGGL(k_dense_wg_tables, dim3(std::max(1, std::min(64, (ntiles + 255) / 256))), dim3(256), 0, st, tb);
+    LAUNCH_CHECK("k_dense_wg_tables");
+    hipLaunchKernelGGL(k_wgrad, dim3(ntiles), dim3(256), 0, st, (const WgTile*)tiles_d, 1);
     LAUNCH_CHECK("k_wgrad<dense layer>");
-    hipLaunchKernelGGL(k_colsum, dim3((int)cs.size()), dim3(256), 0, st, (const CsTile*)cs_d, 1);
+    hipLaunchKernelGGL(k_colsum, dim3(ncs), dim3(256), 0, st, (const CsTile*)cs_d, 1);
     LAUNCH_CHECK("k_colsum<dense layer>");
     return 0;
 }
@@ -2244,29 +2232,31 @@ extern "C" int cf_op_dense_layer_bwd(const cf_dense_layer* w, const float* x_q, 
         const int nchunks = (tiles_q + kChunkRows - 1) / kChunkRows;
         float* part2 = ws + L.wpart;                 // free again: the weight gradients above are done with it
         if ((long long)nchunks * pw > (long long)L.splits * 256 * 128) return fail("cf_op_dense_layer_bwd: chunk buffer too small");
-        {
-            std::vector<CsTile> cs1;
-            for (int ch = 0; ch < nchunks; ++ch) {
-                const int rows = std::min(kChunkRows, tiles_q - ch * kChunkRows);
-                push_cs(cs1, pp + (size_t)ch * kChunkRows * pw, pw, pw, rows, 1, part2 + (size_t)ch * pw);
-            }
-            if (cs1.size() * sizeof(CsTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64) return fail("cf_op_dense_layer_bwd: tile table overflow");
-            HIP_TRY(hipMemcpyAsync(tiles_d, cs1.data(), cs1.size() * sizeof(CsTile), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            hipLaunchKernelGGL(k_colsum, dim3((int)cs1.size()), dim3(256), 0, st, (const CsTile*)tiles_d, 1);
-            LAUNCH_CHECK("k_colsum<dense layer bias, stage 1>");
+        const int per = (pw + 63) / 64, n1 = nchunks * per;
+        int n2 = 0;
+        DenseCsTab tb;
+        tb.partial = pp;
+        tb.part2 = part2;
+        tb.cs1 = reinterpret_cast<CsTile*>(tiles_d);
+        tb.cs2 = cs_d;
+        tb.tiles_q = tiles_q;
+        tb.chunk_rows = kChunkRows;
+        tb.nchunks = nchunks;
+        tb.pw = pw;
+        const int offs[7] = {0, 128, 256, 384, 384 + dff, 512 + dff, 640 + dff}, ncl[7] = {kD, kD, kD, dff, kD, kD, kD};
+        float* dsts[7] = {g->ln2_g, g->ln2_b, g->b2, g->b1, g->ln1_g, g->ln1_b, g->bo};
+        for (int k = 0; k < 7; ++k) {
+            tb.off[k] = offs[k];
+            tb.ncols[k] = ncl[k];
+            tb.dst[k] = dsts[k];
+            n2 += (ncl[k] + 63) / 64;
         }
-        std::vector<CsTile> cs;
-        push_cs(cs, part2 + 0, pw, kD, nchunks, 1, g->ln2_g);
-        push_cs(cs, part2 + 128, pw, kD, nchunks, 1, g->ln2_b);
-        push_cs(cs, part2 + 256, pw, kD, nchunks, 1, g->b2);
-        push_cs(cs, part2 + 384, pw, dff, nchunks, 1, g->b1);
-        push_cs(cs, part2 + 384 + dff, pw, kD, nchunks, 1, g->ln1_g);
-        push_cs(cs, part2 + 512 + dff, pw, kD, nchunks, 1, g->ln1_b);
-        push_cs(cs, part2 + 640 + dff, pw, kD, nchunks, 1, g->bo);
-        HIP_TRY(hipMemcpyAsync(cs_d, cs.data(), cs.size() * sizeof(CsTile), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        hipLaunchKernelGGL(k_colsum, dim3((int)cs.size()), dim3(256), 0, st, (const CsTile*)cs_d, 1);
+        if ((size_t)n1 * sizeof(CsTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64) return fail("cf_op_dense_layer_bwd: tile table overflow");
+        hipLaunchKernelGGL(k_dense_cs_tables, dim3(std::max(1, std::min(64, (n1 + 255) / 256))), dim3(256), 0, st, tb);
+        LAUNCH_CHECK("k_dense_cs_tables");
+        hipLaunchKernelGGL(k_colsum, dim3(n1), dim3(256), 0, st, (const CsTile*)tb.cs1, 1);
+        LAUNCH_CHECK("k_colsum<dense layer bias, stage 1>");
+        hipLaunchKernelGGL(k_colsum, dim3(n2), dim3(256), 0, st, (const CsTile*)cs_d, 1);
         LAUNCH_CHECK("k_colsum<dense layer bias>");
     }
     return 0;

@@ -1590,6 +1590,73 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
         }
     }
 }
+// the same tiling of a stand-alone row-major matrix W[rows][K] (rows, K multiples of 16): workgroup b takes rows 16 b ..
+__global__ __launch_bounds__(256) void k_retile_rows(const float* __restrict__ src, float* __restrict__ dst, int K) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* sp = src + (size_t)blockIdx.x * 16 * K + (size_t)r * K + q * 4;
+    float* dp = dst + (size_t)blockIdx.x * 16 * K + lane * 4;
+    for (int kt = w; kt < K / 16; kt += 4) stg4(dp + (size_t)kt * 256, ldg4(sp + kt * 16));
+}
+
+// Tile tables of the dense layer's split-K weight gradients, written ON the device (the arguments travel by value, so the
+// launch can be captured; an upload from a host temporary needs a stream synchronisation per call).  Same entries and
+// order as push_wg / push_cs on the host: tile t = (split, n0 / 64, k0 / 64).
+struct DenseWgTab {
+    const float* dY;
+    const float* X;
+    float* part;
+    float* dW;
+    WgTile* tiles;
+    CsTile* cs;
+    long long rows;
+    int lddy, ldx, N_, K_, splits, split_rows;
+};
+__global__ __launch_bounds__(256) void k_dense_wg_tables(DenseWgTab a) {
+    const int tn = (a.N_ + 63) / 64, tk = (a.K_ + 63) / 64, per = tn * tk, nt = per * a.splits;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < nt; t += gridDim.x * 256) {
+        const int s = t / per, rem = t - s * per;
+        const long long r0 = (long long)s * a.split_rows;
+        WgTile w;
+        for (int i = 0; i < 4; ++i) w.seg[i] = WgSeg{nullptr, nullptr, 0, 0, 0};
+        w.seg[0] = WgSeg{a.dY + r0 * a.lddy, a.X + r0 * a.ldx, a.lddy, a.ldx, (int)min((long long)a.split_rows, a.rows - r0)};
+        w.nseg = 1;
+        w.C = a.part + (size_t)s * a.N_ * a.K_;
+        w.ldc = a.K_;
+        w.Nn = a.N_;
+        w.Kk = a.K_;
+        w.n0 = (rem / tk) * 64;
+        w.k0 = (rem % tk) * 64;
+        a.tiles[t] = w;
+    }
+    const int ncs = (a.N_ * a.K_ + 63) / 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ncs; i += gridDim.x * 256)
+        a.cs[i] = CsTile{a.part, a.dW, a.N_ * a.K_, a.N_ * a.K_, i * 64, a.splits, 1, nullptr};
+}
+// Column-sum tables of the dense layer's bias / LayerNorm gradients: stage 1 sums chunks of `chunk_rows` partial rows
+// (width pw) into part2[chunk][pw]; stage 2 sums the chunk rows of seven column ranges into their gradient tensors.
+struct DenseCsTab {
+    const float* partial;
+    float* part2;
+    CsTile* cs1;
+    CsTile* cs2;
+    int tiles_q, chunk_rows, nchunks, pw;
+    int off[7], ncols[7];
+    float* dst[7];
+};
+__global__ __launch_bounds__(256) void k_dense_cs_tables(DenseCsTab a) {
+    const int per = (a.pw + 63) / 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.nchunks * per; i += gridDim.x * 256) {
+        const int ch = i / per, c0 = (i - ch * per) * 64;
+        const int rows = min(a.chunk_rows, a.tiles_q - ch * a.chunk_rows);
+        a.cs1[i] = CsTile{a.partial + (size_t)ch * a.chunk_rows * a.pw, a.part2 + (size_t)ch * a.pw, a.pw, a.pw, c0, rows, 1, nullptr};
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int n = 0;
+        for (int k = 0; k < 7; ++k)
+            for (int c0 = 0; c0 < a.ncols[k]; c0 += 64) a.cs2[n++] = CsTile{a.part2 + a.off[k], a.dst[k], a.pw, a.ncols[k], c0, a.nchunks, 1, nullptr};
+    }
+}
+
 }  // namespace cf
 
 #include "cf_reg_fused.h"

@@ -151,8 +151,6 @@ class Trainer:
                  overlap_allreduce=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
-        if model._kws[0]["n_layers"] > 1:
-            self.use_graph = False      # the all-rows Embedding path uploads tile tables per call: eager launches only
         self.dp = world_size > 1 or process_group is not None
         # Data parallel: the early (Regulation + head) bucket's all-reduce normally runs on the side stream UNDER the Pairwise +
         # Embedding backward.  Those kernels are latency-bound and sensitive to co-running work (a weight-gradient launch

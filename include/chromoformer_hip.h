@@ -172,7 +172,7 @@ int cf_stream_wait(cf_handle* h, void* waiter, void* signaller);
  * cf_op_dense_layer_fwd per Embedding layer -- which is also what cf_forward / cf_backward run for the whole Embedding
  * stack when embed.n_layers > 1 (keys and values of a layer are then all rows of the previous one).  Pad masks: the full
  * [B,1,1,L,L] tensor (mask stride L*L) is honoured entry by entry; a compact centre row is expanded as the dataset's
- * structured mask not(valid x valid).  Forward only; synchronises the stream (not capturable). */
+ * structured mask not(valid x valid).  Forward only. */
 int cf_embed_full(cf_handle* h, const cf_batch* batch, float* const* out, void* stream);
 
 /* ---- hipGraph capture ---------------------------------------------------------------- */
@@ -235,7 +235,8 @@ int cf_op_dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const float
  * (cf_op_dense_layer_train_workspace floats); cf_op_dense_layer_bwd turns dy [N*Lq, 128] into dx_q [N*Lq, 128],
  * dx_kv [N*Lk, 128] (a self-attention caller adds the two) and the gradients of all twelve tensors (`grads`, same
  * shapes as the weights, overwritten).  `tables`: device scratch of 4 MiB for the tile tables.  Weight gradients
- * are split-K sums in a fixed order: bit-reproducible.  Synchronises the stream while it uploads the tables. */
+ * are split-K sums in a fixed order: bit-reproducible.  The tables are written by a device kernel from by-value arguments:
+ * nothing synchronises, the call can be captured. */
 typedef struct cf_dense_layer_grads {
     float *wq, *wkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
 } cf_dense_layer_grads;

@@ -58,19 +58,26 @@ def test_two_embedding_layers_forward_backward_adamw(reg):
     assert max((sd[k].cpu() - P[k].detach()).abs().max().item() for k in P) < 2e-5
 
 
-def test_trainer_runs_the_all_rows_path_eagerly():
+def test_trainer_replays_the_all_rows_path_from_a_graph():
+    """The dense-layer operators build their tile tables on the device from by-value arguments: nothing synchronises, so the
+    step with two Embedding layers is captured and replayed like the default one -- bit-identical to eager launches."""
     from chromoformer_amd import ChromoformerClassifier
     from chromoformer_amd.engine import Trainer
-    model = ChromoformerClassifier(embed_kws=CFG2["embed"], seed=42, max_batch=4).cuda(0)
-    tr = Trainer(model, lr=3e-5)
-    assert tr.use_graph is False
-    slot = tr.stage(orc.synthetic_batch(4, seed=2, regime="dense"))
-    losses = []
-    for _ in range(3):
-        _, loss = tr.step(slot)
-        tr.stream.synchronize()
-        losses.append(float(loss))
-    assert losses[2] < losses[0] and all(np.isfinite(losses))
+    res = []
+    for graph in (False, True):
+        model = ChromoformerClassifier(embed_kws=CFG2["embed"], seed=42, max_batch=4).cuda(0)
+        tr = Trainer(model, lr=3e-5, use_graph=graph)
+        slot = tr.stage(orc.synthetic_batch(4, seed=2, regime="dense"))
+        losses = []
+        for _ in range(3):
+            _, loss = tr.step(slot)
+            tr.stream.synchronize()
+            losses.append(float(loss))
+        assert losses[2] < losses[0] and all(np.isfinite(losses))
+        res.append((losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
 @pytest.mark.parametrize("compact", [False, True])
