@@ -121,7 +121,7 @@ _lib = None
 
 def build(force=False, verbose=False):
     """Compile csrc/ for gfx950 into libchromoformer_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("cf_api.hip", "cf_kernels.h", "cf_reg_fused.h", "cf_attc2.h", "cf_head.h", "cf_attn.h", "cf_bin.h")]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "chromoformer_hip.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH

@@ -22,6 +22,9 @@
 // Reference math: modules.py:28-88 (self-attention block with gate and frequency bias), 100-101 (FeedForward),
 // 121-124 (layer stack).  Six workgroup barriers per layer and direction.
 #pragma once
+#ifndef CF_STAGGER      // 1: waves 4..7 run the attention BEFORE the gate chunk (opposite to their SIMD partner).  Measured: no change
+#define CF_STAGGER 0    // (116.8 vs 117.0 us, three interleaved rounds) -- the two waves of a SIMD drift apart on their own.
+#endif
 #ifndef CF_QPRE
 #define CF_QPRE 7
 #endif
@@ -257,26 +260,29 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         float* hq = P.hq + hq0;
         float* ag = P.a + row0 * kRDm + w * 32;
         float* hg = P.hdn + row0 * DFF + w * HW;
-        // ---- q | k | v | gate of head w: 4 chunks x (2 tiles x K = 128), one ring over all 32 units
-        f32x4 vacc[2], gacc[2];
+        // ---- q | k | v | gate of head w: 4 chunks x (2 tiles x K = 128), one ring over all 32 units; then the attention of the
+        //      head (modules.py:58-81), wave-local.  (CF_STAGGER: the two waves of a SIMD, w and w + 4, can run the gate chunk
+        //      and the attention in opposite orders; see the macro for the measurement.)
+        f32x4 vacc[2], gacc[2], o[2];
         BBuf<8, 8> bwo;
-        {
-            const float* qb = P.watt_t + wq;
-            const float* ap = xs + oALD;
-            float4 an = lds4(ap);
-            f32x4 acc[2];
+        const float* qb = P.watt_t + wq;
+        const float* ap = xs + oALD;
+        float4 an = lds4(ap);
+        f32x4 pacc[2];
+        auto units = [&](auto u0_c, auto u1_c) {
+            constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
+            for (int u = U0; u < U1; ++u) {
                 if (u + kQPre < 32) {
                     rq.s[(u + kQPre) % 8][0] = ldg_blk(qb, wl, qidx(u + kQPre, 0));
                     rq.s[(u + kQPre) % 8][1] = ldg_blk(qb, wl, qidx(u + kQPre, 1));
                 }
                 if (u >= 24) b_issue1(bwo, P.wo_t + wo16, wl, idx_one, u - 24);      // out-projection weights, spread over the gate chunk
                 __builtin_amdgcn_sched_barrier(0);
-                if ((u & 7) == 0) zero_acc(acc);
+                if ((u & 7) == 0) zero_acc(pacc);
                 const float4 av = an;
                 an = lds4(ap + ((u + 1) & 7) * 16);
-                mma_unit(av, av, rq.s[u % 8][0], rq.s[u % 8][1], acc[0], acc[1]);
+                mma_unit(av, av, rq.s[u % 8][0], rq.s[u % 8][1], pacc[0], pacc[1]);
                 if ((u & 7) == 7) {
                     const int c = u >> 3;
                     if (c < 2) {            // q, k: row-major into the wave's patch (operands of the scores), transposed tiles to global
@@ -284,36 +290,34 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                            for (int ii = 0; ii < 4; ++ii) dst[ii * 36 + t * 16] = acc[t][ii];
+                            for (int ii = 0; ii < 4; ++ii) dst[ii * 36 + t * 16] = pacc[t][ii];
                             float* tp_ = lane_at(sbase(hq, (c == 0 ? kHqQ : kHqK) + t * 256), bT);      // (scalar bases are formed outside the conditionals)
-                            if (SAVE && rok[0]) stg4(tp_, acc4(acc[t]));
+                            if (SAVE && rok[0]) stg4(tp_, acc4(pacc[t]));
                         }
                     } else if (c == 2) {    // v: stays in registers (B operand of p v); rows to global for the backward
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            vacc[t] = acc[t];
+                            vacc[t] = pacc[t];
                             if (SAVE) {
                                 float* vp_ = lane_at(sbase(hq, kHqV), bV);
 #pragma unroll
                                 for (int ii = 0; ii < 4; ++ii)
-                                    if (rok[ii]) stg(vp_ + ii * 32 + t * 16, acc[t][ii]);
+                                    if (rok[ii]) stg(vp_ + ii * 32 + t * 16, pacc[t][ii]);
                             }
                         }
                     } else {                // gate
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            gacc[t] = acc[t];
+                            gacc[t] = pacc[t];
                             float* tp_ = lane_at(sbase(hq, kHqG + t * 256), bT);
-                            if (SAVE && rok[0]) stg4(tp_, acc4(acc[t]));
+                            if (SAVE && rok[0]) stg4(tp_, acc4(pacc[t]));
                         }
                     }
                 }
             }
-        }
-        CF_STAMP8(1);
-        // ---- attention of head w (modules.py:58-81), wave-local
-        wave_lds_sync();
-        {
+        };
+        auto attend = [&]() {      // scores, mask, softmax, p v of the head -> o
+            wave_lds_sync();
             f32x4 sc[2];
             zero_acc(sc);
             mma_unit(lds4(qs + oA36), lds4(qs + oA36 + 16), lds4(ks + oA36), lds4(ks + oA36 + 16), sc[0], sc[1]);
@@ -333,22 +337,30 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
             if (SAVE && rok[0] && lr < T) stg4(pp_, make_float4(p[0], p[1], p[2], p[3]));      // p^T tile
             wave_lds_sync();
             const float4 pa = lds4(ps + oA20);      // A[i = lr][j = 4 lq + m]; B[j = 4 lq + m][d] = the v accumulators
-            f32x4 o[2];
             zero_acc(o);
             mma_unit(pa, pa, acc4(vacc[0]), acc4(vacc[1]), o[0], o[1]);
+        };
+        units(std::integral_constant<int, 0>{}, std::integral_constant<int, 24>{});
+        if (CF_STAGGER && w >= 4) {
+            attend();
+            units(std::integral_constant<int, 24>{}, std::integral_constant<int, 32>{});
+        } else {
+            units(std::integral_constant<int, 24>{}, std::integral_constant<int, 32>{});
+            CF_STAMP8(1);
+            attend();
+        }
+        {
             float* ap_ = lane_at(sbase(ag, 0), zA);      // (scalar bases are formed outside the per-row conditionals)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float val[4];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    val[ii] = o[t][ii] * fast_sigmoid(gacc[t][ii]);
+                    const float val = o[t][ii] * fast_sigmoid(gacc[t][ii]);
                     if (rok[ii]) {
-                        as_[oDLW + ii * LW + t * 16] = val[ii];
-                        if (SAVE) stg(ap_ + ii * kRDm + t * 16, val[ii]);
+                        as_[oDLW + ii * LW + t * 16] = val;
+                        if (SAVE) stg(ap_ + ii * kRDm + t * 16, val);
                     }
                 }
-            }
         }
         LnParams ln1, ln2;
         if (w < 4) ln1 = ln_params_load(P.g1, P.be1);
