@@ -10,6 +10,18 @@
 // positional table become [16 x 128] . [128 x L] and [16 x L] . [L x 128] products and each table
 // element fetched from L2 is used for 16 rows instead of 2.  The 7-mark features of the 8 regions
 // (the only HBM stream) are staged once in LDS and serve both feature passes.
+//
+// Phases of a workgroup (barriers b1 .. b5; per-wave shader-clock stamps: tools/attc_stamps.py):
+//   stage   small loads (operand rows, Wlp, masks) -> LDS; the feature strips and PE^T chunk 0 are requested behind them   | b1
+//   (2a)    t = vin . PE^T on the matrix cores (wave = 64-column block), u = vin Wlp by the last wave; features -> LDS;
+//           pass 5's PE operand is requested where the early waves wait for the late ones                                  | b2
+//   (2b)    epilogue in the accumulator layout: + f.u, scale, mask; per (row, block) softmax statistics (fwd) / <p,dp> (bwd)| b3
+//   (3)     every lane combines the <= 16 block statistics of its rows: p / ds -> score tile (+ global p)                  | b4
+//   (4),(5) w = sum_j sc_j f_j (VALU), out = sc . PE on the matrix cores (2 column groups x 4 K quarters)                  | b5
+//   tail    K-split partials through LDS, each wave finishes a quarter of the rows: + Wlp w, store
+// Measured at L = 400, 8 regions (cycles of the 2 GHz shader clock): the two matrix passes are bound by the MFMA pipe (2 x ~9 K
+// with two waves per SIMD, no-load experiment: 9 K), the table loads add ~2.5 K, the first barrier costs the 3-4 K of one
+// HBM round trip; 43 K -> 35 K (backward), 51 K -> 47 K (forward) against the version that staged everything up front.
 #pragma once
 #include <type_traits>
 
@@ -33,8 +45,8 @@ struct Attc2Args {
 };
 #define CF_STAMP2(slot)                                                                                   \
     do {                                                                                                  \
-        if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                              \
-            a.tdbg[(BWD ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime();                               \
+        if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)                       \
+            a.tdbg[(threadIdx.x >> 6) * 32 + (BWD ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime();      \
     } while (0)
 constexpr int kAGMax = 8;                                // regions per workgroup: 8, 4, 2 or 1 (template parameter AG)
 constexpr int kAT = 512;                                 // threads per workgroup (8 waves)
@@ -102,24 +114,30 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 
     CF_STAMP2(0);
     const int nblk = (L + 63) / 64;
-    FragNN<4, 8> ft0;                         // PE^T operand ring of this wave's first block of pass 2
-    // ---- stage: features (the HBM stream), operand rows, masks
+    float* stat_s = red_s;                    // [2][16][16] per-(row, column block) softmax statistics (free until pass 5's reduction)
+    static_assert(2 * kTile * 16 <= kTile * LD, "statistics fit in the K-split partial buffer");
+    // The workgroup's time goes to the CU's vector-memory path (64 bytes per clock; ~620 KB per L = 400 workgroup, most of it the
+    // two positional tables out of L2) and to its matrix pipes; a wave stalls at ISSUE once the path's queue is full.  So the
+    // first barrier stands in front of the bulk loads, not behind them: only the operand rows, Wlp and the masks are fetched
+    // before it, the table operand and the features are requested behind it and the products start on the first chunk to land.
+    FragNN<4, 8> ft0;                         // PE^T operand of this wave's first column block of pass 2: all of K = 128 in registers
+    const float* fg = a.feats[r] + (size_t)n0 * L * F;
+    const int nf = nreg * L * F;
+    constexpr int NFL = AG == 8 ? 12 : AG == 4 ? 6 : AG == 2 ? 3 : 2;         // 16-byte feature loads per thread: L <= 438 (AG = 1: 585)
+    const bool f16b = ((L * F) & 3) == 0 && kAG * L * F <= NFL * 4 * kAT;     // one round of copies (L = 400, 8 regions: 22,400 of 24,576 floats)
+    float4 fv12[NFL];
     {
-        const float* fg = a.feats[r] + (size_t)n0 * L * F;
-        const int nf = nreg * L * F;
         const uint8_t* mg = a.mask[r] + (size_t)n0 * a.mstride[r];
         const bool words = ((L | (int)a.mstride[r] | (int)(reinterpret_cast<uintptr_t>(a.mask[r]))) & 3) == 0;
         const int LW = Lpad >> 2, lw = L >> 2;
         constexpr int MW = kAG >= 2 ? kAG / 2 : 1;       // mask words per thread: kAG * (Lpad / 4 <= 256) / 512
-        // every load of the stage is issued before the first LDS store waits for one (loads return in order, so a
-        // load -> store -> load -> store sequence would pay the L2 latency once per array)
-        const float wl0 = (tid & 7) < F ? ldg(a.wlp[r] + (tid >> 3) * F + (tid & 7)) : 0.f;
-        const float wl1 = (tid & 7) < F ? ldg(a.wlp[r] + ((tid + kAT) >> 3) * F + (tid & 7)) : 0.f;      // kD * 8 = 2 * kAT entries
         float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
         {
             const int m = tid >> 5, c4 = tid & 31;               // 16 rows x 32 float4
             if ((m >> 1) < nreg) vv = ldg4(a.vin[r] + (size_t)n0 * 256 + m * kD + c4 * 4);
         }
+        const float wl0 = (tid & 7) < F ? ldg(a.wlp[r] + (tid >> 3) * F + (tid & 7)) : 0.f;
+        const float wl1 = (tid & 7) < F ? ldg(a.wlp[r] + ((tid + kAT) >> 3) * F + (tid & 7)) : 0.f;      // kD * 8 = 2 * kAT entries
         uint32_t mwv[MW];
         if (words) {
 #pragma unroll
@@ -128,31 +146,31 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
                 mwv[k] = (idx < kAG * LW && sreg < nreg && jw < lw) ? *(const CF_GLOBAL uint32_t*)(mg + (size_t)sreg * a.mstride[r] + 4 * jw) : 0x01010101u;
             }
         }
-        if (((L * F) & 3) == 0) {                      // 16-byte copies, 12 in flight per thread
-            const int n4 = (kAG * L * F) >> 2, nf4 = nf >> 2;
-            {                                          // first round: covers L*F <= 3072 (L = 400: 2800)
-                float4 v[12];
+        // the feature strips (the HBM stream: longest latency, needed last) and the first chunk of the PE^T operand are requested
+        // here, behind the small loads the barrier waits for and in front of it: ~27 KB per wave, about as long to issue as the
+        // operand rows take to arrive.  Always NFL feature loads, no branch around them and no select behind them: the wait counts
+        // stay exact (strips past the end re-read the last one; when the 16-byte path does not apply the values are not used).
+        {
+            const float* fa = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(fg) & ~(uintptr_t)15);
+            const int last4 = f16b ? (nf >> 2) - 1 : max((nf >> 2) - 2, 0);      // (aligned down: stay one strip inside)
 #pragma unroll
-                for (int u = 0; u < 12; ++u) {
-                    const int i = tid + u * kAT;
-                    v[u] = (u * kAT < n4 && i < nf4) ? ldg4(fg + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 12; ++u) {
-                    const int i = tid + u * kAT;
-                    if (i < n4) *reinterpret_cast<float4*>(feats_s + (size_t)i * 4) = v[u];
-                }
-            }
-            for (int i = tid + 12 * kAT; i < n4; i += kAT)
-                *reinterpret_cast<float4*>(feats_s + (size_t)i * 4) = i < nf4 ? ldg4(fg + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid < 8) feats_s[kAG * L * F + tid] = 0.f;
-        } else {
-            for (int i = tid; i < kAG * L * F + 8; i += kAT) feats_s[i] = i < nf ? ldg(fg + i) : 0.f;
+            for (int u = 0; u < NFL; ++u) fv12[u] = ldg4(fa + (size_t)min(tid + u * kAT, last4) * 4);
+            const float* bm_ = a.pet[r] + min(w, nblk - 1) * 64;
+            ft0.bp = bm_ + (size_t)(lq * 4) * LT + 4 * lr;
+            ft0.ldb = LT;
+            frag_chunk_nn(ft0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        stat_s[tid] = tid < kTile * 16 ? 0.f : -INFINITY;      // block sums | block maxima of column blocks nobody owns
+        if (tid < kTile) u_s[tid * 8 + 7] = 0.f;               // (mark 7 does not exist: the epilogue multiplies it by a zero feature)
+        {
+            const int m = tid >> 5;                                // zero tail of the score rows (K padding of pass 5)
+            for (int j = L + (tid & 31); j < Lpad; j += 32) sc_s[m * LS + j] = 0.f;
+        }
+        *reinterpret_cast<float4*>(vin_s + (tid >> 5) * LD + (tid & 31) * 4) = vv;
         static_assert(kD * 8 == 2 * kAT, "wlp staging assumes two entries per thread");
         wlp_s[tid] = wl0;
         wlp_s[tid + kAT] = wl1;
-        *reinterpret_cast<float4*>(vin_s + (tid >> 5) * LD + (tid & 31) * 4) = vv;
         if (words) {
             uint32_t* mk_w = reinterpret_cast<uint32_t*>(mk_s);
 #pragma unroll
@@ -163,209 +181,251 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
                 for (int j = tid; j < Lpad; j += kAT)
                     mk_s[s * Lpad + j] = (s < nreg && j < L) ? *(const CF_GLOBAL uint8_t*)(mg + (size_t)s * a.mstride[r] + j) : (uint8_t)1;
         }
-        {
-            const int m = tid >> 5;                                // zero tail of the score rows (K padding of pass 5)
-            for (int j = L + (tid & 31); j < Lpad; j += 32) sc_s[m * LS + j] = 0.f;
-        }
-        // PE^T operand ring of pass 2: requested last (loads return in order: anything issued before the staging loads
-        // would have to land before their data can be stored), in flight across the barrier and pass 1
-        frag_load_nn(ft0, a.pet[r] + min(w, nblk - 1) * 64, LT);
     }
+    CF_STAMP2(10);
     __syncthreads();
     CF_STAMP2(1);
-    // ---- (1) u[m][f] = sum_e vin[m][e] Wlp[e][f]: thread = (m, f, quarter of e)
-    {
-        const int m = tid >> 5, f = (tid >> 2) & 7, part = tid & 3;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < kD / 4; ++i) {
-            const int e = part * (kD / 4) + i;
-            acc = fmaf(vin_s[m * LD + e], wlp_s[e * 8 + f], acc);
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        if (part == 0) u_s[m * 8 + f] = acc;
+    // ---- (1) u[m][f] = sum_e vin[m][e] Wlp[e][f] on the matrix cores, by the last wave (the one with the fewest column blocks):
+    //      one [16 x 128] . [128 x 16] tile whose B operand comes straight from global (columns f >= F repeat column F - 1 and
+    //      are not stored).  Its loads are issued first, so they return first.
+    float ub[32];
+    if (w == NW - 1) {
+        const float* wp_ = a.wlp[r] + (size_t)(lq * 4) * F + min(lr, F - 1);
+#pragma unroll
+        for (int st8 = 0; st8 < 8; ++st8)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ub[st8 * 4 + i] = ldg(wp_ + (size_t)(st8 * 16 + i) * F);
     }
+    // ---- (2a) t[m][j] = vin[m] . PE^T[:, j];  wave w takes column blocks w and w + 8 (L <= 1024).  Loads and products are
+    //      interleaved in program order (a wave that meets a full memory queue stalls where it stands).
+    f32x4 acc2[2][4];
+    zero_acc(acc2[0]);
+    zero_acc(acc2[1]);
+    {
+        const float* ap = vin_s + lr * LD + lq * 4;
+        auto products = [&](auto c_c) {
+            constexpr int c = decltype(c_c)::value;
+            if (w < nblk)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float4 av4 = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+                    const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float* bv = reinterpret_cast<const float*>(&ft0.ring[c][k][i]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[0][t] = mfma4(av[i], bv[t], acc2[0][t]);
+                    }
+                }
+        };
+        frag_chunk_nn(ft0, 1, 1);
+        frag_chunk_nn(ft0, 2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (w == NW - 1) {
+            f32x4 ua = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st8 = 0; st8 < 8; ++st8) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + st8 * 16);
+                ua = mfma4(av.x, ub[st8 * 4], ua);
+                ua = mfma4(av.y, ub[st8 * 4 + 1], ua);
+                ua = mfma4(av.z, ub[st8 * 4 + 2], ua);
+                ua = mfma4(av.w, ub[st8 * 4 + 3], ua);
+            }
+            if (lr < F)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) u_s[(lq * 4 + ii) * 8 + lr] = ua[ii];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        products(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        frag_chunk_nn(ft0, 3, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        products(std::integral_constant<int, 1>{});
+        products(std::integral_constant<int, 2>{});
+        products(std::integral_constant<int, 3>{});
+    }
+    if (w + NW < nblk) {
+        FragNN<4, 8> ft;
+        frag_load_nn(ft, a.pet[r] + (w + NW) * 64, LT);
+        frag_mma_nn(ft, vin_s, LD, acc2[1]);
+    }
+    CF_STAMP2(8);
+    // ---- features to LDS (behind the products)
+    if (f16b) {
+        const int n4 = (kAG * L * F) >> 2;
+#pragma unroll
+        for (int u = 0; u < NFL; ++u) {
+            const int i = tid + u * kAT;
+            if (i < n4) *reinterpret_cast<float4*>(feats_s + (size_t)i * 4) = fv12[u];
+        }
+        if (tid < 8) feats_s[kAG * L * F + tid] = 0.f;
+    } else {
+        for (int i = tid; i < kAG * L * F + 8; i += kAT) feats_s[i] = i < nf ? ldg(fg + i) : 0.f;
+    }
+    // pass 5's PE operand (2 column groups x 4 quarters of the bin range): requested here, where the waves that finished their
+    // products wait for the others anyway (the issue itself stalls ~3 K cycles on the memory queue); in flight across the
+    // epilogue, the softmax and pass 4
+    const int cg = w & 1, kh = w >> 1, kper = Lpad / 4;
+    FragNN<4, 8> fp5;
+    frag_load_nn_rt(fp5, a.pe[r] + (size_t)(kh * kper) * kD + cg * 64, kD, kper / 32);
+    CF_STAMP2(9);
     __syncthreads();
     CF_STAMP2(2);
-    // ---- (2) t[m][j] = vin[m] . PE^T[:, j]  (+ f_j . u[m]);  wave w takes column blocks w, w+8, ...
-    {
-        for (int jb = w; jb < nblk; jb += NW) {
-            f32x4 acc[4];
-            zero_acc(acc);
-            if (jb == w) frag_mma_nn(ft0, vin_s, LD, acc);
-            else {
-                FragNN<4, 8> ft;
-                frag_load_nn(ft, a.pet[r] + jb * 64, LT);
-                frag_mma_nn(ft, vin_s, LD, acc);
-            }
-            const int j0 = jb * 64 + 4 * lr;
+    // ---- (2b) epilogue of pass 2 in the accumulator layout (lane: rows 4 lq + ii, columns j0 .. j0 + 3 of its block):
+    //      + f_j . u[m]; forward: scale, mask, then the block's share of the softmax (block maximum, exponentials, block sum);
+    //      backward: the block's share of <p, dp>.  One barrier later every lane combines the <= 16 block statistics of its rows
+    //      and writes p (forward; also to global) / ds (backward) into the score tile, the A operand of pass 5.
+    float xs[2][4][4];                           // [block][ii][t]: exp(score - block maximum) (fwd) / dp (bwd)
+    float4 pv[2][4];                             // backward: saved p of the lane's entries
+    float bstat[2][4];                           // forward: block maximum of row ii
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {            // the lane's rows 4q..4q+3 = regions 2q, 2q+1 (two heads each)
-                const int s = lq * 2 + sp;
-                if (s >= kAG) continue;
-                float fv[4][8];                           // marks of bins j0..j0+3 of region s: 28 consecutive floats
-                if (j0 + 3 < L && F == 7) {
-                    const float4* fp4 = reinterpret_cast<const float4*>(feats_s + (size_t)(s * L + j0) * 7);
-                    float tmp[28];
+    for (int bi = 0; bi < 2; ++bi) {
+        const int jb = w + bi * NW;
+        if (jb >= nblk) continue;
+        const int j0 = jb * 64 + 4 * lr;
+        if (BWD) {
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        const float4 t4 = fp4[k];
-                        tmp[4 * k] = t4.x;
-                        tmp[4 * k + 1] = t4.y;
-                        tmp[4 * k + 2] = t4.z;
-                        tmp[4 * k + 3] = t4.w;
+            for (int ii = 0; ii < 4; ++ii) {
+                const int m = lq * 4 + ii;
+                pv[bi][ii] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((m >> 1) < nreg && (m >> 1) < kAG) {
+                    const float* pg = a.p[r] + ((size_t)n0 * 2 + m) * L;
+                    if (j0 + 3 < L && (L & 3) == 0) pv[bi][ii] = ldg4(pg + j0);
+                    else {
+                        if (j0 < L) pv[bi][ii].x = ldg(pg + j0);
+                        if (j0 + 1 < L) pv[bi][ii].y = ldg(pg + j0 + 1);
+                        if (j0 + 2 < L) pv[bi][ii].z = ldg(pg + j0 + 2);
+                        if (j0 + 3 < L) pv[bi][ii].w = ldg(pg + j0 + 3);
                     }
+                }
+            }
+        }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+        for (int sp = 0; sp < 2; ++sp) {            // the lane's rows 4q..4q+3 = regions 2q, 2q+1 (two heads each)
+            const int s = lq * 2 + sp;
+            if (s >= kAG) continue;
+            float fv[4][8];                           // marks of bins j0..j0+3 of region s: 28 consecutive floats
+            if (j0 + 3 < L && F == 7) {
+                const float4* fp4 = reinterpret_cast<const float4*>(feats_s + (size_t)(s * L + j0) * 7);
+                float tmp[28];
 #pragma unroll
-                        for (int f = 0; f < 8; ++f) fv[t][f] = f < 7 ? tmp[t * 7 + f] : 0.f;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int f = 0; f < 8; ++f) fv[t][f] = (j0 + t < L && f < F) ? feats_s[(size_t)(s * L + j0 + t) * F + f] : 0.f;
+                for (int k = 0; k < 7; ++k) {
+                    const float4 t4 = fp4[k];
+                    tmp[4 * k] = t4.x;
+                    tmp[4 * k + 1] = t4.y;
+                    tmp[4 * k + 2] = t4.z;
+                    tmp[4 * k + 3] = t4.w;
                 }
 #pragma unroll
-                for (int hd = 0; hd < 2; ++hd) {
-                    const int ii = sp * 2 + hd, m = lq * 4 + ii;
-                    const float4 u0 = *reinterpret_cast<const float4*>(u_s + m * 8), u1 = *reinterpret_cast<const float4*>(u_s + m * 8 + 4);
-                    float v[4];
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) fv[t][f] = f < 7 ? tmp[t * 7 + f] : 0.f;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) fv[t][f] = (j0 + t < L && f < F) ? feats_s[(size_t)(s * L + j0 + t) * F + f] : 0.f;
+            }
+            const uint32_t mw = *reinterpret_cast<const uint32_t*>(mk_s + s * Lpad + j0);      // j0 + 3 < Lpad (Lpad >= 64 nblk)
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                const int ii = sp * 2 + hd, m = lq * 4 + ii;
+                const float4 u0 = *reinterpret_cast<const float4*>(u_s + m * 8), u1 = *reinterpret_cast<const float4*>(u_s + m * 8 + 4);
+                float bm = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float x = acc2[bi][t][ii];
+                    x = fmaf(fv[t][0], u0.x, x);
+                    x = fmaf(fv[t][1], u0.y, x);
+                    x = fmaf(fv[t][2], u0.z, x);
+                    x = fmaf(fv[t][3], u0.w, x);
+                    x = fmaf(fv[t][4], u1.x, x);
+                    x = fmaf(fv[t][5], u1.y, x);
+                    x = fmaf(fv[t][6], u1.z, x);
+                    x = fmaf(fv[t][7], u1.w, x);
+                    if (!BWD) {
+                        x = x * a.rscale;
+                        if ((mw >> (8 * t)) & 0xffu) x = kMaskFill;
+                        if (j0 + t < L) bm = fmaxf(bm, x);
+                    }
+                    xs[bi][ii][t] = x;
+                }
+                float part;
+                if (!BWD) {
+                    bm = group16_max(bm);                    // finite: the block holds at least one column j < L
+                    part = 0.f;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int j = j0 + t;
-                        float x = acc[t][ii];
-                        x = fmaf(fv[t][0], u0.x, x);
-                        x = fmaf(fv[t][1], u0.y, x);
-                        x = fmaf(fv[t][2], u0.z, x);
-                        x = fmaf(fv[t][3], u0.w, x);
-                        x = fmaf(fv[t][4], u1.x, x);
-                        x = fmaf(fv[t][5], u1.y, x);
-                        x = fmaf(fv[t][6], u1.z, x);
-                        x = fmaf(fv[t][7], u1.w, x);
-                        if (!BWD) {
-                            x = x * a.rscale;
-                            if (mk_s[s * Lpad + min(j, Lpad - 1)]) x = kMaskFill;
-                        }
-                        v[t] = j < L ? x : 0.f;
+                        const float e = j0 + t < L ? __expf(xs[bi][ii][t] - bm) : 0.f;
+                        xs[bi][ii][t] = e;
+                        part += e;
                     }
-                    if (j0 < Lpad) *reinterpret_cast<float4*>(sc_s + m * LS + j0) = make_float4(v[0], v[1], v[2], v[3]);
+                    bstat[bi][ii] = bm;
+                } else {
+                    const float4 p4 = pv[bi][ii];
+                    part = (p4.x * xs[bi][ii][0] + p4.y * xs[bi][ii][1]) + (p4.z * xs[bi][ii][2] + p4.w * xs[bi][ii][3]);
+                }
+                part = group16_sum(part);
+                if (lr == 0) {
+                    stat_s[m * 16 + jb] = part;
+                    if (!BWD) stat_s[kTile * 16 + m * 16 + jb] = bm;
                 }
             }
         }
     }
     __syncthreads();
     CF_STAMP2(3);
-    const int cg = w & 1, kh = w >> 1, kper = Lpad / 4;      // pass 5: 2 column groups x 4 quarters of the bin range
-    FragNN<4, 8> fp5;
-    frag_load_nn_rt(fp5, a.pe[r] + (size_t)(kh * kper) * kD + cg * 64, kD, kper / 32);   // in flight across passes 3, 4
+    // ---- (3) softmax over the bins (fwd) / its backward (bwd): combine the block statistics of the lane's rows
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int m = lq * 4 + ii, s = m >> 1;
+        if (s >= kAG || w >= nblk) continue;
+        const bool present = s < nreg;
+        float fac[2] = {0.f, 0.f}, dot = 0.f;
+        const float bsum = stat_s[m * 16 + lr];      // lane lr <-> column block lr of row m (unowned blocks: sum 0, maximum -inf)
+        if (!BWD) {
+            const float bmax = stat_s[kTile * 16 + m * 16 + lr];
+            const float mx = group16_max(bmax);
+            const float z = group16_sum(bsum * __expf(bmax - mx));
+            const float rz = 1.0f / z;
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) fac[bi] = (w + bi * NW < nblk) ? __expf(bstat[bi][ii] - mx) * rz : 0.f;
+        } else {
+            dot = group16_sum(bsum);
+        }
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+            const int jb = w + bi * NW;
+            if (jb >= nblk) continue;
+            const int j0 = jb * 64 + 4 * lr;
+            float4 o;
+            if (!BWD) {
+                o = make_float4(xs[bi][ii][0] * fac[bi], xs[bi][ii][1] * fac[bi], xs[bi][ii][2] * fac[bi], xs[bi][ii][3] * fac[bi]);
+                if (present) {
+                    float* pg = a.p[r] + ((size_t)n0 * 2 + m) * L;
+                    if (j0 + 3 < L && (L & 3) == 0) stg4(pg + j0, o);
+                    else {
+                        if (j0 < L) stg(pg + j0, o.x);
+                        if (j0 + 1 < L) stg(pg + j0 + 1, o.y);
+                        if (j0 + 2 < L) stg(pg + j0 + 2, o.z);
+                        if (j0 + 3 < L) stg(pg + j0 + 3, o.w);
+                    }
+                }
+            } else {
+                const uint32_t mw = *reinterpret_cast<const uint32_t*>(mk_s + s * Lpad + j0);
+                const float4 p4 = pv[bi][ii];
+                o.x = (mw & 0xffu) ? 0.f : p4.x * (xs[bi][ii][0] - dot) * a.rscale;
+                o.y = (mw & 0xff00u) ? 0.f : p4.y * (xs[bi][ii][1] - dot) * a.rscale;
+                o.z = (mw & 0xff0000u) ? 0.f : p4.z * (xs[bi][ii][2] - dot) * a.rscale;
+                o.w = (mw & 0xff000000u) ? 0.f : p4.w * (xs[bi][ii][3] - dot) * a.rscale;      // j >= L: p = 0 there
+            }
+            *reinterpret_cast<float4*>(sc_s + m * LS + j0) = o;      // j0 + 3 < Lpad
+        }
+    }
     // LPR lanes per row m: 32 with all 16 rows live, a whole wave per row when at most 8 are
     constexpr int LPR = AG == 8 ? 32 : 64, LSH = AG == 8 ? 5 : 6;
     const int gm = tid >> LSH, sub = tid & (LPR - 1);
     const bool row_live = gm < 2 * kAG;
-    auto sum32 = [](float v) {
-        v = group16_sum(v);
-        v += __shfl_xor(v, 16, 64);
-        if (LPR == 64) v += __shfl_xor(v, 32, 64);
-        return v;
-    };
-    // ---- (3) softmax over the bins (fwd) / its backward (bwd): LPR lanes per row, each lane owns the 16-byte
-    //      strips j = 4*sub + 4*LPR*k; everything a lane needs is fetched before the arithmetic starts
-    auto softmax_pass = [&](auto kmax_c) {
-        constexpr int KMAX = decltype(kmax_c)::value;      // strips per lane
-        float* row = sc_s + gm * LS;
-        const bool present = row_live && (gm >> 1) < nreg;
-        const int nk = (L + 4 * LPR - 1) / (4 * LPR);
-        float4 xv[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (k < nk) xv[k] = *reinterpret_cast<const float4*>(row + 4 * sub + 4 * LPR * k);      // entries j >= L are 0
-        if (!BWD) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < nk) {
-                    const int j = 4 * sub + 4 * LPR * k;
-                    if (j < L) mx = fmaxf(mx, xv[k].x);
-                    if (j + 1 < L) mx = fmaxf(mx, xv[k].y);
-                    if (j + 2 < L) mx = fmaxf(mx, xv[k].z);
-                    if (j + 3 < L) mx = fmaxf(mx, xv[k].w);
-                }
-            mx = group16_max(mx);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            if (LPR == 64) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float z = 0.f;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < nk) {
-                    const int j = 4 * sub + 4 * LPR * k;
-                    xv[k].x = j < L ? __expf(xv[k].x - mx) : 0.f;
-                    xv[k].y = j + 1 < L ? __expf(xv[k].y - mx) : 0.f;
-                    xv[k].z = j + 2 < L ? __expf(xv[k].z - mx) : 0.f;
-                    xv[k].w = j + 3 < L ? __expf(xv[k].w - mx) : 0.f;
-                    z += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
-                }
-            z = sum32(z);
-            const float rz = 1.0f / z;
-            float* pg = a.p[r] + ((size_t)n0 * 2 + gm) * L;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < nk) {
-                    const int j = 4 * sub + 4 * LPR * k;
-                    const float4 pv = make_float4(xv[k].x * rz, xv[k].y * rz, xv[k].z * rz, xv[k].w * rz);
-                    *reinterpret_cast<float4*>(row + j) = pv;
-                    if (present) {
-                        if (j + 3 < L && (L & 3) == 0) stg4(pg + j, pv);
-                        else {
-                            if (j < L) stg(pg + j, pv.x);
-                            if (j + 1 < L) stg(pg + j + 1, pv.y);
-                            if (j + 2 < L) stg(pg + j + 2, pv.z);
-                            if (j + 3 < L) stg(pg + j + 3, pv.w);
-                        }
-                    }
-                }
-        } else {
-            const float* pg = a.p[r] + ((size_t)n0 * 2 + gm) * L;
-            float4 pv[KMAX];
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < nk) {
-                    const int j = 4 * sub + 4 * LPR * k;
-                    pv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (present) {
-                        if (j + 3 < L && (L & 3) == 0) pv[k] = ldg4(pg + j);
-                        else {
-                            if (j < L) pv[k].x = ldg(pg + j);
-                            if (j + 1 < L) pv[k].y = ldg(pg + j + 1);
-                            if (j + 2 < L) pv[k].z = ldg(pg + j + 2);
-                            if (j + 3 < L) pv[k].w = ldg(pg + j + 3);
-                        }
-                    }
-                }
-            float dot = 0.f;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < nk) dot += (pv[k].x * xv[k].x + pv[k].y * xv[k].y) + (pv[k].z * xv[k].z + pv[k].w * xv[k].w);
-            dot = sum32(dot);
-            const uint8_t* mk = mk_s + (gm >> 1) * Lpad;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < nk) {
-                    const int j = 4 * sub + 4 * LPR * k;
-                    const uint32_t mw = *reinterpret_cast<const uint32_t*>(mk + j);
-                    float4 d;
-                    d.x = (mw & 0xffu) ? 0.f : pv[k].x * (xv[k].x - dot) * a.rscale;
-                    d.y = (mw & 0xff00u) ? 0.f : pv[k].y * (xv[k].y - dot) * a.rscale;
-                    d.z = (mw & 0xff0000u) ? 0.f : pv[k].z * (xv[k].z - dot) * a.rscale;
-                    d.w = (mw & 0xff000000u) ? 0.f : pv[k].w * (xv[k].w - dot) * a.rscale;
-                    *reinterpret_cast<float4*>(row + j) = d;      // j >= L: p = 0 there, so 0 is written back
-                }
-        }
-    };
-    if (row_live) {
-        if (L <= 4 * LPR * 4) softmax_pass(std::integral_constant<int, 4>{});
-        else softmax_pass(std::integral_constant<int, 8>{});      // L <= 1024 (checked on the host)
-    }
     __syncthreads();
     CF_STAMP2(4);
     // ---- (4) w[m][f] = sum_j sc[m][j] f_j[f]
@@ -374,10 +434,38 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
 #pragma unroll
         for (int f = 0; f < 8; ++f) acc[f] = 0.f;
         const float* fp = feats_s + (row_live ? gm >> 1 : 0) * L * F;
-        for (int j = sub; j < (row_live ? L : 0); j += LPR) {
-            const float pv = sc_s[gm * LS + j];
+        if (F == 7) {      // four bins per step: their 28 marks are seven 16-byte LDS reads (the tail past L is multiplied by zeros)
+            for (int j = 4 * sub; j < (row_live ? L : 0); j += 4 * LPR) {
+                const float4 p4 = *reinterpret_cast<const float4*>(sc_s + gm * LS + j);
+                if (j + 3 < L) {
+                    const float4* f4 = reinterpret_cast<const float4*>(fp + (size_t)j * 7);
+                    float tmp[28];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) acc[f] = fmaf(pv, fp[j * F + f], acc[f]);           // entries f >= F are dropped below
+                    for (int k = 0; k < 7; ++k) {
+                        const float4 t4 = f4[k];
+                        tmp[4 * k] = t4.x;
+                        tmp[4 * k + 1] = t4.y;
+                        tmp[4 * k + 2] = t4.z;
+                        tmp[4 * k + 3] = t4.w;
+                    }
+                    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int f = 0; f < 7; ++f) acc[f] = fmaf(pj[t], tmp[t * 7 + f], acc[f]);
+                } else {
+                    const float pj[4] = {p4.x, p4.y, p4.z, p4.w};
+                    for (int t = 0; t < 4 && j + t < L; ++t)
+#pragma unroll
+                        for (int f = 0; f < 7; ++f) acc[f] = fmaf(pj[t], fp[(size_t)(j + t) * 7 + f], acc[f]);
+                }
+            }
+        } else {
+            for (int j = sub; j < (row_live ? L : 0); j += LPR) {
+                const float pv = sc_s[gm * LS + j];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) acc[f] = fmaf(pv, fp[j * F + f], acc[f]);           // entries f >= F are dropped below
+            }
         }
         // 8 sums over LPR lanes in 9 (10) exchanges: each step trades half of the values with the partner lane
         float h4[4], h2[2], h1;
@@ -420,39 +508,41 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         frag_mma_nn_rt(fp5, sc_s + kh * kper, LS, kper / 32, acc);
         CF_STAMP2(6);
         __syncthreads();                       // the score tile, the operand rows and the marks are free now
-        float* part = kh == 1 ? red_s : kh == 2 ? vin_s : sc_s;      // [16][LD] each (LS >= LD)
-        if (kh != 0) {
+        // K-split partials of all four quarters to LDS ([16][LD] each); then wave (cg, kh) finishes the rows 4 lq + kh of its
+        // column group: three partials + its own, + Wlp w, store -- a quarter of the rows per wave instead of all of them in two
+        // (four [16][LD] buffers laid over the score tile, the operand rows, the partial buffer and the first 64 floats of u:
+        //  contiguous in that order and all free now; 16 LS + 32 LD + 128 >= 64 LD for every Lpad >= 256)
+        float* const parts[4] = {sc_s, sc_s + kTile * LD, sc_s + 2 * kTile * LD, sc_s + 3 * kTile * LD};
+        {
+            float* part = sc_s + kh * kTile * LD;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
                 *reinterpret_cast<float4*>(part + (lq * 4 + ii) * LD + cg * 64 + 4 * lr) = make_float4(acc[0][ii], acc[1][ii], acc[2][ii], acc[3][ii]);
         }
         __syncthreads();
-        if (kh == 0) {
-            // Wlp rows of this lane's four output columns: 8 sixteen-byte reads instead of 32 scalar ones per row
+        {
+            const int m = lq * 4 + kh, e0 = cg * 64 + 4 * lr;
+            // Wlp rows of this lane's four output columns: 8 sixteen-byte reads instead of 32 scalar ones
             float wl[4][8];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float4 w0 = *reinterpret_cast<const float4*>(wlp_s + (cg * 64 + 4 * lr + t) * 8);
-                const float4 w1 = *reinterpret_cast<const float4*>(wlp_s + (cg * 64 + 4 * lr + t) * 8 + 4);
+                const float4 w0 = *reinterpret_cast<const float4*>(wlp_s + (e0 + t) * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(wlp_s + (e0 + t) * 8 + 4);
                 wl[t][0] = w0.x, wl[t][1] = w0.y, wl[t][2] = w0.z, wl[t][3] = w0.w;
                 wl[t][4] = w1.x, wl[t][5] = w1.y, wl[t][6] = w1.z, wl[t][7] = w1.w;
             }
+            const float4 wa = *reinterpret_cast<const float4*>(w_s + m * 8), wb = *reinterpret_cast<const float4*>(w_s + m * 8 + 4);
+            const float wm[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            const float4 r0 = *reinterpret_cast<const float4*>(parts[0] + m * LD + e0);
+            const float4 r1 = *reinterpret_cast<const float4*>(parts[1] + m * LD + e0);
+            const float4 r2 = *reinterpret_cast<const float4*>(parts[2] + m * LD + e0);
+            const float4 r3 = *reinterpret_cast<const float4*>(parts[3] + m * LD + e0);
+            float v[4] = {(r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z), (r0.w + r1.w) + (r2.w + r3.w)};
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int m = lq * 4 + ii, e0 = cg * 64 + 4 * lr;
-                const float4 wa = *reinterpret_cast<const float4*>(w_s + m * 8), wb = *reinterpret_cast<const float4*>(w_s + m * 8 + 4);
-                const float wm[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-                const float4 r1 = *reinterpret_cast<const float4*>(red_s + m * LD + e0);
-                const float4 r2 = *reinterpret_cast<const float4*>(vin_s + m * LD + e0);
-                const float4 r3 = *reinterpret_cast<const float4*>(sc_s + m * LD + e0);
-                float v[4] = {acc[0][ii] + r1.x + r2.x + r3.x, acc[1][ii] + r1.y + r2.y + r3.y, acc[2][ii] + r1.z + r2.z + r3.z,
-                              acc[3][ii] + r1.w + r2.w + r3.w};
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int f = 0; f < 8; ++f) v[t] = fmaf(wm[f], wl[t][f], v[t]);
-                if ((m >> 1) < nreg) stg4(a.vout[r] + ((size_t)n0 * 2 + m) * kD + e0, make_float4(v[0], v[1], v[2], v[3]));
-            }
+                for (int f = 0; f < 8; ++f) v[t] = fmaf(wm[f], wl[t][f], v[t]);
+            if ((m >> 1) < nreg && (m >> 1) < kAG) stg4(a.vout[r] + ((size_t)n0 * 2 + m) * kD + e0, make_float4(v[0], v[1], v[2], v[3]));
         }
     }
     CF_STAMP2(7);

@@ -55,7 +55,16 @@ def test_two_embedding_layers_forward_backward_adamw(reg):
     model.adamw_step(3e-5)
     torch.cuda.synchronize()
     sd = model.state_dict()
-    assert max((sd[k].cpu() - P[k].detach()).abs().max().item() for k in P) < 2e-5
+    # first AdamW update u = lr g / (|g| + eps): insensitive to rounding noise in g where |g| >> eps = 1e-8, amplified up to a
+    # fraction of lr = 3e-5 where |g| ~ eps (same treatment as tests/test_gpu_parity.py)
+    for k in P:
+        d = (sd[k].cpu() - P[k].detach()).abs()
+        if P[k].grad is None:
+            assert d.max().item() == 0.0, k
+            continue
+        big = P[k].grad.abs() > 1e-6
+        assert (d[big].max().item() < 5e-7) if big.any() else True, k
+        assert d.max().item() <= 3e-5, k
 
 
 def test_trainer_replays_the_all_rows_path_from_a_graph():

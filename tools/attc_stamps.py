@@ -11,8 +11,12 @@ packed = m.pack_batch(synthetic_batch(B, seed=1, regime="dense"))
 for _ in range(3):
     m.forward_backward(packed, torch.zeros(B, dtype=torch.long))
 torch.cuda.synchronize()
-t = m.debug_buffer("reg_tdbg").cpu().numpy().view(np.uint64)[256:256 + 32].astype(np.int64)
-names = ["stage", "u", "t=vin.PE^T + epilogue", "softmax", "w", "sum p PE (mfma)", "reduce+epilogue"]
+t = m.debug_buffer("reg_tdbg").cpu().numpy().view(np.uint64)[256:256 + 256].astype(np.int64).reshape(8, 32)
+names = ["stage", "products + u", "epilogue + block statistics", "softmax combine", "w", "sum p PE (mfma)", "reduce+epilogue"]
 for k, nm in ((0, "fwd"), (16, "bwd")):
-    d = np.diff(t[k:k + 8])
-    print(nm, "total", t[k + 7] - t[k], " ".join("%s %d |" % (names[i], d[i]) for i in range(7)))
+    t0 = t[0, k]
+    d = np.diff(t[0, k:k + 8])
+    print(nm, "wave 0: total", t[0, k + 7] - t0, " ".join("%s %d |" % (names[i], d[i]) for i in range(7)))
+    for wv in range(8):      # every wave, relative to wave 0's first stamp: start, before barrier 1, after, products done, before barrier 2, after, ...
+        print("   wave %d: start %6d | b1 %6d -> %6d | products done %6d | b2 %6d -> %6d | b3 -> %6d | b4 -> %6d | pass 5 done %6d | end %6d" % (
+            (wv,) + tuple(t[wv, k + i] - t0 for i in (0, 10, 1, 8, 9, 2, 3, 4, 6, 7))))
