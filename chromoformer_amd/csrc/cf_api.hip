@@ -855,15 +855,29 @@ static size_t attr_smem(int T, bool bwd) {
     return (size_t)(T * kRW + kRH * T * T + (bwd ? kRH * T * T + T * kRDm + kRH * T : 0)) * sizeof(float);
 }
 
+#ifndef CF_POST_WAVES
+#define CF_POST_WAVES 8
+#endif
+constexpr int kPostWaves = CF_POST_WAVES;      // waves per workgroup of the row-tile chains (k_post_*, k_qchain_*): 4 or 8
 template <bool VPROJ, int DM>
 static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& a) {
-    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256>), grid, dim3(256), 0, st, a);
+    if (kPostWaves == 8) {
+        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8>), grid, dim3(512), 0, st, a);
+    } else {
+        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 4>), grid, dim3(256), 0, st, a);
+    }
 }
 template <bool VPROJ, int DM>
 static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArgs& a) {
-    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256>), grid, dim3(256), 0, st, a);
+    if (kPostWaves == 8) {
+        if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, 8>), grid, dim3(512), 0, st, a);
+    } else {
+        if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, 4>), grid, dim3(256), 0, st, a);
+    }
 }
 
 struct CentreParams {   // weights of one centre-row layer (_t: tiled copies for the forward products)
@@ -1036,7 +1050,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         po.omap = omap;
         po.N = N;
         po.save = save;
-        hipLaunchKernelGGL(k_qchain_fwd, dim3(tiles_of(N), nres), dim3(256), 0, st, q);
+        hipLaunchKernelGGL((k_qchain_fwd<kPostWaves>), dim3(tiles_of(N), nres), dim3(kPostWaves * 64), 0, st, q);
         LAUNCH_CHECK("k_qchain_fwd");
         if (h->attc2) {
             const int ag = attc2_regions_per_wg(N, h->attc_cap);
@@ -1063,6 +1077,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             a2.scale = scale_c;
             a2.rscale = 1.0f / a2.scale;
             a2.tdbg = (getenv("CF_STAMP_ATTC") && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
+                          ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
+            a2.tall = (getenv("CF_STAMP_ATTC_ALL") && atoi(getenv("CF_STAMP_ATTC_ALL")) == 0 && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
                           ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
             void* kargs2[] = {&a2};
             HIP_TRY(hipLaunchKernel(attc2_kernel<false>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
@@ -1410,13 +1426,15 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             a2.rscale = 1.0f / a2.scale;
             a2.tdbg = (getenv("CF_STAMP_ATTC") && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
                           ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
+            a2.tall = (getenv("CF_STAMP_ATTC_ALL") && atoi(getenv("CF_STAMP_ATTC_ALL")) == 1 && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
+                          ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
             void* kargs2[] = {&a2};
             HIP_TRY(hipLaunchKernel(attc2_kernel<true>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
         } else {
             hipLaunchKernelGGL((k_attc<true>), dim3(N, nres), dim3(256), smem, st, at);
         }
         LAUNCH_CHECK("k_attc<bwd>");
-        hipLaunchKernelGGL(k_qchain_bwd, dim3(tiles_of(N), nres), dim3(256), 0, st, qb);
+        hipLaunchKernelGGL((k_qchain_bwd<kPostWaves>), dim3(tiles_of(N), nres), dim3(kPostWaves * 64), 0, st, qb);
         LAUNCH_CHECK("k_qchain_bwd");
         return 0;
     };

@@ -42,6 +42,7 @@ struct Attc2Args {
     int N, F;
     float scale, rscale;         // sqrt(dh) and its reciprocal
     unsigned long long* tdbg;    // optional shader-clock stamps (workgroup 0 of the last resolution)
+    unsigned long long* tall;    // optional: (start, end) of EVERY workgroup (wave 0), [gridDim.y][gridDim.x][2]
 };
 #define CF_STAMP2(slot)                                                                                   \
     do {                                                                                                  \
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
     const int nreg = min(kAG, N - n0);        // regions present in this workgroup
 
     CF_STAMP2(0);
+    if (a.tall && tid == 0) a.tall[(blockIdx.y * gridDim.x + blockIdx.x) * 2] = __builtin_amdgcn_s_memtime();
     const int nblk = (L + 63) / 64;
     float* stat_s = red_s;                    // [2][16][16] per-(row, column block) softmax statistics (free until pass 5's reduction)
     static_assert(2 * kTile * 16 <= kTile * LD, "statistics fit in the K-split partial buffer");
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         }
     }
     CF_STAMP2(7);
+    if (a.tall && tid == 0) a.tall[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = __builtin_amdgcn_s_memtime();
 }
 
 // Regions per workgroup.  These kernels are latency-bound (a handful of workgroups per CU, dependent phases): the

@@ -63,6 +63,11 @@ __device__ __forceinline__ void stg4(float* p, float4 v) { *(CF_GLOBAL v4f*)(p) 
 template <int NT>
 struct LdgN;
 template <>
+struct LdgN<1> {
+    static __device__ __forceinline__ float ld(const float* p) { return ldg(p); }
+    static __device__ __forceinline__ void st(float* p, float v) { stg(p, v); }
+};
+template <>
 struct LdgN<2> {
     static __device__ __forceinline__ float2 ld(const float* p) { return ldg2(p); }
     static __device__ __forceinline__ void st(float* p, float2 v) { stg2(p, v); }
@@ -198,6 +203,10 @@ __device__ __forceinline__ int col_nt(int t, int r) { return t * 16 + r; }
 // col(t, r) = NT*r + t of the wave's 16*NT-column range (one 8/16-byte load per NT MFMAs).
 template <int NT>
 struct VecN;
+template <>
+struct VecN<1> {
+    typedef float type;
+};
 template <>
 struct VecN<2> {
     typedef float2 type;
@@ -498,45 +507,51 @@ struct QChainArgs {
     float* xcopy[kMaxRes];      // optional: the (row-mapped) input rows, materialised [N,128]
     int N;
 };
-__global__ __launch_bounds__(256) void k_qchain_fwd(QChainArgs a) {
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
+    constexpr int CW = kD / NWV, NTC = CW / 16;           // q columns per wave
+    constexpr int EW = 256 / NWV, NTE = EW / 16;          // qt columns per wave (2 heads x 128)
     __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
     __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
     const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int h = w >> 1, e0 = (w & 1) * 64;
-    FragNT<2, 8> fq;
-    frag_load_nt(fq, a.wq[r] + (size_t)(w * 32) * kD, kD);
-    FragNN<4, 4> fk;
+    const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
+    FragNT<NTC, 8> fq;
+    frag_load_nt(fq, a.wq[r] + (size_t)(w * CW) * kD, kD);
+    FragNN<NTE, 4> fk;
     frag_load_nn(fk, a.wk[r] + (size_t)(h * 64) * kD + e0, kD);
     load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, a.N, a.xmap);
     __syncthreads();
     if (a.xcopy[r])
-        for (int i = threadIdx.x; i < kTile * kD; i += 256)
+        for (int i = threadIdx.x; i < kTile * kD; i += NWV * 64)
             if (row0 + (i >> 7) < a.N) a.xcopy[r][(size_t)(row0 + (i >> 7)) * kD + (i & 127)] = xs[i >> 7][i & 127];
     {
-        f32x4 acc[2];
+        f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nt(fq, &xs[0][0], kD + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTC; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
+                const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 qs[row][col] = acc[t][i];
                 if (row0 + row < a.N) a.q[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
             }
     }
     __syncthreads();
     {
-        f32x4 acc[4];
+        f32x4 acc[NTE];
         zero_acc(acc);
         frag_mma_nn(fk, &qs[0][h * 64], kD + 4, acc);
+        typedef typename VecN<NTE>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = lq * 4 + i;
+            float v[NTE];
+#pragma unroll
+            for (int t = 0; t < NTE; ++t) v[t] = acc[t][i];
             if (row0 + row < a.N)
-                *reinterpret_cast<float4*>(a.qt[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + 4 * lr) =
-                    make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                LdgN<NTE>::st(a.qt[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
         }
     }
 }
@@ -550,43 +565,50 @@ struct QBwdArgs {
     float* dx[kMaxRes];          // [N,128]
     int N;
 };
-__global__ __launch_bounds__(256) void k_qchain_bwd(QBwdArgs a) {
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
+    constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / tiles per wave
     __shared__ __attribute__((aligned(16))) float ds[kTile][256 + 4];
     __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
     const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int h = w >> 1;
-    FragNT<2, 8> fk;
-    frag_load_nt(fk, a.wk[r] + (size_t)(w * 32) * kD, kD);
-    FragNN<2, 8> fq;
-    frag_load_nn(fq, a.wq[r] + w * 32, kD);
+    const int h = (w * CW) >> 6;
+    FragNT<NTC, 8> fk;
+    frag_load_nt(fk, a.wk[r] + (size_t)(w * CW) * kD, kD);
+    FragNN<NTC, 8> fq;
+    frag_load_nn(fq, a.wq[r] + w * CW, kD);
     load_tile(&ds[0][0], 260, a.dqt[r], 256, 256, row0, a.N, identity_map());
     __syncthreads();
     {   // dq[:, h*64+d] = sum_e dqt[:, h, e] Wk[h*64+d, e]
-        f32x4 acc[2];
+        f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nt(fk, &ds[0][h * kD], 260, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTC; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
+                const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 qs[row][col] = acc[t][i];
                 if (row0 + row < a.N) a.dq[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
             }
     }
     __syncthreads();
     {   // dx = dres + dq Wq
-        f32x4 acc[2];
+        f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nn(fq, &qs[0][0], kD + 4, acc);
+        typedef typename VecN<NTC>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = lq * 4 + i;
             if (row0 + row < a.N) {
-                const size_t o = (size_t)(row0 + row) * kD + w * 32 + 2 * lr;
-                const float2 dr = *reinterpret_cast<const float2*>(a.dres[r] + o);
-                *reinterpret_cast<float2*>(a.dx[r] + o) = make_float2(acc[0][i] + dr.x, acc[1][i] + dr.y);
+                const size_t o = (size_t)(row0 + row) * kD + w * CW + NTC * lr;
+                const vec_t drv = LdgN<NTC>::ld(a.dres[r] + o);
+                const float* dr = reinterpret_cast<const float*>(&drv);
+                float v[NTC];
+#pragma unroll
+                for (int t = 0; t < NTC; ++t) v[t] = acc[t][i] + dr[t];
+                LdgN<NTC>::st(a.dx[r] + o, *reinterpret_cast<const vec_t*>(v));
             }
         }
     }
@@ -825,33 +847,41 @@ struct PostArgs {
     int save;    // 0: inference, skip the activation saves
 };
 
-template <bool VPROJ, int DM, int DFF>
-__global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
+// NWV waves per workgroup (4 or 8): wave w owns 128 / NWV output columns of every product (DFF / NWV of the hidden layer), so with
+// eight waves two of them share a SIMD and one's operand waits hide behind the other's products; the LayerNorms run on waves 0..3.
+template <bool VPROJ, int DM, int DFF, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
     constexpr int HW = (DFF > 256 ? DFF : 256);
+    constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / column tiles per wave
+    constexpr int CH = DFF / NWV, NT1 = CH / 16;          // hidden columns / tiles per wave
     __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
     __shared__ __attribute__((aligned(16))) float as_[kTile][DM + 4];
     __shared__ __attribute__((aligned(16))) float ts[kTile][kD + 4];
     __shared__ __attribute__((aligned(16))) float hs[kTile][HW + 4];
     const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    FragNT<2, DM / 16> fo;
-    frag_load_nt(fo, a.wo[r] + (size_t)(w * 32) * DM, DM);
-    const LnParams lnp1 = ln_params_load(a.g1[r], a.be1[r]), lnp2 = ln_params_load(a.g2[r], a.be2[r]);
+    FragNT<NTC, DM / 16> fo;
+    frag_load_nt(fo, a.wo[r] + (size_t)(w * CW) * DM, DM);
+    LnParams lnp1, lnp2;
+    if (w < 4) {
+        lnp1 = ln_params_load(a.g1[r], a.be1[r]);
+        lnp2 = ln_params_load(a.g2[r], a.be2[r]);
+    }
     load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, N, a.xmap);
     if (VPROJ) {
-        FragNT<2, 8> fv;
-        frag_load_nt(fv, a.wv[r] + (size_t)(w * 32) * kD, kD);
+        FragNT<NTC, 8> fv;
+        frag_load_nt(fv, a.wv[r] + (size_t)(w * CW) * kD, kD);
         load_tile(&hs[0][0], HW + 4, a.ain[r], 256, 256, row0, N, identity_map());
         __syncthreads();
-        const int h = w >> 1;
-        f32x4 acc[2];
+        const int h = (w * CW) >> 6;
+        f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nt(fv, &hs[0][h * kD], HW + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTC; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
+                const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 as_[row][col] = acc[t][i];
                 if (a.save && row0 + row < N) a.a_out[r][(size_t)(row0 + row) * DM + col] = acc[t][i];
             }
@@ -860,22 +890,22 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
     }
     __syncthreads();
     {   // t1 = x + a Wo^T + bo
-        f32x4 acc[2];
+        f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nt(fo, &as_[0][0], DM + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTC; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
+                const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 ts[row][col] = acc[t][i] + a.bo[r][col] + xs[row][col];
             }
     }
-    constexpr int NT1 = DFF / 64;
     FragNT<NT1, 8> f1;      // issued before the LayerNorm so the L2 latency hides behind it
-    frag_load_nt(f1, a.w1[r] + (size_t)(w * (DFF / 4)) * kD, kD);
+    frag_load_nt(f1, a.w1[r] + (size_t)(w * CH) * kD, kD);
     __syncthreads();
-    ln_fwd_tile16(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
+    if (w < 4)
+        ln_fwd_tile16(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
     __syncthreads();
     {   // hdn = relu(y1 W1^T + b1)
         f32x4 acc[NT1];
@@ -885,29 +915,29 @@ __global__ __launch_bounds__(256) void k_post_fwd(PostArgs a) {
         for (int t = 0; t < NT1; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * (DFF / 4) + col_nt(t, lr);
+                const int row = lq * 4 + i, col = w * CH + col_nt(t, lr);
                 const float v = fmaxf(acc[t][i] + a.b1[r][col], 0.f);
                 hs[row][col] = v;
                 if (a.save && row0 + row < N) a.hdn[r][(size_t)(row0 + row) * DFF + col] = v;
             }
     }
-    FragNT<2, DFF / 16> f2;
-    frag_load_nt(f2, a.w2[r] + (size_t)(w * 32) * DFF, DFF);
+    FragNT<NTC, DFF / 16> f2;
+    frag_load_nt(f2, a.w2[r] + (size_t)(w * CW) * DFF, DFF);
     __syncthreads();
     {   // t2 = y1 + hdn W2^T + b2
-        f32x4 acc[2];
+        f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nt(f2, &hs[0][0], HW + 4, acc);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTC; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = lq * 4 + i, col = w * 32 + col_nt(t, lr);
+                const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 xs[row][col] = acc[t][i] + a.b2[r][col] + ts[row][col];
             }
     }
     __syncthreads();
-    ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+    if (w < 4) ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
 }
 
 // backward of the chain.  Per tile it also emits the column sums that make up the
@@ -936,10 +966,12 @@ struct PostBwdArgs {
 };
 __host__ __device__ constexpr int post_partial_width(int dff) { return 768 + dff; }
 
-template <bool VPROJ, int DM, int DFF>
-__global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
+template <bool VPROJ, int DM, int DFF, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
     constexpr int WW = (DFF > DM ? DFF : DM);
-    constexpr int NT2 = DFF / 64, NTO = DM / 64;
+    constexpr int CW = kD / NWV, NTC = CW / 16;           // columns / tiles per wave of a 128-wide product
+    constexpr int CH = DFF / NWV, NT2 = CH / 16;          // ... of the hidden layer
+    constexpr int CO = DM / NWV, NTO = CO / 16;           // ... of the attention output
     __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1 -> dt1
     __shared__ __attribute__((aligned(16))) float xh[kTile][kD + 4];    // xhat2 -> xhat1
     __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2
@@ -948,19 +980,19 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     float* part = a.partial[r] + (size_t)blockIdx.x * post_partial_width(DFF);
     FragNN<NT2, 8> fw2;
-    frag_load_nn(fw2, a.w2[r] + w * (DFF / 4), DFF);
+    frag_load_nn(fw2, a.w2[r] + w * CH, DFF);
     load_tile(&ds[0][0], kD + 4, a.dout[r], kD, kD, row0, N, a.dmap);
     load_tile(&xh[0][0], kD + 4, a.xh2[r], kD, kD, row0, N, identity_map());
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0);      // d ln2.weight
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128);           // d ln2.bias
-    {
+    if (w < 4) {
         const int sub = threadIdx.x & 15;
         ln_bwd_tile16(&ds[0][0], &t2[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g2[r] + sub * 8), ldg4(a.g2[r] + sub * 8 + 4), a.rs2[r], row0,
                       min(kTile, N - row0), a.dt2[r]);   // t2 = dt2
     }
-    FragNN<2, DFF / 16> fw1;
-    frag_load_nn(fw1, a.w1[r] + w * 32, kD);
+    FragNN<NTC, DFF / 16> fw1;
+    frag_load_nn(fw1, a.w1[r] + w * CW, kD);
     __syncthreads();
     colsum16(&t2[0][0], kD + 4, nullptr, 0, kD, part + 256);           // d l2.bias
     {   // dpre1 = (dt2 W2) * (hdn > 0)
@@ -970,42 +1002,42 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
         typedef typename VecN<NT2>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = lq * 4 + i, col = w * (DFF / 4) + NT2 * lr;
+            const int row = lq * 4 + i, col = w * CH + NT2 * lr;
             float v[NT2];
 #pragma unroll
             for (int t = 0; t < NT2; ++t) v[t] = 0.f;
             if (row0 + row < N) {
                 const size_t o = (size_t)(row0 + row) * DFF + col;
-                const vec_t hv = *reinterpret_cast<const vec_t*>(a.hdn[r] + o);
+                const vec_t hv = LdgN<NT2>::ld(a.hdn[r] + o);
                 const float* hp = reinterpret_cast<const float*>(&hv);
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) v[t] = hp[t] > 0.f ? acc[t][i] : 0.f;
-                *reinterpret_cast<vec_t*>(a.dpre1[r] + o) = *reinterpret_cast<const vec_t*>(v);
+                LdgN<NT2>::st(a.dpre1[r] + o, *reinterpret_cast<const vec_t*>(v));
             }
             *reinterpret_cast<vec_t*>(&wide[row][col]) = *reinterpret_cast<const vec_t*>(v);
         }
     }
     load_tile(&xh[0][0], kD + 4, a.xh1[r], kD, kD, row0, N, identity_map());   // xhat2 is dead now
     FragNN<NTO, 8> fwo;
-    frag_load_nn(fwo, a.wo[r] + w * (DM / 4), DM);
+    frag_load_nn(fwo, a.wo[r] + w * CO, DM);
     __syncthreads();
     colsum16(&wide[0][0], WW + 4, nullptr, 0, DFF, part + 384);        // d l1.bias
     {   // dy1 = dt2 + dpre1 W1
-        f32x4 acc[2];
+        f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nn(fw1, &wide[0][0], WW + 4, acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = lq * 4 + i, col = w * 32 + 2 * lr;
-            ds[row][col] = acc[0][i] + t2[row][col];
-            ds[row][col + 1] = acc[1][i] + t2[row][col + 1];
+            const int row = lq * 4 + i, col = w * CW + NTC * lr;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) ds[row][col + t] = acc[t][i] + t2[row][col + t];
         }
     }
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF);   // d ln1.weight
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 512 + DFF);          // d ln1.bias
     __syncthreads();
-    {
+    if (w < 4) {
         const int sub = threadIdx.x & 15;
         ln_bwd_tile16(&ds[0][0], &ds[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g1[r] + sub * 8), ldg4(a.g1[r] + sub * 8 + 4), a.rs1[r], row0,
                       min(kTile, N - row0), a.dt1[r]);   // ds = dt1
@@ -1019,28 +1051,32 @@ __global__ __launch_bounds__(256) void k_post_bwd(PostBwdArgs a) {
         typedef typename VecN<NTO>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = lq * 4 + i, col = w * (DM / 4) + NTO * lr;
+            const int row = lq * 4 + i, col = w * CO + NTO * lr;
             float v[NTO];
 #pragma unroll
             for (int t = 0; t < NTO; ++t) v[t] = acc[t][i];
             *reinterpret_cast<vec_t*>(&wide[row][col]) = *reinterpret_cast<const vec_t*>(v);
-            if (row0 + row < N) *reinterpret_cast<vec_t*>(a.da[r] + (size_t)(row0 + row) * DM + col) = *reinterpret_cast<const vec_t*>(v);
+            if (row0 + row < N) LdgN<NTO>::st(a.da[r] + (size_t)(row0 + row) * DM + col, *reinterpret_cast<const vec_t*>(v));
         }
     }
     if (VPROJ) {   // dxbar[:, h, e] = sum_d da[:, h*64+d] Wv[h*64+d, e]
-        const int h = w >> 1, e0 = (w & 1) * 64;
-        FragNN<4, 4> fwv;
+        constexpr int EW = 256 / NWV, NTE = EW / 16;
+        const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
+        FragNN<NTE, 4> fwv;
         frag_load_nn(fwv, a.wv[r] + (size_t)(h * 64) * kD + e0, kD);
         __syncthreads();
-        f32x4 acc[4];
+        f32x4 acc[NTE];
         zero_acc(acc);
         frag_mma_nn(fwv, &wide[0][h * 64], WW + 4, acc);
+        typedef typename VecN<NTE>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = lq * 4 + i;
+            float v[NTE];
+#pragma unroll
+            for (int t = 0; t < NTE; ++t) v[t] = acc[t][i];
             if (row0 + row < N)
-                *reinterpret_cast<float4*>(a.dxbar[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + 4 * lr) =
-                    make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                LdgN<NTE>::st(a.dxbar[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
         }
     }
 }
