@@ -89,7 +89,7 @@ def train_loop_rate(model, lr, steps, store_genes, regime, dev):
     feed = EpochFeed(model, store, BSZ)
     quiet = lambda *a, **k: None
     wb = type("W", (), {"log": staticmethod(quiet)})
-    report = lambda lo, la, ls: _report_train(quiet, wb, 1, float(ls.mean().item()), trainer.lr, lo, la, False)
+    report = lambda lo, la, ls: _report_train(quiet, wb, 1, float(ls.numpy().mean()), trainer.lr, lo, la, False)
     torch.manual_seed(7)
     train_epoch(trainer, feed, shard_indices(epoch_permutation(len(store)), 0, 1, BSZ)[:30], report)      # warm-up (captures the graph)
     torch.cuda.synchronize()

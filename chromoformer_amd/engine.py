@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -101,6 +102,7 @@ class EpochFeed:
         self.slot.feed = self
         self.cap = max_batches or (len(store) // bsz + 1)
         self.order = torch.zeros(self.cap * bsz, dtype=torch.int32, device=dev)
+        self._order_host = torch.zeros(self.cap * bsz, dtype=torch.int32).pin_memory()
         self.cursor = torch.zeros(2, dtype=torch.int32, device=dev)          # [next batch, arrival counter of the gather launch]
         # the step logs live in pinned HOST memory (device-addressable): cf_record_step writes a KB per step straight into
         # it, the loop reads it once an event says the window is complete -- no device-to-host copy, which would queue
@@ -118,11 +120,15 @@ class EpochFeed:
             raise ValueError("epoch of %d batches exceeds the feed's capacity %d" % (len(batches), self.cap))
         if any(len(b) != self.B for b in batches):
             raise ValueError("every batch of an EpochFeed epoch must hold exactly %d genes" % self.B)
-        flat = torch.tensor([int(i) for b in batches for i in b], dtype=torch.int32)
-        self._hold = flat = flat.pin_memory() if flat.numel() else flat
+        # the order goes through ONE pinned staging buffer, filled with a numpy conversion: between two epochs the GPU is
+        # idle until this returns (a Python list comprehension + a fresh pinned allocation cost ~5 ms per epoch, 3 % of an
+        # 18,000-gene epoch).  The previous epoch's copy out of the buffer has completed: its windows have all been read.
+        n = len(batches) * self.B
+        if n:
+            self._order_host[:n] = torch.from_numpy(np.asarray(batches, dtype=np.int32).reshape(-1))
         with torch.cuda.stream(stream):
-            if flat.numel():
-                self.order[: flat.numel()].copy_(flat, non_blocking=True)
+            if n:
+                self.order[:n].copy_(self._order_host[:n], non_blocking=True)
             self.cursor.zero_()
         self.n_batches = len(batches)
 

@@ -15,7 +15,7 @@ trainer = Trainer(model, lr=3e-5)
 feed = EpochFeed(model, store, B)
 quiet = lambda *a, **k: None
 wb = type("W", (), {"log": staticmethod(quiet)})
-report = lambda lo, la, ls: _report_train(quiet, wb, 1, float(ls.mean().item()), trainer.lr, lo, la, False)
+report = lambda lo, la, ls: _report_train(quiet, wb, 1, float(ls.numpy().mean()), trainer.lr, lo, la, False)
 batches = shard_indices(epoch_permutation(len(store)), 0, 1, B)
 train_epoch(trainer, feed, batches[:30], report)
 torch.cuda.synchronize()
