@@ -412,7 +412,7 @@ struct WgJob {
 };
 static void push_wg(std::vector<WgTile>& out, const WgJob& j) {
     for (int n0 = 0; n0 < j.Nn; n0 += 64)
-        for (int k0 = 0; k0 < j.Kk; k0 += 64) {
+        for (int k0 = 0; k0 < j.Kk; k0 += kWgTk) {
             WgTile t;
             memset(&t, 0, sizeof t);
             for (int s = 0; s < j.nseg; ++s) t.seg[s] = j.seg[s];
@@ -2130,7 +2130,7 @@ extern "C" int cf_op_dense_layer_fwd_train(const cf_dense_layer* w, const float*
 static int dense_wgrad(const float* dY, int lddy, const float* X, int ldx, long long rows, float* dW, int N_, int K_, float* part,
                        WgTile* tiles_d, CsTile* cs_d, hipStream_t st) {
     const int splits = (int)((rows + kDenseSplitRows - 1) / kDenseSplitRows);
-    const int ntiles = ((N_ + 63) / 64) * ((K_ + 63) / 64) * splits, ncs = (N_ * K_ + 63) / 64;
+    const int ntiles = ((N_ + 63) / 64) * ((K_ + kWgTk - 1) / kWgTk) * splits, ncs = (N_ * K_ + 63) / 64;
     if ((size_t)ntiles * sizeof(WgTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64 || (size_t)ncs * sizeof(CsTile) > (size_t)(kDenseTab / 2) * sizeof(float) * 64)
         return fail("cf_op_dense_layer_bwd: tile table overflow");
     DenseWgTab tb{dY, X, part, dW, tiles_d, cs_d, rows, lddy, ldx, N_, K_, splits, kDenseSplitRows};

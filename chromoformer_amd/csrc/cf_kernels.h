@@ -1388,40 +1388,48 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col,
     if (col + 3 < ncols) v.w = ldg(p + col + 3);
     return v;
 }
+#ifndef CF_WG_TK
+#define CF_WG_TK 64      // 128 measured: 91.6 vs 78.1 us per step (half as many workgroups: the barriers of a stage are no longer hidden)
+#endif
 constexpr int kWgM = 32;            // reduction rows per LDS stage
+constexpr int kWgTk = CF_WG_TK;     // tile width along K (columns of dW): 64 or 128; tiles are 64 (n) x kWgTk (k)
 constexpr int kWgLdA = 64 + 16;     // A stage row stride: a half-wave's scalar reads (two rows x 16 columns) hit 32 distinct banks
-constexpr int kWgLdB = 64 + 4;
+constexpr int kWgLdB = kWgTk + 4;
 __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) {
-    // 64 x 64 output tile; wave w owns rows n0+16w..+15.  Both operands are staged through LDS (every element of dY
-    // is used by one wave but every element of X by all four: reading X straight from L2 in each wave made the
-    // kernel L1-bound at 37 % of the MFMA peak), one 19 KB stage of 32 reduction rows (single-buffered: seven workgroups
-    // per CU hide the two barriers better than a double buffer with four did); the global loads of stage i+1 are in
-    // flight while stage i is multiplied.  B is read 16 bytes per lane, so accumulator c holds
-    // the strided columns k0 + 4r + c.
+    // 64 x kWgTk output tile; wave w owns rows n0+16w..+15 and all the tile's columns.  Both operands are staged through LDS
+    // (every element of dY is used by one wave but every element of X by all four: reading X straight from L2 in each wave
+    // made the kernel L1-bound at 37 % of the MFMA peak), one stage of 32 reduction rows (single-buffered: several workgroups
+    // per CU hide the two barriers better than a double buffer with fewer did); the global loads of stage i+1 are in
+    // flight while stage i is multiplied.  B is read 16 bytes per lane, so accumulator 4 h + c holds the strided columns
+    // k0 + 64 h + 4 r + c.  A 64 x 128 tile moves (64 + 128) x 32 floats per 2 x 64 x 128 x 32 flops: 21 flop per byte out of
+    // L2 against 16 for a 64 x 64 tile.
+    constexpr int NH = kWgTk / 64;
     __shared__ __attribute__((aligned(16))) float As[1][kWgM * kWgLdA];
     __shared__ __attribute__((aligned(16))) float Bs[1][kWgM * kWgLdB];
     const WgTile& t = tiles[blockIdx.x];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int kc = t.k0 + 4 * lr;
-    const bool kv = kc < t.Kk;
-    f32x4 acc[4];
+    f32x4 acc[4 * NH];
     zero_acc(acc);
-    const int sm = tid >> 4, sc = (tid & 15) * 4;          // staging: rows sm, sm + 16; columns sc .. sc + 3
+    const int sm = tid >> 4, sc = (tid & 15) * 4;          // staging: rows sm, sm + 16; columns sc .. sc + 3 (+ 64 h)
     for (int s = 0; s < t.nseg; ++s) {
         const WgSeg sg = t.seg[s];
         const int M = sg.rows_per_gene * batch, nst = (M + kWgM - 1) / kWgM;
         const bool va = ((sg.lda | t.n0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.A) & 15) == 0;
         const bool vb = ((sg.ldb | t.k0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.B) & 15) == 0;
-        float4 ra[kWgM / 16], rb[kWgM / 16];
+        float4 ra[kWgM / 16], rb[kWgM / 16][NH];
         auto fetch = [&](int st) {
 #pragma unroll
             for (int p = 0; p < kWgM / 16; ++p) {
                 const int m = st * kWgM + sm + 16 * p;
                 if (m < M) {
                     ra[p] = wg_load4(sg.A + (size_t)m * sg.lda, t.n0 + sc, t.Nn, va);
-                    rb[p] = wg_load4(sg.B + (size_t)m * sg.ldb, t.k0 + sc, t.Kk, vb);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) rb[p][h] = wg_load4(sg.B + (size_t)m * sg.ldb, t.k0 + 64 * h + sc, t.Kk, vb);
                 } else {
-                    ra[p] = rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) rb[p][h] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         };
@@ -1429,7 +1437,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
 #pragma unroll
             for (int p = 0; p < kWgM / 16; ++p) {
                 *reinterpret_cast<float4*>(&As[buf][(sm + 16 * p) * kWgLdA + sc]) = ra[p];
-                *reinterpret_cast<float4*>(&Bs[buf][(sm + 16 * p) * kWgLdB + sc]) = rb[p];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) *reinterpret_cast<float4*>(&Bs[buf][(sm + 16 * p) * kWgLdB + 64 * h + sc]) = rb[p][h];
             }
         };
         fetch(0);
@@ -1443,19 +1452,27 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
 #pragma unroll
             for (int i = 0; i < kWgM / 4; ++i) {
                 const float av = ap[4 * i * kWgLdA];
-                const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * i * kWgLdB);
-                acc[0] = mfma4(av, bv.x, acc[0]);
-                acc[1] = mfma4(av, bv.y, acc[1]);
-                acc[2] = mfma4(av, bv.z, acc[2]);
-                acc[3] = mfma4(av, bv.w, acc[3]);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * i * kWgLdB + 64 * h);
+                    acc[4 * h + 0] = mfma4(av, bv.x, acc[4 * h + 0]);
+                    acc[4 * h + 1] = mfma4(av, bv.y, acc[4 * h + 1]);
+                    acc[4 * h + 2] = mfma4(av, bv.z, acc[4 * h + 2]);
+                    acc[4 * h + 3] = mfma4(av, bv.w, acc[4 * h + 3]);
+                }
             }
         }
     }
-    if (!kv) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = t.n0 + w * 16 + lq * 4 + i;
-        if (row < t.Nn) *reinterpret_cast<float4*>(t.C + (size_t)row * t.ldc + kc) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+    for (int h = 0; h < NH; ++h) {
+        if (kc + 64 * h >= t.Kk) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = t.n0 + w * 16 + lq * 4 + i;
+            if (row < t.Nn)
+                *reinterpret_cast<float4*>(t.C + (size_t)row * t.ldc + kc + 64 * h) =
+                    make_float4(acc[4 * h + 0][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i]);
+        }
     }
 }
 
@@ -1648,7 +1665,7 @@ struct DenseWgTab {
     int lddy, ldx, N_, K_, splits, split_rows;
 };
 __global__ __launch_bounds__(256) void k_dense_wg_tables(DenseWgTab a) {
-    const int tn = (a.N_ + 63) / 64, tk = (a.K_ + 63) / 64, per = tn * tk, nt = per * a.splits;
+    const int tn = (a.N_ + 63) / 64, tk = (a.K_ + kWgTk - 1) / kWgTk, per = tn * tk, nt = per * a.splits;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < nt; t += gridDim.x * 256) {
         const int s = t / per, rem = t - s * per;
         const long long r0 = (long long)s * a.split_rows;
@@ -1661,7 +1678,7 @@ __global__ __launch_bounds__(256) void k_dense_wg_tables(DenseWgTab a) {
         w.Nn = a.N_;
         w.Kk = a.K_;
         w.n0 = (rem / tk) * 64;
-        w.k0 = (rem % tk) * 64;
+        w.k0 = (rem % tk) * kWgTk;
         a.tiles[t] = w;
     }
     const int ncs = (a.N_ * a.K_ + 63) / 64;
