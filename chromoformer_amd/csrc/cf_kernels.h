@@ -285,6 +285,36 @@ __device__ __forceinline__ void load_tile(float* dst, int ldd, const float* __re
     }
 }
 
+// The same in two phases -- request into registers, put into LDS -- for the prologue of a chain kernel: loads return in
+// order, so the tile a kernel's first barrier waits for is requested FIRST, the operand rings of the products behind it, and
+// the put waits for the tile alone.  No branch around and no select directly behind the loads (rows past the end are
+// clamped and zeroed at the put): the wait count stays exact.
+template <int NCOLS, int NTHR>
+struct TileReq {
+    static constexpr int C4 = NCOLS / 4, NV = (kTile * C4 + NTHR - 1) / NTHR;
+    float4 v[NV];
+};
+template <int NCOLS, int NTHR>
+__device__ __forceinline__ void tile_req(TileReq<NCOLS, NTHR>& t, const float* __restrict__ src, int lds_, int row0, int nrows,
+                                         const RowMap& map) {
+    constexpr int C4 = NCOLS / 4;
+#pragma unroll
+    for (int u = 0; u < TileReq<NCOLS, NTHR>::NV; ++u) {
+        const int i = min((int)threadIdx.x + u * NTHR, kTile * C4 - 1), rr = i / C4, c4 = i - rr * C4;
+        t.v[u] = ldg4(src + (size_t)map_row(map, min(row0 + rr, nrows - 1)) * lds_ + c4 * 4);
+    }
+}
+template <int NCOLS, int NTHR>
+__device__ __forceinline__ void tile_put(const TileReq<NCOLS, NTHR>& t, float* dst, int ldd, int row0, int nrows) {
+    constexpr int C4 = NCOLS / 4;
+#pragma unroll
+    for (int u = 0; u < TileReq<NCOLS, NTHR>::NV; ++u) {
+        const int i = (int)threadIdx.x + u * NTHR, rr = i / C4, c4 = i - rr * C4;
+        if (i < kTile * C4)
+            *reinterpret_cast<float4*>(dst + rr * ldd + c4 * 4) = row0 + rr < nrows ? t.v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // LayerNorm forward over the 128 columns of the 4 rows this wave owns (rows 4w..4w+3 of
 // an LDS tile).  y = xhat * g + b is written back into the tile; xhat / rstd / y go to
 // global (row-major [N,128]) when the pointers are non-null.
@@ -516,11 +546,13 @@ __global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
     const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
+    TileReq<kD, NWV * 64> tx;
+    tile_req(tx, a.x[r], kD, row0, a.N, a.xmap);
     FragNT<NTC, 8> fq;
     frag_load_nt(fq, a.wq[r] + (size_t)(w * CW) * kD, kD);
     FragNN<NTE, 4> fk;
     frag_load_nn(fk, a.wk[r] + (size_t)(h * 64) * kD + e0, kD);
-    load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, a.N, a.xmap);
+    tile_put(tx, &xs[0][0], kD + 4, row0, a.N);
     __syncthreads();
     if (a.xcopy[r])
         for (int i = threadIdx.x; i < kTile * kD; i += NWV * 64)
@@ -573,11 +605,13 @@ __global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
     const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int h = (w * CW) >> 6;
+    TileReq<256, NWV * 64> td;
+    tile_req(td, a.dqt[r], 256, row0, a.N, identity_map());
     FragNT<NTC, 8> fk;
     frag_load_nt(fk, a.wk[r] + (size_t)(w * CW) * kD, kD);
     FragNN<NTC, 8> fq;
     frag_load_nn(fq, a.wq[r] + w * CW, kD);
-    load_tile(&ds[0][0], 260, a.dqt[r], 256, 256, row0, a.N, identity_map());
+    tile_put(td, &ds[0][0], 260, row0, a.N);
     __syncthreads();
     {   // dq[:, h*64+d] = sum_e dqt[:, h, e] Wk[h*64+d, e]
         f32x4 acc[NTC];
@@ -860,18 +894,22 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
     __shared__ __attribute__((aligned(16))) float hs[kTile][HW + 4];
     const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    TileReq<kD, NWV * 64> tx;
+    TileReq<256, NWV * 64> th;
+    tile_req(tx, a.x[r], kD, row0, N, a.xmap);
+    if (VPROJ) tile_req(th, a.ain[r], 256, row0, N, identity_map());
     FragNT<NTC, DM / 16> fo;
+    FragNT<NTC, 8> fv;
+    if (VPROJ) frag_load_nt(fv, a.wv[r] + (size_t)(w * CW) * kD, kD);
     frag_load_nt(fo, a.wo[r] + (size_t)(w * CW) * DM, DM);
     LnParams lnp1, lnp2;
     if (w < 4) {
         lnp1 = ln_params_load(a.g1[r], a.be1[r]);
         lnp2 = ln_params_load(a.g2[r], a.be2[r]);
     }
-    load_tile(&xs[0][0], kD + 4, a.x[r], kD, kD, row0, N, a.xmap);
+    tile_put(tx, &xs[0][0], kD + 4, row0, N);
     if (VPROJ) {
-        FragNT<NTC, 8> fv;
-        frag_load_nt(fv, a.wv[r] + (size_t)(w * CW) * kD, kD);
-        load_tile(&hs[0][0], HW + 4, a.ain[r], 256, 256, row0, N, identity_map());
+        tile_put(th, &hs[0][0], HW + 4, row0, N);
         __syncthreads();
         const int h = (w * CW) >> 6;
         f32x4 acc[NTC];
@@ -979,10 +1017,13 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
     const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     float* part = a.partial[r] + (size_t)blockIdx.x * post_partial_width(DFF);
+    TileReq<kD, NWV * 64> td, tx;
+    tile_req(td, a.dout[r], kD, row0, N, a.dmap);
+    tile_req(tx, a.xh2[r], kD, row0, N, identity_map());
     FragNN<NT2, 8> fw2;
     frag_load_nn(fw2, a.w2[r] + w * CH, DFF);
-    load_tile(&ds[0][0], kD + 4, a.dout[r], kD, kD, row0, N, a.dmap);
-    load_tile(&xh[0][0], kD + 4, a.xh2[r], kD, kD, row0, N, identity_map());
+    tile_put(td, &ds[0][0], kD + 4, row0, N);
+    tile_put(tx, &xh[0][0], kD + 4, row0, N);
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0);      // d ln2.weight
     colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128);           // d ln2.bias
