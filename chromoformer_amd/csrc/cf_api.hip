@@ -1499,7 +1499,11 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
     return 0;
 }
 
-// deferred weight / bias gradients: two launches over the tile tables
+#ifndef CF_MERGE_REDUCE
+#define CF_MERGE_REDUCE 1
+#endif
+constexpr bool kMergeReduce = CF_MERGE_REDUCE;
+// deferred weight / bias gradients: one launch per bucket over the two tile tables
 static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUCKET_REG | CF_BUCKET_PE) {
     if (buckets & CF_BUCKET_PE) {
         hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
@@ -1509,13 +1513,17 @@ static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUC
         if (!(buckets & (bk == 0 ? CF_BUCKET_REG : CF_BUCKET_PE))) continue;
         const int w0 = bk == 0 ? 0 : h->n_wg_r, wn = bk == 0 ? h->n_wg_r : h->n_wg - h->n_wg_r;
         const int c0 = bk == 0 ? 0 : h->n_cs_r, cn = bk == 0 ? h->n_cs_r : h->n_cs - h->n_cs_r;
-        h->time_mark("k_wgrad", st);
-        hipLaunchKernelGGL(k_wgrad, dim3(wn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, B);
-        h->time_mark("k_wgrad", st);
-        LAUNCH_CHECK("k_wgrad");
-        h->time_mark("k_colsum", st);
-        hipLaunchKernelGGL(k_colsum, dim3(cn), dim3(256), 0, st, (const CsTile*)h->cs_tiles + c0, B);
-        h->time_mark("k_colsum", st);
+        if (!kMergeReduce || h->timed == "k_wgrad" || h->timed == "k_colsum") {      // timed separately
+            h->time_mark("k_wgrad", st);
+            hipLaunchKernelGGL(k_wgrad, dim3(wn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, B);
+            h->time_mark("k_wgrad", st);
+            LAUNCH_CHECK("k_wgrad");
+            h->time_mark("k_colsum", st);
+            hipLaunchKernelGGL(k_colsum, dim3(cn), dim3(256), 0, st, (const CsTile*)h->cs_tiles + c0, B);
+            h->time_mark("k_colsum", st);
+        } else {
+            hipLaunchKernelGGL(k_reduce, dim3(wn + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B);
+        }
         LAUNCH_CHECK("k_colsum");
     }
     return 0;

@@ -1436,7 +1436,7 @@ constexpr int kWgM = 32;            // reduction rows per LDS stage
 constexpr int kWgTk = CF_WG_TK;     // tile width along K (columns of dW): 64 or 128; tiles are 64 (n) x kWgTk (k)
 constexpr int kWgLdA = 64 + 16;     // A stage row stride: a half-wave's scalar reads (two rows x 16 columns) hit 32 distinct banks
 constexpr int kWgLdB = kWgTk + 4;
-__global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) {
+__device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch) {
     // 64 x kWgTk output tile; wave w owns rows n0+16w..+15 and all the tile's columns.  Both operands are staged through LDS
     // (every element of dY is used by one wave but every element of X by all four: reading X straight from L2 in each wave
     // made the kernel L1-bound at 37 % of the MFMA peak), one stage of 32 reduction rows (single-buffered: several workgroups
@@ -1447,7 +1447,6 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
     constexpr int NH = kWgTk / 64;
     __shared__ __attribute__((aligned(16))) float As[1][kWgM * kWgLdA];
     __shared__ __attribute__((aligned(16))) float Bs[1][kWgM * kWgLdB];
-    const WgTile& t = tiles[blockIdx.x];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int kc = t.k0 + 4 * lr;
     f32x4 acc[4 * NH];
@@ -1517,6 +1516,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
     }
 }
 
+__global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) { wgrad_tile(tiles[blockIdx.x], batch); }
+
 // Weight gradient of the 7-mark projections (lin_proj / lin_proj_pcre, [128, F]): too narrow
 // for an MFMA tile.  One workgroup sums a chunk of 8 genes into partial[chunk][128*F]; the
 // chunks are added by k_colsum.   dW[e][f] = sum over segments, sum_m A[m][e] * B[m][f]
@@ -1560,9 +1561,8 @@ struct CsTile {
     int rows_per_gene, div;      // M = ceil(rows_per_gene * batch / div)
     const float* src2;           // optional elementwise factor (same leading dimension): LayerNorm weight gradients
 };
-__global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles, int batch) {
+__device__ __forceinline__ void colsum_tile(const CsTile& t, int batch) {
     __shared__ float red[4][64];
-    const CsTile& t = tiles[blockIdx.x];
     const int M = (t.rows_per_gene * batch + t.div - 1) / t.div;
     const int c = t.c0 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     float s = 0.f;
@@ -1580,6 +1580,14 @@ __global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles
     red[ph][threadIdx.x & 63] = s;
     __syncthreads();
     if (ph == 0 && c < t.ncols) t.out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles, int batch) { colsum_tile(tiles[blockIdx.x], batch); }
+// Both reductions of a gradient bucket in ONE launch: workgroups [0, n_wg) take weight-gradient tiles, the rest column-sum
+// tiles (independent of each other; the bandwidth-bound column sums run beside the matrix products instead of behind them,
+// and one launch boundary goes)
+__global__ __launch_bounds__(256) void k_reduce(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int batch) {
+    if ((int)blockIdx.x < n_wg) wgrad_tile(wg[blockIdx.x], batch);
+    else colsum_tile(cs[blockIdx.x - n_wg], batch);
 }
 
 // =======================================================================================
