@@ -1,0 +1,8 @@
+#!/bin/bash
+V=$1; shift
+for r in 1 2; do
+  for v in "$@"; do
+    b=$(env $V=$v python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --no-graph 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['loss'])")
+    echo "round $r (eager) $V=$v: step_ms $b"
+  done
+done
