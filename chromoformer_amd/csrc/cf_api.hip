@@ -1235,7 +1235,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         a.T = T;
         a.n_res = nres;
         a.n_out = c.n_out;
-        hipLaunchKernelGGL(k_head_fwd, dim3(tiles_of(B)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_head_fwd, dim3(tiles_of(B)), dim3(kHeadThreads), 0, st, a);
         LAUNCH_CHECK("k_head_fwd");
     }
     h->last_fwd_B = save ? B : 0;
@@ -1271,7 +1271,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         a.T = T;
         a.n_res = nres;
         a.n_out = c.n_out;
-        hipLaunchKernelGGL(k_head_bwd, dim3(tiles_of(B)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_head_bwd, dim3(tiles_of(B)), dim3(kHeadThreads), 0, st, a);
         LAUNCH_CHECK("k_head_bwd");
     }
     if ((parts & 2) && h->reg_fused) {

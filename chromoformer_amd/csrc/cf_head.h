@@ -18,42 +18,65 @@ struct HeadFwdArgs {
     float* logits_user;          // caller's copy (may be null)
     int B, T, n_res, n_out;
 };
-__global__ __launch_bounds__(256) void k_head_fwd(HeadFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[2][kTile][kD + 4];
+constexpr int kHeadThreads = 512;      // eight waves: wave w owns 16 of the 128 hidden columns
+__global__ __launch_bounds__(kHeadThreads) void k_head_fwd(HeadFwdArgs a) {
+    // all n_res resolution chunks of the concatenated input are fetched at once into one [16][n_res*128] tile (one barrier), then
+    // every wave runs ONE product over the whole reduction range with a continuous operand ring
+    constexpr int KMAX = kMaxRes * kD;
+    __shared__ __attribute__((aligned(16))) float xs[kTile][KMAX + 4];
     __shared__ __attribute__((aligned(16))) float hs[kTile][kD + 4];
     const int row0 = blockIdx.x * kTile, K = a.n_res * kD, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int col0 = w * 32;
-    f32x4 acc[2];
-    zero_acc(acc);
-    for (int r = 0, buf = 0; r < a.n_res; ++r, buf ^= 1) {       // reduction chunk r of W1 = resolution r of the concatenation
-        FragNT<2, 8> f;
-        frag_load_nt(f, a.w1_t + (size_t)col0 * K + (size_t)r * kD * 16, K);
-        for (int i = tid; i < kTile * (kD / 4); i += 256) {
-            const int row = i >> 5, c4 = i & 31, g = row0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < a.B) {
-                const size_t o = (size_t)g * a.T * kD + c4 * 4;
-                const float4 p = ldg4(a.xl[r] + o), q = ldg4(a.x0[r] + o);
-                v = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
-                stg4(a.hin + (size_t)g * K + r * kD + c4 * 4, v);
-            }
-            *reinterpret_cast<float4*>(&xs[buf][row][c4 * 4]) = v;
+    const int col0 = w * 16;
+    FragNT<1, 8> f;      // (chunks are requested by hand below: the reduction length n_res * 128 is a run-time value)
+    f.wp = a.w1_t + (size_t)col0 * K + lane * 4;
+    f.tstride = K * 16;
+    const int nch = K / 32;
+    for (int i = tid; i < kTile * (K / 4); i += kHeadThreads) {
+        const int row = i / (K / 4), c4k = i - row * (K / 4), r = c4k >> 5, c4 = c4k & 31, g = row0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < a.B) {
+            const size_t o = (size_t)g * a.T * kD + c4 * 4;
+            const float4 p = ldg4(a.xl[r] + o), q = ldg4(a.x0[r] + o);
+            v = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+            stg4(a.hin + (size_t)g * K + r * kD + c4 * 4, v);
         }
-        __syncthreads();
-        frag_mma_nt(f, &xs[buf][0][0], kD + 4, acc);
+        *reinterpret_cast<float4*>(&xs[row][c4k * 4]) = v;
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = lq * 4 + i, col = col0 + col_nt(t, lr);
-            const float v = fmaxf(acc[t][i] + a.b1[col], 0.f);
-            hs[row][col] = v;
-            if (row0 + row < a.B) a.h1[(size_t)(row0 + row) * kD + col] = v;
-        }
+    for (int c = 0; c < kRing - 1; ++c) frag_chunk_nt(f, c, min(c, nch - 1));
     __syncthreads();
-    {   // logits: 16 lanes per gene
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float* ap = &xs[lr][lq * 4];
+        for (int c0 = 0; c0 < nch; c0 += kRing) {
+#pragma unroll
+            for (int u = 0; u < kRing; ++u) {
+                const int c = c0 + u;
+                if (c + kRing - 1 < nch) frag_chunk_nt(f, (u + kRing - 1) % kRing, c + kRing - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c < nch)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float4 av = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
+                        const float4 b = f.ring[u][k][0];
+                        acc = mfma4(av.x, b.x, acc);
+                        acc = mfma4(av.y, b.y, acc);
+                        acc = mfma4(av.z, b.z, acc);
+                        acc = mfma4(av.w, b.w, acc);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = lq * 4 + i, col = col0 + lr;
+        const float v = fmaxf(acc[i] + a.b1[col], 0.f);
+        hs[row][col] = v;
+        if (row0 + row < a.B) a.h1[(size_t)(row0 + row) * kD + col] = v;
+    }
+    __syncthreads();
+    if (tid < 256) {   // logits: 16 lanes per gene
         const int row = tid >> 4, sub = tid & 15, g = row0 + row;
         for (int c = 0; c < a.n_out; ++c) {
             float s = 0.f;
@@ -82,7 +105,7 @@ struct HeadBwdArgs {
     float gscale;
     int B, T, n_res, n_out;
 };
-__global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
+__global__ __launch_bounds__(kHeadThreads) void k_head_bwd(HeadBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];
     __shared__ float dl[kTile][2];
     __shared__ float li[kTile];
@@ -118,23 +141,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
         li[tid] = l;
     }
     __syncthreads();
-    if (a.labels && tid == 0) {       // mean loss: per-workgroup partials, summed in workgroup order by the last to arrive
-        float s = 0.f;
-        for (int i = 0; i < kTile; ++i) s += li[i];
-        a.loss_part[blockIdx.x] = s;
-        __threadfence();
-        unsigned* counter = reinterpret_cast<unsigned*>(a.loss + 2);
-        if (atomicAdd(counter, 1u) == gridDim.x - 1) {
-            __threadfence();
-            float tot = 0.f;
-            for (unsigned i = 0; i < gridDim.x; ++i) tot += *(volatile float*)(a.loss_part + i);
-            tot /= (float)a.B;
-            a.loss[0] = tot;
-            if (a.loss_user) a.loss_user[0] = tot;
-            *counter = 0u;
-        }
-    }
-    for (int i = tid; i < kTile * kD; i += 256) {      // dh1 = (dlogits W2) * (h1 > 0)
+    for (int i = tid; i < kTile * kD; i += kHeadThreads) {      // dh1 = (dlogits W2) * (h1 > 0)
         const int row = i >> 7, j = i & 127, g = row0 + row;
         float s = dl[row][0] * a.w2[j];
         if (a.n_out == 2) s = fmaf(dl[row][1], a.w2[kD + j], s);
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
         if (g < a.B) a.dh1[(size_t)g * kD + j] = v;
     }
     __syncthreads();
-    for (int jb = w; jb < K / 64; jb += 4) {          // dhin[:, 64 jb ..] = dh1 . W1[:, 64 jb ..]
+    for (int jb = w; jb < K / 64; jb += kHeadThreads / 64) {          // dhin[:, 64 jb ..] = dh1 . W1[:, 64 jb ..]
         FragNN<4, 8> f;
         frag_load_nn(f, a.w1 + jb * 64, K);
         f32x4 acc[4];
@@ -158,6 +165,23 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a) {
                 stg4(a.dhin + (size_t)g * K + jb * 64 + 4 * lr, v);
                 stg4(a.dxl[r] + (size_t)g * a.T * kD + e0, v);
             }
+        }
+    }
+    // (last: the fences of this block cost a few thousand cycles, and nothing in the kernel waits for the loss)
+    if (a.labels && tid == 0) {       // mean loss: per-workgroup partials, summed in workgroup order by the last to arrive
+        float s = 0.f;
+        for (int i = 0; i < kTile; ++i) s += li[i];
+        a.loss_part[blockIdx.x] = s;
+        __threadfence();
+        unsigned* counter = reinterpret_cast<unsigned*>(a.loss + 2);
+        if (atomicAdd(counter, 1u) == gridDim.x - 1) {
+            __threadfence();
+            float tot = 0.f;
+            for (unsigned i = 0; i < gridDim.x; ++i) tot += *(volatile float*)(a.loss_part + i);
+            tot /= (float)a.B;
+            a.loss[0] = tot;
+            if (a.loss_user) a.loss_user[0] = tot;
+            *counter = 0u;
         }
     }
 }
