@@ -973,12 +973,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
     const float scale_c = sqrtf(64.f);
     CentreParams ep[kMaxRes], pp[kMaxRes];
     for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
-    // refresh the tiled weight copy (the parameters may have been changed by anyone since the last call)
-    hipLaunchKernelGGL(k_retile, dim3(h->n_retile), dim3(256), 0, st, (const float*)h->params, h->tiled, h->reg8 ? h->tiledT : (float*)nullptr,
-                       (const RetileUnit*)h->retile_units);
-    LAUNCH_CHECK("k_retile");
-
-    {   // Embedding centre-row input
+    {   // refresh the tiled weight copies (the parameters may have been changed by anyone since the last call) and, in the same
+        // launch, the Embedding centre-row input
         X0Args a;
         for (int r = 0; r < nres; ++r) {
             a.feats[r] = bt->promoter_feats[r];
@@ -989,8 +985,9 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             a.L[r] = c.n_bins[r];
         }
         a.F = F;
-        hipLaunchKernelGGL(k_embed_x0, dim3(B, nres), dim3(128), 0, st, a);
-        LAUNCH_CHECK("k_embed_x0");
+        hipLaunchKernelGGL(k_fwd_prologue, dim3(h->n_retile + B * nres), dim3(256), 0, st, (const float*)h->params, h->tiled,
+                           h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, h->n_retile, a, B);
+        LAUNCH_CHECK("k_fwd_prologue");
     }
     // one centre-row layer: query chain -> attention -> post chain
     auto centre_layer = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* xin, RowMap xmap,

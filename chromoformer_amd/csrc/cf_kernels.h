@@ -513,8 +513,7 @@ struct X0Args {
     int L[kMaxRes];
     int F;
 };
-__global__ __launch_bounds__(128) void k_embed_x0(X0Args a) {
-    const int r = blockIdx.y, n = blockIdx.x, e = threadIdx.x;
+__device__ __forceinline__ void embed_x0_row(const X0Args& a, int r, int n, int e) {
     const int L = a.L[r], c = L / 2, F = a.F;
     const float* f = a.feats[r] + ((size_t)n * L + c) * F;
     float acc = 0.f;
@@ -522,6 +521,7 @@ __global__ __launch_bounds__(128) void k_embed_x0(X0Args a) {
     a.x0[r][(size_t)n * kD + e] = acc + a.pe[r][(size_t)c * kD + e];
     if (e < 8) a.featc[r][(size_t)n * 8 + e] = e < F ? f[e] : 0.f;
 }
+__global__ __launch_bounds__(128) void k_embed_x0(X0Args a) { embed_x0_row(a, blockIdx.y, blockIdx.x, threadIdx.x); }
 
 // =======================================================================================
 // Query chain:  q = x Wq^T ;  qt[h] = q[h] Wk[h]   (the key projection absorbed into the
@@ -1667,10 +1667,9 @@ struct RetileUnit {
     long long toff;    // float offset of the tensor
     int K, N, n0, tr;  // row length, rows of the tensor, first row of the unit, emit the transposed tiling too
 };
-__global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
-                                                const RetileUnit* __restrict__ units) {
+__device__ __forceinline__ void retile_unit(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
+                                            const RetileUnit u) {
     __shared__ __attribute__((aligned(16))) float tp[4][16][20];
-    const RetileUnit u = units[blockIdx.x];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* src = params + u.off + (size_t)r * u.K + q * 4;
     float* dst = tiled + u.off + lane * 4;
@@ -1690,6 +1689,21 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    }
+}
+__global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
+                                                const RetileUnit* __restrict__ units) {
+    retile_unit(params, tiled, tiledT, units[blockIdx.x]);
+}
+// First launch of a forward pass: the tiled weight copies (workgroups [0, n_units)) and, independent of them, the Embedding's
+// centre-row input x0 (one workgroup per (gene, resolution) behind them) -- one launch boundary less
+__global__ __launch_bounds__(256) void k_fwd_prologue(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
+                                                      const RetileUnit* __restrict__ units, int n_units, X0Args a, int B) {
+    if ((int)blockIdx.x < n_units) {
+        retile_unit(params, tiled, tiledT, units[blockIdx.x]);
+    } else if (threadIdx.x < 128) {
+        const int i = blockIdx.x - n_units;
+        embed_x0_row(a, i / B, i % B, threadIdx.x);
     }
 }
 // the same tiling of a stand-alone row-major matrix W[rows][K] (rows, K multiples of 16): workgroup b takes rows 16 b ..
