@@ -1449,35 +1449,22 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
                        bt->pcre_mask_stride, NP, c.pair_dff))
             return -1;
     }
-    {   // join the streams meeting at the promoter embedding, back through lin_proj_p
-        JoinArgs j;
-        DgradArgs a;
+    {   // join the streams meeting at the promoter embedding, back through lin_proj_p: one launch
+        JoinDgradArgs a;
         for (int r = 0; r < nres; ++r) {
-            j.dxp[r] = h->P[r][0].dx;
-            j.dx0[r] = h->dRx[r][0];
-            j.dxp0[r] = h->dxp0[r];
-            j.resid[r] = h->resid[r];
-            a.dy[r] = h->dxp0[r];
+            a.dxp[r] = h->P[r][0].dx;
+            a.dx0[r] = h->dRx[r][0];
             a.w[r] = h->P_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
-            a.res[r] = h->resid[r];
+            a.dxp0[r] = h->dxp0[r];
             a.dx[r] = h->edout[r];
         }
-        j.dhin = h->dhin;
-        j.S = S;
-        j.T = T;
-        j.n_res = nres;
-        hipLaunchKernelGGL(k_join, dim3(B, nres), dim3(128), 0, st, j);
-        LAUNCH_CHECK("k_join");
-        a.lddy = kD;
-        a.ldw = kD;
-        a.rmap = identity_map();
-        a.ldres = kD;
-        a.lddx = kD;
-        a.N = NE;
-        a.K = kD;
-        a.Ncols = kD;
-        hipLaunchKernelGGL((k_dgrad<2>), dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
-        LAUNCH_CHECK("k_dgrad<lin_proj_p>");
+        a.dhin = h->dhin;
+        a.B = B;
+        a.S = S;
+        a.T = T;
+        a.n_res = nres;
+        hipLaunchKernelGGL(k_join_dgrad, dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_join_dgrad");
     }
     if (h->embed_dense) {
         if (embed_dense_backward(h, bt, st)) return -1;      // writes the Embedding gradients directly (no deferred tiles)

@@ -1402,6 +1402,70 @@ __global__ __launch_bounds__(128) void k_join(JoinArgs a) {
     a.resid[r][(size_t)g * kD + e] = a.dx0[r][(size_t)g * a.T * kD + e] + a.dhin[(size_t)g * (a.n_res * kD) + r * kD + e];
 }
 
+// The join and the input gradient of lin_proj_p in one launch: dxp0[g] = sum_slots dxp[g, slot] (written for the weight
+// gradient by the first column block), edout[g] = dxp0[g] . W + (dx0[g, token 0] + dhin[g, r]).  One workgroup = 16 genes x 32
+// output columns, K = 128 split over the four waves as in k_dgrad<2>; the A operand is summed from the S slot rows on the fly
+// (same order as k_join: slot 0 first), so the result is bit-identical to k_join + k_dgrad.
+struct JoinDgradArgs {
+    const float* dxp[kMaxRes];   // [B*S,128]
+    const float* dx0[kMaxRes];   // [B*T,128]
+    const float* dhin;           // [B, n_res*128]
+    const float* w[kMaxRes];     // lin_proj_p.weight [128,128] row-major
+    float* dxp0[kMaxRes];        // [B,128]
+    float* dx[kMaxRes];          // [B,128]
+    int B, S, T, n_res;
+};
+__global__ __launch_bounds__(256) void k_join_dgrad(JoinDgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4][kTile][32 + 1];
+    const int r = blockIdx.z, row0 = blockIdx.x * kTile, col0 = blockIdx.y * 32;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int kw = w * 32;                            // this wave's slice of K = 128
+    const bool rv = row0 + lr < a.B;
+    const int g = rv ? row0 + lr : 0;
+    const float* bp = a.w[r] + (size_t)(kw + lq * 4) * kD + col0 + 2 * lr;
+    float2 rb[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[k][i] = ldg2(bp + (size_t)(k * 16 + i) * kD);
+    float4 ra[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float* ap = a.dxp[r] + (size_t)g * a.S * kD + kw + k * 16 + lq * 4;
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < a.S; ++i) {
+            const float4 v = ldg4(ap + (size_t)i * kD);
+            sacc = make_float4(sacc.x + v.x, sacc.y + v.y, sacc.z + v.z, sacc.w + v.w);
+        }
+        ra[k] = rv ? sacc : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rv && blockIdx.y == 0) stg4(a.dxp0[r] + (size_t)g * kD + kw + k * 16 + lq * 4, sacc);
+    }
+    f32x4 acc[2];
+    zero_acc(acc);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float a4[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = mfma4(a4[i], rb[k][i].x, acc[0]);
+            acc[1] = mfma4(a4[i], rb[k][i].y, acc[1]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[w][lq * 4 + i][2 * lr + t] = acc[t][i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kTile * 32; idx += 256) {
+        const int row = idx >> 5, c = idx & 31, col = col0 + c, gg = row0 + row;
+        if (gg < a.B) {
+            const float v = (red[0][row][c] + red[1][row][c]) + (red[2][row][c] + red[3][row][c]);
+            const float res = a.dx0[r][(size_t)gg * a.T * kD + col] + a.dhin[(size_t)gg * (a.n_res * kD) + r * kD + col];
+            a.dx[r][(size_t)gg * kD + col] = v + res;
+        }
+    }
+}
+
 // =======================================================================================
 // Deferred weight gradients: one launch, a table of 64x64 output tiles.
 //   C[n][k] = sum over segments, sum_m A[m][n] * Bm[m][k]      (dW = dY^T X)
