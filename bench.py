@@ -122,8 +122,9 @@ def dp_path_ms(model, batch, steps, warmup, dev):
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     out = {}
     try:
-        for key, overlap in (("overlapped", True), ("serialised", False)):
-            trainer = Trainer(model, lr=3e-5, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=overlap)
+        for key, overlap, graph in (("overlapped", True, True), ("serialised", False, True), ("overlapped_eager", True, False),
+                                    ("serialised_eager", False, False)):
+            trainer = Trainer(model, lr=3e-5, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=overlap, use_graph=graph)
             slot = trainer.stage(batch)
             for _ in range(warmup):
                 trainer.step(slot)
