@@ -992,10 +992,15 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
     // one centre-row layer: query chain -> attention -> post chain
     auto centre_layer = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* xin, RowMap xmap,
                             const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff,
-                            float* const* outp, RowMap omap, bool copy_x) -> int {
+                            float* const* outp, RowMap omap, bool copy_x, const float* const* lin_w = nullptr,
+                            float* const* lin_y = nullptr) -> int {
         QChainArgs q;
         AttcArgs at;
         PostArgs po;
+        for (int r = 0; r < kMaxRes; ++r) {
+            po.lin_w[r] = lin_w && r < nres ? lin_w[r] : nullptr;
+            po.lin_y[r] = lin_y && r < nres ? lin_y[r] : nullptr;
+        }
         size_t smem = 0;
         for (int r = 0; r < nres; ++r) {
             CentreBuf& b = *bufs[r];
@@ -1099,11 +1104,18 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             xin[r] = h->ex0[r];
             outp[r] = h->Rx[r][0];
         }
+        // ... with lin_proj_p on the promoter centre embedding (net.py:118) as the last product of the layer's chain kernel
+        const float* lw[kMaxRes];
+        float* ly[kMaxRes];
+        for (int r = 0; r < nres; ++r) {
+            lw[r] = h->T_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
+            ly[r] = h->xp0[r];
+        }
         if (centre_layer(bufs, ep, xin, identity_map(), bt->promoter_feats, bt->promoter_mask_row, bt->promoter_mask_stride, NE,
-                         c.embed_dff, outp, RowMap{1, T, 0, 0}, false))
+                         c.embed_dff, outp, RowMap{1, T, 0, 0}, false, lw, ly))
             return -1;
     }
-    {   // lin_proj_p on the promoter centre embedding (net.py:118)
+    if (h->embed_dense) {   // lin_proj_p on the promoter centre embedding (net.py:118)
         LinArgs a;
         for (int r = 0; r < nres; ++r) {
             a.x[r] = h->Rx[r][0];

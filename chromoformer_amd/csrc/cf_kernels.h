@@ -879,6 +879,8 @@ struct PostArgs {
     RowMap omap;
     int N;
     int save;    // 0: inference, skip the activation saves
+    const float* lin_w[kMaxRes] = {};   // optional trailing Linear without bias on the chain's output rows (tiled [128,128] copy):
+    float* lin_y[kMaxRes] = {};         // lin_y = out . lin_w^T, rows [N,128] (the Embedding's layer feeds lin_proj_p, net.py:118)
 };
 
 // NWV waves per workgroup (4 or 8): wave w owns 128 / NWV output columns of every product (DFF / NWV of the hidden layer), so with
@@ -974,8 +976,24 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
                 xs[row][col] = acc[t][i] + a.b2[r][col] + ts[row][col];
             }
     }
+    const bool lin = a.lin_w[r] != nullptr;
+    FragNT<NTC, 8> fl;
+    if (lin) frag_load_nt(fl, a.lin_w[r] + (size_t)(w * CW) * kD, kD);
     __syncthreads();
     if (w < 4) ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+    if (lin) {      // one launch less than a separate Linear kernel on 4 row tiles
+        __syncthreads();
+        f32x4 acc[NTC];
+        zero_acc(acc);
+        frag_mma_nt(fl, &xs[0][0], kD + 4, acc);
+#pragma unroll
+        for (int t = 0; t < NTC; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
+                if (row0 + row < N) a.lin_y[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+            }
+    }
 }
 
 // backward of the chain.  Per tile it also emits the column sums that make up the
