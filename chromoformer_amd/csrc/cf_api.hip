@@ -102,7 +102,7 @@ static int check_config(const cf_config& c) {
         return fail("embed.n_layers must be in 1..%d (got %d); more than one layer runs the all-rows path", kMaxEmbedLayers, c.embed_layers);
     if (c.embed_heads != 2 || c.embed_dmodel != 128) return fail("embed: n_heads=2, d_model=128 required");
     if (c.pair_heads != 2 || c.pair_dmodel != 128) return fail("pairwise_interaction: n_heads=2, d_model=128 required");
-    if (c.pair_layers < 1 || c.pair_layers > 2) return fail("pairwise_interaction.n_layers must be 1 or 2");
+    if (c.pair_layers < 1 || 2 * c.pair_layers > kLpMaxSeg) return fail("pairwise_interaction.n_layers must be in 1..%d (got %d)", kLpMaxSeg / 2, c.pair_layers);
     if (c.reg_heads != 8 || c.reg_dmodel != 256) return fail("regulation: n_heads=8, d_model=256 required");
     if (c.reg_layers < 1 || c.reg_layers > 32) return fail("regulation.n_layers must be in 1..32");
     const int dffs[3] = {c.embed_dff, c.pair_dff, c.reg_dff};
@@ -578,7 +578,7 @@ static int build_tables(cf_handle* h) {
             push_wg(wg, wg1(h->dxp0[r], kD, h->Rx[r][0], T * kD, 1, h->G_(pre + "lin_proj_p.weight"), kD, kD, kD));
             LpJob j;
             memset(&j, 0, sizeof j);
-            // lin_proj_pcre collects two terms per layer (pair_layers <= 2 -> <= 4 segments)
+            // lin_proj_pcre collects two terms per layer (pair_layers <= 4 -> <= kLpMaxSeg segments)
             int ns = 0;
             for (int l = 0; l < c.pair_layers; ++l) {
                 j.seg[ns++] = WgSeg{h->P[r][l].dxbar, h->P[r][l].w, kD, 8, 2 * S};

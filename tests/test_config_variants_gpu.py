@@ -17,6 +17,7 @@ VARIANTS = {
     "shallow_narrow": dict(regulation=dict(n_layers=2, n_heads=8, d_model=256, d_ff=128),
                            pairwise_interaction=dict(n_layers=1, n_heads=2, d_model=128, d_ff=128),
                            embed=dict(n_layers=1, n_heads=2, d_model=128, d_ff=256)),
+    "three_pairwise_layers": dict(pairwise_interaction=dict(n_layers=3, n_heads=2, d_model=128, d_ff=256)),
     "deep_reg": dict(regulation=dict(n_layers=8, n_heads=8, d_model=256, d_ff=256)),
     "other_bins": dict(binsizes=[1000, 250, 50], w_max=20000),          # L = 20 / 80 / 400 again but other PE tables ... and
     "odd_lengths": dict(binsizes=[4000, 800, 160], w_max=40000),        # L = 10 / 50 / 250: not multiples of 16 or 64
