@@ -803,8 +803,9 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     if (const char* e = getenv("CF_XCD_MAP")) h->xcd_map = atoi(e) != 0;
     if (const char* e = getenv("CF_ATTC_CAP")) h->attc_cap = atoi(e);
     const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
-    h->n_fwd = 2 + 3 + 1 + 3 * c.pair_layers + reg_launches + 1;       // retile, x0 | Embedding | lin_proj_p | Pairwise | Regulation | head
-    h->n_bwd = 1 + reg_launches + 3 * c.pair_layers + 2 + 3 + 5;       // head | Regulation | Pairwise | join, dgrad | Embedding | reductions
+    // (centre-row Embedding: lin_proj_p rides in its chain kernel; the all-rows path launches it separately, beside its own kernels)
+    h->n_fwd = 1 + 3 + (h->embed_dense ? 1 : 0) + 3 * c.pair_layers + reg_launches + 1;      // prologue | Embedding | Pairwise | Regulation | head
+    h->n_bwd = 1 + reg_launches + 3 * c.pair_layers + 1 + 3 + 1 + 2;      // head | Regulation | Pairwise | join + dgrad | Embedding | 7-mark projections | 2 bucket reductions
     h->n_opt = 1;
     *out = h;
     return 0;
