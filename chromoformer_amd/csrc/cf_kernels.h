@@ -490,9 +490,11 @@ __device__ __forceinline__ void colsum_rows(const float* A, int lda, const float
     }
 }
 
-// column sums over the 16 rows of an LDS tile: out[c] = sum_r A[r][c] (* Bt[r][c])
-__device__ __forceinline__ void colsum16(const float* A, int lda, const float* Bt, int ldb, int ncols, float* out) {
-    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+// column sums over the 16 rows of an LDS tile: out[c] = sum_r A[r][c] (* Bt[r][c]); threads t0, t0 + 1, ... of the workgroup
+// take the columns (t0 = 0: all threads), so that different waves can run different sums side by side
+__device__ __forceinline__ void colsum16(const float* A, int lda, const float* Bt, int ldb, int ncols, float* out, int t0 = 0) {
+    if ((int)threadIdx.x < t0) return;
+    for (int c = threadIdx.x - t0; c < ncols; c += blockDim.x - t0) {
         float s = 0.f;
 #pragma unroll
         for (int rr = 0; rr < kTile; ++rr) s += Bt ? A[rr * lda + c] * Bt[rr * ldb + c] : A[rr * lda + c];
@@ -1035,16 +1037,19 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
     const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     float* part = a.partial[r] + (size_t)blockIdx.x * post_partial_width(DFF);
-    TileReq<kD, NWV * 64> td, tx;
+    // With eight waves the LayerNorm backwards run on waves 0..3 while waves 4..7 take the column sums of the same phase.
+    constexpr bool SPLIT = NWV == 8;
+    TileReq<kD, NWV * 64> td, tx, tx1;
     tile_req(td, a.dout[r], kD, row0, N, a.dmap);
     tile_req(tx, a.xh2[r], kD, row0, N, identity_map());
     FragNN<NT2, 8> fw2;
     frag_load_nn(fw2, a.w2[r] + w * CH, DFF);
+    tile_req(tx1, a.xh1[r], kD, row0, N, identity_map());      // xhat1 rows: needed three phases later, requested now
     tile_put(td, &ds[0][0], kD + 4, row0, N);
     tile_put(tx, &xh[0][0], kD + 4, row0, N);
     __syncthreads();
-    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0);      // d ln2.weight
-    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128);           // d ln2.bias
+    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0, SPLIT ? 256 : 0);      // d ln2.weight  (waves 4, 5)
+    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128, SPLIT ? 384 : 0);           // d ln2.bias    (waves 6, 7)
     if (w < 4) {
         const int sub = threadIdx.x & 15;
         ln_bwd_tile16(&ds[0][0], &t2[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g2[r] + sub * 8), ldg4(a.g2[r] + sub * 8 + 4), a.rs2[r], row0,
@@ -1076,7 +1081,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
             *reinterpret_cast<vec_t*>(&wide[row][col]) = *reinterpret_cast<const vec_t*>(v);
         }
     }
-    load_tile(&xh[0][0], kD + 4, a.xh1[r], kD, kD, row0, N, identity_map());   // xhat2 is dead now
+    tile_put(tx1, &xh[0][0], kD + 4, row0, N);   // xhat2 is dead now
     FragNN<NTO, 8> fwo;
     frag_load_nn(fwo, a.wo[r] + w * CO, DM);
     __syncthreads();
@@ -1093,20 +1098,21 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
         }
     }
     __syncthreads();
-    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF);   // d ln1.weight
-    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 512 + DFF);          // d ln1.bias
-    __syncthreads();
+    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF, SPLIT ? 256 : 0);   // d ln1.weight
+    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 512 + DFF, SPLIT ? 384 : 0);          // d ln1.bias
+    float (*d1)[kD + 4] = SPLIT ? t2 : ds;      // dt1: into the dead dt2 tile when the sums above still read dy1, else in place
+    if (!SPLIT) __syncthreads();
     if (w < 4) {
         const int sub = threadIdx.x & 15;
-        ln_bwd_tile16(&ds[0][0], &ds[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g1[r] + sub * 8), ldg4(a.g1[r] + sub * 8 + 4), a.rs1[r], row0,
-                      min(kTile, N - row0), a.dt1[r]);   // ds = dt1
+        ln_bwd_tile16(&ds[0][0], &d1[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g1[r] + sub * 8), ldg4(a.g1[r] + sub * 8 + 4), a.rs1[r], row0,
+                      min(kTile, N - row0), a.dt1[r]);
     }
     __syncthreads();
-    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF);     // d out-proj bias
+    colsum16(&d1[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF, SPLIT ? 256 : 0);     // d out-proj bias
     {   // da = dt1 Wo
         f32x4 acc[NTO];
         zero_acc(acc);
-        frag_mma_nn(fwo, &ds[0][0], kD + 4, acc);
+        frag_mma_nn(fwo, &d1[0][0], kD + 4, acc);
         typedef typename VecN<NTO>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
