@@ -502,6 +502,24 @@ __device__ __forceinline__ void colsum16(const float* A, int lda, const float* B
     }
 }
 
+// the same with ALL threads of the workgroup: four adjacent lanes share a column, each sums four of the 16 rows and the quad adds
+// up on two DPP swaps -- 4 LDS reads per thread instead of 16 on a quarter of the threads (the sum is the same for every lane
+// of the quad; fixed order: ((r0+r1+r2+r3) + (r4..r7)) + ((r8..r11) + (r12..r15)))
+__device__ __forceinline__ void colsum16q(const float* A, int lda, const float* Bt, int ldb, int ncols, float* out) {
+    const int rg = threadIdx.x & 3;
+    for (int c = threadIdx.x >> 2; c < ncols; c += blockDim.x >> 2) {
+        float s = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = rg * 4 + rr;
+            s += Bt ? A[row * lda + c] * Bt[row * ldb + c] : A[row * lda + c];
+        }
+        s += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+        s += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+        if (rg == 0) stg(out + c, s);
+    }
+}
+
 // =======================================================================================
 // Embedding: centre-row input  x0 = Wlp f_c + PE_c   (net.py:42-53 at row L//2)
 // also emits the centre features padded to 8 (operand of the lin_proj weight gradient)
@@ -1058,7 +1076,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
     FragNN<NTC, DFF / 16> fw1;
     frag_load_nn(fw1, a.w1[r] + w * CW, kD);
     __syncthreads();
-    colsum16(&t2[0][0], kD + 4, nullptr, 0, kD, part + 256);           // d l2.bias
+    colsum16q(&t2[0][0], kD + 4, nullptr, 0, kD, part + 256);          // d l2.bias
     {   // dpre1 = (dt2 W2) * (hdn > 0)
         f32x4 acc[NT2];
         zero_acc(acc);
@@ -1085,7 +1103,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
     FragNN<NTO, 8> fwo;
     frag_load_nn(fwo, a.wo[r] + w * CO, DM);
     __syncthreads();
-    colsum16(&wide[0][0], WW + 4, nullptr, 0, DFF, part + 384);        // d l1.bias
+    colsum16q(&wide[0][0], WW + 4, nullptr, 0, DFF, part + 384);       // d l1.bias
     {   // dy1 = dt2 + dpre1 W1
         f32x4 acc[NTC];
         zero_acc(acc);
@@ -1108,7 +1126,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
                       min(kTile, N - row0), a.dt1[r]);
     }
     __syncthreads();
-    colsum16(&d1[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF, SPLIT ? 256 : 0);     // d out-proj bias
+    colsum16q(&d1[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF);    // d out-proj bias
     {   // da = dt1 Wo
         f32x4 acc[NTO];
         zero_acc(acc);
