@@ -227,6 +227,7 @@ struct cf_handle {
     float *pe[kMaxRes], *pet[kMaxRes];
     float *pe2[kMaxRes], *pet2[kMaxRes];      // padded layouts of the gene-batched attention kernel (cf_attc2.h)
     bool attc2 = false;
+    bool attc1 = true;                        // one-region launches on the vector-ALU kernel (CF_ATTC1=0: k_attc2<., 1>)
     AdamHyper* hyper = nullptr;               // step-dependent AdamW scalars for the graph-replayed optimiser launch
     std::vector<hipEvent_t> sync_ev;          // cf_stream_wait
     size_t sync_ev_used = 0;
@@ -802,6 +803,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     }
     if (const char* e = getenv("CF_XCD_MAP")) h->xcd_map = atoi(e) != 0;
     if (const char* e = getenv("CF_ATTC_CAP")) h->attc_cap = atoi(e);
+    if (const char* e = getenv("CF_ATTC1")) h->attc1 = atoi(e) != 0;
     const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
     // (centre-row Embedding: lin_proj_p rides in its chain kernel; the all-rows path launches it separately, beside its own kernels)
     h->n_fwd = 1 + 3 + (h->embed_dense ? 1 : 0) + 3 * c.pair_layers + reg_launches + 1;      // prologue | Embedding | Pairwise | Regulation | head
@@ -1084,7 +1086,13 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             a2.tall = (getenv("CF_STAMP_ATTC_ALL") && atoi(getenv("CF_STAMP_ATTC_ALL")) == 0 && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
                           ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
             void* kargs2[] = {&a2};
-            HIP_TRY(hipLaunchKernel(attc2_kernel<false>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
+            if (ag == 1 && h->attc1) {      // one region per workgroup: the vector-ALU kernel (cf_attc1.h)
+                size_t sm1 = 0;
+                for (int r = 0; r < nres; ++r) sm1 = std::max(sm1, attc1_smem(at.L[r], F));
+                HIP_TRY(hipLaunchKernel((const void*)k_attc1<false>, dim3(N, nres), dim3(kAT), kargs2, sm1, st));
+            } else {
+                HIP_TRY(hipLaunchKernel(attc2_kernel<false>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
+            }
         } else {
             hipLaunchKernelGGL((k_attc<false>), dim3(N, nres), dim3(256), smem, st, at);
         }
@@ -1439,7 +1447,13 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             a2.tall = (getenv("CF_STAMP_ATTC_ALL") && atoi(getenv("CF_STAMP_ATTC_ALL")) == 1 && (!getenv("CF_STAMP_ATTC_AG") || atoi(getenv("CF_STAMP_ATTC_AG")) == ag))
                           ? reinterpret_cast<unsigned long long*>(h->tdbg) + 256 : nullptr;
             void* kargs2[] = {&a2};
-            HIP_TRY(hipLaunchKernel(attc2_kernel<true>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
+            if (ag == 1 && h->attc1) {
+                size_t sm1 = 0;
+                for (int r = 0; r < nres; ++r) sm1 = std::max(sm1, attc1_smem(at.L[r], F));
+                HIP_TRY(hipLaunchKernel((const void*)k_attc1<true>, dim3(N, nres), dim3(kAT), kargs2, sm1, st));
+            } else {
+                HIP_TRY(hipLaunchKernel(attc2_kernel<true>(ag), dim3((N + ag - 1) / ag, nres), dim3(kAT), kargs2, sm2, st));
+            }
         } else {
             hipLaunchKernelGGL((k_attc<true>), dim3(N, nres), dim3(256), smem, st, at);
         }
