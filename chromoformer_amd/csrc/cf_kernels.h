@@ -1644,10 +1644,10 @@ __global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs
     for (int s = 0; s < j.nseg; ++s) {
         const WgSeg& sg = j.seg[s];
         const int m1 = g1 * sg.rows_per_gene;
-#pragma unroll 4
-        for (int m = g0 * sg.rows_per_gene; m < m1; ++m) {
-            const float av = sg.A[(size_t)m * sg.lda + e];
-            const float4 bv = *reinterpret_cast<const float4*>(sg.B + (size_t)m * sg.ldb + fh * 4);
+#pragma unroll 8
+        for (int m = g0 * sg.rows_per_gene; m < m1; ++m) {      // (global-address-space loads: pointers out of a device table are generic)
+            const float av = ldg(sg.A + (size_t)m * sg.lda + e);
+            const float4 bv = ldg4(sg.B + (size_t)m * sg.ldb + fh * 4);
             acc[0] = fmaf(av, bv.x, acc[0]);
             acc[1] = fmaf(av, bv.y, acc[1]);
             acc[2] = fmaf(av, bv.z, acc[2]);
@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs
     float* out = j.partial + (size_t)blockIdx.x * (kD * j.F) + e * j.F;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (fh * 4 + k < j.F) out[fh * 4 + k] = acc[k];
+        if (fh * 4 + k < j.F) stg(out + fh * 4 + k, acc[k]);
 }
 
 // Deferred column sums (bias / LayerNorm / gamma gradients): out[c] = sum_m src[m][c] (* src2[m][c])
