@@ -1616,8 +1616,7 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch) {
         for (int i = 0; i < 4; ++i) {
             const int row = t.n0 + w * 16 + lq * 4 + i;
             if (row < t.Nn)
-                *reinterpret_cast<float4*>(t.C + (size_t)row * t.ldc + kc + 64 * h) =
-                    make_float4(acc[4 * h + 0][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i]);
+                stg4(t.C + (size_t)row * t.ldc + kc + 64 * h, make_float4(acc[4 * h + 0][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i]));
         }
     }
 }
@@ -1686,7 +1685,7 @@ __device__ __forceinline__ void colsum_tile(const CsTile& t, int batch) {
     }
     red[ph][threadIdx.x & 63] = s;
     __syncthreads();
-    if (ph == 0 && c < t.ncols) t.out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (ph == 0 && c < t.ncols) stg(t.out + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 __global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles, int batch) { colsum_tile(tiles[blockIdx.x], batch); }
 // Both reductions of a gradient bucket in ONE launch: workgroups [0, n_wg) take weight-gradient tiles, the rest column-sum
