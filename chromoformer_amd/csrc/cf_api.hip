@@ -996,13 +996,22 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
     auto centre_layer = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* xin, RowMap xmap,
                             const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff,
                             float* const* outp, RowMap omap, bool copy_x, const float* const* lin_w = nullptr,
-                            float* const* lin_y = nullptr) -> int {
+                            float* const* lin_y = nullptr, bool q_done = false, const CentreParams* next_prm = nullptr,
+                            CentreBuf* const* next_bufs = nullptr) -> int {
+        // q_done: the previous layer's chain kernel has already run this layer's query chain; next_prm / next_bufs: run the next
+        // layer's query chain at the end of this layer's chain kernel (only for identity row maps: the output tile IS its input)
         QChainArgs q;
         AttcArgs at;
         PostArgs po;
         for (int r = 0; r < kMaxRes; ++r) {
             po.lin_w[r] = lin_w && r < nres ? lin_w[r] : nullptr;
             po.lin_y[r] = lin_y && r < nres ? lin_y[r] : nullptr;
+            if (next_prm && r < nres) {
+                po.nq_wq[r] = next_prm[r].wq_t;
+                po.nq_wk[r] = next_prm[r].wk;
+                po.nq_q[r] = next_bufs[r]->q;
+                po.nq_qt[r] = next_bufs[r]->qt;
+            }
         }
         size_t smem = 0;
         for (int r = 0; r < nres; ++r) {
@@ -1055,8 +1064,10 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         po.omap = omap;
         po.N = N;
         po.save = save;
-        hipLaunchKernelGGL((k_qchain_fwd<kPostWaves>), dim3(tiles_of(N), nres), dim3(kPostWaves * 64), 0, st, q);
-        LAUNCH_CHECK("k_qchain_fwd");
+        if (!q_done) {
+            hipLaunchKernelGGL((k_qchain_fwd<kPostWaves>), dim3(tiles_of(N), nres), dim3(kPostWaves * 64), 0, st, q);
+            LAUNCH_CHECK("k_qchain_fwd");
+        }
         if (h->attc2) {
             const int ag = attc2_regions_per_wg(N, h->attc_cap);
             Attc2Args a2;
@@ -1155,8 +1166,15 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         }
         const RowMap xmap = l == 0 ? RowMap{S, 1, 0, 0} : identity_map();
         const RowMap omap = last ? RowMap{S, T, 1, 1} : identity_map();
+        CentreParams npp[kMaxRes];
+        CentreBuf* nbufs[kMaxRes];
+        if (!last)
+            for (int r = 0; r < nres; ++r) {
+                npp[r] = pair_params(h, r, l + 1);
+                nbufs[r] = &h->P[r][l + 1];
+            }
         if (centre_layer(bufs, pp, xin, xmap, bt->pcre_feats, bt->pcre_mask_row, bt->pcre_mask_stride, NP, c.pair_dff, outp, omap,
-                         l == 0))
+                         l == 0, nullptr, nullptr, l > 0, last ? nullptr : npp, last ? nullptr : nbufs))
             return -1;
     }
     if (h->reg_fused) {   // Regulation: all layers in one launch, one workgroup per (gene, resolution)

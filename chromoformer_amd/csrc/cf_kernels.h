@@ -901,6 +901,12 @@ struct PostArgs {
     int save;    // 0: inference, skip the activation saves
     const float* lin_w[kMaxRes] = {};   // optional trailing Linear without bias on the chain's output rows (tiled [128,128] copy):
     float* lin_y[kMaxRes] = {};         // lin_y = out . lin_w^T, rows [N,128] (the Embedding's layer feeds lin_proj_p, net.py:118)
+    // optional: the query chain of the NEXT layer on the chain's output rows (q = out Wq^T, qt[h] = q[h] Wk[h]; k_qchain_fwd's
+    // work on the tile that is in LDS anyway: one launch and one round trip through memory less per layer boundary)
+    const float* nq_wq[kMaxRes] = {};   // next layer's Wq, tiled copy
+    const float* nq_wk[kMaxRes] = {};   // next layer's Wk, row-major
+    float* nq_q[kMaxRes] = {};          // [N,128]
+    float* nq_qt[kMaxRes] = {};         // [N,2,128]
 };
 
 // NWV waves per workgroup (4 or 8): wave w owns 128 / NWV output columns of every product (DFF / NWV of the hidden layer), so with
@@ -996,11 +1002,48 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
                 xs[row][col] = acc[t][i] + a.b2[r][col] + ts[row][col];
             }
     }
-    const bool lin = a.lin_w[r] != nullptr;
-    FragNT<NTC, 8> fl;
+    const bool lin = a.lin_w[r] != nullptr, nq = a.nq_wq[r] != nullptr;
+    FragNT<NTC, 8> fl;      // (operand ring of the trailing Linear, or of the next layer's q projection: never both)
     if (lin) frag_load_nt(fl, a.lin_w[r] + (size_t)(w * CW) * kD, kD);
+    if (nq) frag_load_nt(fl, a.nq_wq[r] + (size_t)(w * CW) * kD, kD);
     __syncthreads();
     if (w < 4) ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+    if (nq) {
+        constexpr int EW = 256 / NWV, NTE = EW / 16;          // qt columns per wave (2 heads x 128)
+        const int hq = (w * EW) >> 7, e0 = (w * EW) & 127;
+        FragNN<NTE, 4> fk;
+        frag_load_nn(fk, a.nq_wk[r] + (size_t)(hq * 64) * kD + e0, kD);
+        __syncthreads();
+        {   // q = out Wq^T   (ts is free: the last reader was the FFN's second product)
+            f32x4 acc[NTC];
+            zero_acc(acc);
+            frag_mma_nt(fl, &xs[0][0], kD + 4, acc);
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
+                    ts[row][col] = acc[t][i];
+                    if (row0 + row < N) a.nq_q[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+                }
+        }
+        __syncthreads();
+        {
+            f32x4 acc[NTE];
+            zero_acc(acc);
+            frag_mma_nn(fk, &ts[0][hq * 64], kD + 4, acc);
+            typedef typename VecN<NTE>::type vec_t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lq * 4 + i;
+                float v[NTE];
+#pragma unroll
+                for (int t = 0; t < NTE; ++t) v[t] = acc[t][i];
+                if (row0 + row < N)
+                    LdgN<NTE>::st(a.nq_qt[r] + (size_t)(row0 + row) * 256 + hq * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
+            }
+        }
+    }
     if (lin) {      // one launch less than a separate Linear kernel on 4 row tiles
         __syncthreads();
         f32x4 acc[NTC];
