@@ -109,7 +109,9 @@ def train_loop_rate(model, lr, steps, store_genes, regime, dev):
 def dp_path_ms(model, batch, steps, warmup, dev):
     """Fixed overhead of the data-parallel code path, measurable on ONE GPU: the same step through a one-rank RCCL group
     (two graphs, two all-reduces of the 16.6 MB / 4.6 MB buckets -- in-place no-ops for RCCL at world 1 but launched --,
-    three event waits), overlapped and serialised schedule."""
+    three event waits), overlapped and serialised schedule, graph replay and eager launches.  Every leg runs at least 200
+    steps whatever --steps says (a 20-step sample let one 12 ms stall double a leg in BENCH_r02.json), and an event behind
+    every step gives the longest single step of the leg (`max_step_ms`), so that a stall shows as what it is."""
     import socket
     import torch.distributed as dist
     from chromoformer_amd.engine import Trainer
@@ -120,7 +122,8 @@ def dp_path_ms(model, batch, steps, warmup, dev):
     port = s.getsockname()[1]
     s.close()
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
-    out = {}
+    steps, warmup = max(200, steps), max(20, warmup)
+    out, worst = {}, {}
     try:
         for key, overlap, graph in (("overlapped", True, True), ("serialised", False, True), ("overlapped_eager", True, False),
                                     ("serialised_eager", False, False)):
@@ -129,13 +132,19 @@ def dp_path_ms(model, batch, steps, warmup, dev):
             for _ in range(warmup):
                 trainer.step(slot)
             torch.cuda.synchronize()
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
             t0 = time.perf_counter()
-            for _ in range(steps):
+            marks[0].record(trainer.stream)
+            for k in range(steps):
                 trainer.step(slot)
+                marks[k + 1].record(trainer.stream)
             torch.cuda.synchronize()
             out[key] = round(1e3 * (time.perf_counter() - t0) / steps, 4)
+            worst[key] = round(max(marks[k].elapsed_time(marks[k + 1]) for k in range(steps)), 4)
     finally:
         dist.destroy_process_group()
+    out["max_step_ms"] = worst
+    out["steps"] = steps
     return out
 
 
@@ -205,10 +214,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph in the timed region (split in two around the "
-                    "event-bracketed roofline kernel: measured +12 us per step); default: the 33 launches of a step are issued eagerly, "
-                    "with HIP events around the roofline kernel, and the one-graph replay time is reported as `graph_replay_ms_per_step`")
-    ap.add_argument("--no-graph", action="store_true", help="(the default since round 2; kept for old command lines)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the step as hipGraphs in the timed region (split around the event-bracketed roofline kernel: measured "
+                         "+8..12 us per step).  Default: graph replay under data parallelism (--gpus > 1: five host calls per step "
+                         "instead of ~30 matter with eight ranks driving one host), eager launches on one GPU, where the one-graph "
+                         "replay time is reported beside it as `graph_replay_ms_per_step`")
+    ap.add_argument("--eager", "--no-graph", dest="graph", action="store_false", help="issue the launches of a step one by one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regime", default="dense", choices=["dense", "realistic"])
     ap.add_argument("--config", default="default", choices=["default", "stress"],
@@ -255,6 +266,8 @@ def main():
     from chromoformer_amd.engine import Trainer
     from chromoformer_amd.synth import synthetic_batch
 
+    if args.graph is None:
+        args.graph = world > 1
     model = ChromoformerClassifier(seed=42, max_batch=BSZ).cuda(local)
     batch = synthetic_batch(BSZ, seed=1234 + rank, regime=args.regime)
     trainer = Trainer(model, lr=3e-5, world_size=world, process_group=pg, use_graph=args.graph,

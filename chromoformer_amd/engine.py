@@ -174,7 +174,8 @@ class Trainer:
         self.stream = torch.cuda.Stream(device=model._device)
         self.side = torch.cuda.Stream(device=model._device)       # all-reduce of the early gradient bucket
         torch.cuda.synchronize(model._device)      # parameter upload / buffer fills of the model ran on the default stream
-        self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        # four events, created once: a fresh torch.cuda.Event per step is a hipEventCreate on the critical path of the host loop
+        self._ev_fork, self._ev_join, self._ev_late, self._ev_done = (torch.cuda.Event() for _ in range(4))
         self._buckets = {}
         for b in (_lib.BUCKET_REG, _lib.BUCKET_PE):
             off, n = C.c_longlong(), C.c_longlong()
@@ -318,12 +319,11 @@ class Trainer:
             else:
                 # the late bucket's all-reduce goes to the side stream as well (behind the early one) and the main stream
                 # steps the early bucket meanwhile: only the late bucket's 6 us of AdamW wait for the second all-reduce
-                ev_late = torch.cuda.Event()
+                ev_late, ev_done = self._ev_late, self._ev_done
                 ev_late.record(self.stream)
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ev_late)
                     torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
-                    ev_done = torch.cuda.Event()
                     ev_done.record(self.side)
                 self.stream.wait_event(self._ev_join)            # early bucket reduced
                 m._step += 1

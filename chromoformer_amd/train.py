@@ -114,11 +114,19 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # the same two hooks as bench.py: CF_SHARE_DEVICE=1 puts every rank on device 0 and CF_DIST_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device) -- how the multi-process entrypoint is exercised on a one-GPU box
+    if os.environ.get("CF_SHARE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("CF_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
     say = print if rank == 0 else (lambda *a, **k: None)
     say(config)
@@ -128,6 +136,11 @@ def main(argv=None):
     i_max, w_prom, w_max, n_feats = config["i_max"], config["w_prom"], config["w_max"], config["n_feats"]
     d_emb = config["embed"]["d_model"]
 
+    if rank == 0:
+        # a marker (or a half-written file) of an EARLIER run to the same output must not vouch for this one
+        for stale in (args.output + ".done", args.output + ".tmp"):
+            if os.path.exists(stale):
+                os.remove(stale)
     seed_everything(seed)
     wandb.init(project="chromoformer-refactoring", entity="dohlee", group=args.exp_id)
     wandb.config.update(args)
@@ -172,6 +185,10 @@ def main(argv=None):
     criterion = nn.MSELoss() if args.regression else nn.CrossEntropyLoss()
     trainer = Trainer(model, lr=float(config["lr"]), gamma=gamma, world_size=world, process_group=pg)
     feed = EpochFeed(model, train_store, bsz)          # batches are gathered from the resident split inside the step graph
+    if world > 1:                                      # one line per rank: what it loaded (stderr; stdout stays rank 0's, as in the reference)
+        n_steps = (len(train_genes) // world // bsz) if static else (len(train_genes) // (world * bsz))
+        print("[rank %d/%d] dp-shard %s: train store %d of %d genes, validation slice %d of %d genes, %d steps per epoch"
+              % (rank, world, args.dp_shard, len(train_store), len(train_genes), len(val_store), n_val, n_steps), file=sys.stderr, flush=True)
 
     val_score = val_label = val_loss = None
     for epoch in range(1, num_epoch):
