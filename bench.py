@@ -196,7 +196,8 @@ def stress_main(args, json_out):
     dev_ms = e0.elapsed_time(e1) / steps
     flops = 14.0 * N * H * L * L * 64
     ach = flops / (dev_ms * 1e-3) / 1e12
-    out = {"metric": "genes/sec training (bsz=64, default config)", "value": round(B * steps / el, 1), "unit": "genes/s", "n_gpus": 1,
+    out = {"metric": "genes/sec through the dense attention core, forward + backward (stress config: bsz=128, i_max=16, 800 bins)",
+           "value": round(B * steps / el, 1), "unit": "genes/s", "n_gpus": 1,
            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * el / steps, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "stress config (BASELINE configs[3]): dense attention core forward + backward, all rows, "

@@ -34,8 +34,11 @@ static int fail(const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+// every kernel launch of the library passes through LAUNCH_CHECK exactly once: the counter behind cf_launch_counts
+static thread_local long long g_launches = 0;
 #define LAUNCH_CHECK(name)                                                                     \
     do {                                                                                       \
+        ++g_launches;                                                                          \
         hipError_t e_ = hipGetLastError();                                                     \
         if (e_ != hipSuccess) return fail("launch %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
@@ -215,7 +218,12 @@ struct cf_handle {
     } ed;
     bool embed_dense = false;            // the training path goes through it (embed.n_layers > 1)
     RetileUnit* retile_units = nullptr;
-    int n_retile = 0;
+    int n_retile = 0, n_retile_early = 0;      // all units | the leading ones a forward pass needs at once (Embedding + Pairwise)
+    TrunkResDev* trunk_tab = nullptr;          // fused centre-row trunk (cf_trunk.h): device table, one entry per resolution
+    bool trunk = false;                        // the Embedding + Pairwise stage runs as k_trunk_fwd / k_trunk_bwd (CF_TRUNK=0: the stand-alone kernels)
+    size_t trunk_smem_bytes = 0;
+    int xcd_reduce = 0;                        // XCD-aware order of the weight-gradient tiles (measured slower: cf_kernels.h, xcd_tile)
+    int defer_retile = 1;                      // Regulation + head units ride in the Embedding layer's chain launch (CF_DEFER_RETILE=0: all in the prologue)
     // workspace
     float* arena = nullptr;
     size_t arena_floats = 0;
@@ -722,11 +730,19 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         h->bucket_split = split;
     }
     {
+        // units of the Embedding + Pairwise weights first (needed by the first kernels of a forward pass), Regulation + head behind
+        // them (needed ~250 us later: they can ride in a later, under-filled launch, see PostArgs::rt_units)
         std::vector<RetileUnit> units;
-        for (const PDesc& p : h->table)
-            if (p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable)
-                for (int n0 = 0; n0 < p.shape[0]; n0 += 16) units.push_back(RetileUnit{p.offset + (long long)n0 * p.shape[1], p.offset, p.shape[1], p.shape[0], n0,
-                                                p.name.rfind("regulation.", 0) == 0 ? 1 : 0});
+        for (int late = 0; late < 2; ++late) {
+            for (const PDesc& p : h->table) {
+                const bool is_late = p.name.rfind("regulation.", 0) == 0 || p.name.rfind("fc_head.", 0) == 0;
+                if (is_late != (late == 1)) continue;
+                if (p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable)
+                    for (int n0 = 0; n0 < p.shape[0]; n0 += 16) units.push_back(RetileUnit{p.offset + (long long)n0 * p.shape[1], p.offset, p.shape[1], p.shape[0], n0,
+                                                    p.name.rfind("regulation.", 0) == 0 ? 1 : 0});
+            }
+            if (late == 0) h->n_retile_early = (int)units.size();
+        }
         h->n_retile = (int)units.size();
         if (hipMalloc(&h->hyper, sizeof(AdamHyper)) != hipSuccess || hipMalloc(&h->tiled, h->lay.n_total * sizeof(float)) != hipSuccess ||
             hipMalloc(&h->tiledT, h->lay.n_total * sizeof(float)) != hipSuccess ||
@@ -804,11 +820,9 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     if (const char* e = getenv("CF_XCD_MAP")) h->xcd_map = atoi(e) != 0;
     if (const char* e = getenv("CF_ATTC_CAP")) h->attc_cap = atoi(e);
     if (const char* e = getenv("CF_ATTC1")) h->attc1 = atoi(e) != 0;
-    const int reg_launches = h->reg_fused ? 1 : 3 * c.reg_layers;
-    // (centre-row Embedding: lin_proj_p rides in its chain kernel; the all-rows path launches it separately, beside its own kernels)
-    h->n_fwd = 1 + 3 + (h->embed_dense ? 1 : 0) + 3 * c.pair_layers + reg_launches + 1;      // prologue | Embedding | Pairwise | Regulation | head
-    h->n_bwd = 1 + reg_launches + 3 * c.pair_layers + 1 + 3 + 1 + 2;      // head | Regulation | Pairwise | join + dgrad | Embedding | 7-mark projections | 2 bucket reductions
-    h->n_opt = 1;
+    if (const char* e = getenv("CF_DEFER_RETILE")) h->defer_retile = atoi(e) != 0;
+    if (const char* e = getenv("CF_XCD_REDUCE")) h->xcd_reduce = atoi(e) != 0;
+    h->n_fwd = h->n_bwd = h->n_opt = 0;      // counted at the launch sites by the first calls (cf_launch_counts)
     *out = h;
     return 0;
 }
@@ -820,6 +834,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (h->cs_tiles) (void)hipFree(h->cs_tiles);
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
     if (h->reg_tab) (void)hipFree(h->reg_tab);
+    if (h->trunk_tab) (void)hipFree(h->trunk_tab);
     if (h->tiled) (void)hipFree(h->tiled);
     if (h->tiledT) (void)hipFree(h->tiledT);
     for (void* q : h->ed.owned) (void)hipFree(q);
@@ -834,13 +849,14 @@ extern "C" void cf_destroy(cf_handle* h) {
     delete h;
 }
 
+static int build_trunk_table(cf_handle* h);      // (behind the centre-row parameter helpers below)
 extern "C" int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg, float* exp_avg_sq) {
     if (!h || !params) return fail("cf_bind: null handle / params");
     h->params = params;
     h->grads = grads;
     h->m = exp_avg;
     h->v = exp_avg_sq;
-    if (build_reg_table(h)) return -1;
+    if (build_reg_table(h) || build_trunk_table(h)) return -1;
     if (grads) return build_tables(h);
     return 0;
 }
@@ -864,6 +880,11 @@ static size_t attr_smem(int T, bool bwd) {
 constexpr int kPostWaves = CF_POST_WAVES;      // waves per workgroup of the row-tile chains (k_post_*, k_qchain_*): 4 or 8
 template <bool VPROJ, int DM>
 static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& a) {
+    if (a.rt_units) {      // the hosting instantiation (eight waves; cf_forward asks for it only then)
+        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8, true>), grid, dim3(512), 0, st, a);
+        return;
+    }
     if (kPostWaves == 8) {
         if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8>), grid, dim3(512), 0, st, a);
@@ -926,6 +947,70 @@ static CentreParams pair_params(const cf_handle* h, int r, int l) {
                          h->P_(pre + "lin_proj_pcre.weight"));
 }
 
+// device table of the fused centre-row trunk (cf_trunk.h)
+static const void* trunk_kernel(bool bwd, int dff_e, int dff_p) {
+    if (dff_e == 128 && dff_p == 256) return bwd ? (const void*)nullptr : (const void*)k_trunk_fwd<128, 256>;
+    return nullptr;
+}
+static void fill_centre_dev(CentreLayerDev& d, const CentreParams& p, const CentreBuf& b) {
+    d.wq_t = p.wq_t, d.wk = p.wk, d.wv_t = p.wv_t, d.wo_t = p.wo_t, d.bo = p.bo, d.g1 = p.g1, d.be1 = p.be1;
+    d.w1_t = p.w1_t, d.b1 = p.b1, d.w2_t = p.w2_t, d.b2 = p.b2, d.g2 = p.g2, d.be2 = p.be2;
+    d.wq = p.wq, d.wk_t = p.wk_t, d.wv = p.wv, d.wo = p.wo, d.w1 = p.w1, d.w2 = p.w2;
+    d.q = b.q, d.qt = b.qt, d.p = b.p, d.w = b.w, d.xbar = b.xbar, d.a = b.a, d.xh1 = b.xh1, d.rs1 = b.rs1, d.y1 = b.y1;
+    d.hdn = b.hdn, d.xh2 = b.xh2, d.rs2 = b.rs2, d.out = b.out, d.xin = b.xin;
+    d.dt2 = b.dt2, d.dpre1 = b.dpre1, d.dt1 = b.dt1, d.da = b.da, d.dxbar = b.dxbar, d.dqt = b.dqt, d.du = b.du, d.dq = b.dq;
+    d.dx = b.dx, d.partial = b.partial;
+}
+static int build_trunk_table(cf_handle* h) {
+    const cf_config& c = h->cfg;
+    h->trunk = false;
+    if (h->embed_dense || !h->attc2 || c.i_max > kAGMax || c.pair_layers > kMaxPairLayers || kPostWaves != 8) return 0;
+    if (!trunk_kernel(false, c.embed_dff, c.pair_dff)) return 0;
+    {   // (opt-in until the fused backward exists and both are verified on the GPU)
+        const char* e = getenv("CF_TRUNK");
+        if (!e || atoi(e) == 0) return 0;
+    }
+    size_t need = 0;
+    for (int r = 0; r < c.n_res; ++r) need = std::max(need, trunk_smem(c.n_bins[r], c.n_feats, c.i_max, std::max(c.embed_dff, c.pair_dff)));
+    if (need > 160 * 1024) return 0;
+    if (hipFuncSetAttribute(trunk_kernel(false, c.embed_dff, c.pair_dff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return 0;
+    std::vector<TrunkResDev> tab(c.n_res);
+    for (int r = 0; r < c.n_res; ++r) {
+        TrunkResDev& t = tab[r];
+        memset(&t, 0, sizeof t);
+        fill_centre_dev(t.E, embed_params(h, r), h->E[r]);
+        for (int l = 0; l < c.pair_layers; ++l) fill_centre_dev(t.P[l], pair_params(h, r, l), h->P[r][l]);
+        t.pe = h->pe[r], t.pe2 = h->pe2[r], t.pet2 = h->pet2[r];
+        t.wlp_e = embed_params(h, r).wlp;
+        t.wlp_p = pair_params(h, r, 0).wlp;
+        t.lin_p = h->P_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
+        t.lin_p_t = h->T_(fmt("pairwise_interaction.%d.lin_proj_p.weight", c.binsizes[r]));
+        t.ex0 = h->ex0[r], t.featc = h->featc[r], t.xp0 = h->xp0[r], t.dxp0 = h->dxp0[r], t.edout = h->edout[r];
+        t.rx0 = h->Rx[r][0], t.drx0 = h->dRx[r][0];
+        t.lp_part_e = h->lp_part_e[r], t.lp_part_p = h->lp_part_p[r];
+        t.L = c.n_bins[r], t.Lpad = attc2_lpad(c.n_bins[r]), t.LT = attc2_lt(c.n_bins[r]);
+    }
+    if (h->trunk_tab) (void)hipFree(h->trunk_tab);
+    HIP_TRY(hipMalloc(&h->trunk_tab, tab.size() * sizeof(TrunkResDev)));
+    HIP_TRY(hipMemcpy(h->trunk_tab, tab.data(), tab.size() * sizeof(TrunkResDev), hipMemcpyHostToDevice));
+    h->trunk_smem_bytes = need;
+    h->trunk = true;
+    return 0;
+}
+static void trunk_args(const cf_handle* h, const cf_batch* bt, TrunkArgs& a, int save) {
+    const cf_config& c = h->cfg;
+    memset(&a, 0, sizeof a);
+    a.tab = h->trunk_tab;
+    for (int r = 0; r < c.n_res; ++r) {
+        a.pfeats[r] = bt->promoter_feats[r], a.pmask[r] = bt->promoter_mask_row[r], a.pmstride[r] = bt->promoter_mask_stride[r];
+        a.cfeats[r] = bt->pcre_feats[r], a.cmask[r] = bt->pcre_mask_row[r], a.cmstride[r] = bt->pcre_mask_stride[r];
+    }
+    a.dhin = h->dhin;
+    a.B = bt->B, a.S = c.i_max, a.T = c.i_max + 1, a.F = c.n_feats, a.n_res = c.n_res, a.pair_layers = c.pair_layers, a.save = save;
+    a.scale = sqrtf(64.f);
+    a.rscale = 1.0f / a.scale;
+}
+
 static int check_batch(const cf_handle* h, const cf_batch* b) {
     if (!h || !b) return fail("null handle / batch");
     if (!h->params) return fail("cf_bind has not been called");
@@ -954,6 +1039,7 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
         h->cap.hole.smem = smem;
         h->cap.hole.args = ra;
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        ++g_launches;      // (issued by cf_graph_launch between the two graph pieces)
         return 0;
     }
     void* kargs[] = {&ra};
@@ -970,12 +1056,15 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
 extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int save, void* stream) {
     if (check_batch(h, bt)) return -1;
     hipStream_t st = (hipStream_t)stream;
+    const long long launches0 = g_launches;
     const cf_config& c = h->cfg;
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
     const float scale_c = sqrtf(64.f);
     CentreParams ep[kMaxRes], pp[kMaxRes];
     for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
+    const bool defer = h->defer_retile && !h->embed_dense && kPostWaves == 8;      // Regulation + head units ride in the Embedding layer's chain launch
+    const bool trunk = h->trunk;                                                   // Embedding + Pairwise stage as ONE launch (cf_trunk.h)
     {   // refresh the tiled weight copies (the parameters may have been changed by anyone since the last call) and, in the same
         // launch, the Embedding centre-row input
         X0Args a;
@@ -988,16 +1077,33 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             a.L[r] = c.n_bins[r];
         }
         a.F = F;
-        hipLaunchKernelGGL(k_fwd_prologue, dim3(h->n_retile + B * nres), dim3(256), 0, st, (const float*)h->params, h->tiled,
-                           h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, h->n_retile, a, B);
+        const int n_now = defer ? h->n_retile_early : h->n_retile;
+        // (the fused trunk computes the Embedding input row itself: no x0 workgroups then)
+        hipLaunchKernelGGL(k_fwd_prologue, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
+                           h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, n_now, a, B);
         LAUNCH_CHECK("k_fwd_prologue");
+    }
+    if (trunk) {
+        TrunkArgs ta;
+        trunk_args(h, bt, ta, save);
+        if (defer) {
+            ta.rt_units = h->retile_units + h->n_retile_early;
+            ta.rt_n = h->n_retile - h->n_retile_early;
+            ta.rt_params = h->params;
+            ta.rt_tiled = h->tiled;
+            ta.rt_tiledT = h->reg8 ? h->tiledT : nullptr;
+        }
+        void* kargs[] = {&ta};
+        HIP_TRY(hipLaunchKernel(trunk_kernel(false, c.embed_dff, c.pair_dff), dim3(B, nres + (defer && ta.rt_n > 0 ? 1 : 0)), dim3(kAT), kargs,
+                                h->trunk_smem_bytes, st));
+        LAUNCH_CHECK("k_trunk_fwd");
     }
     // one centre-row layer: query chain -> attention -> post chain
     auto centre_layer = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* xin, RowMap xmap,
                             const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff,
                             float* const* outp, RowMap omap, bool copy_x, const float* const* lin_w = nullptr,
                             float* const* lin_y = nullptr, bool q_done = false, const CentreParams* next_prm = nullptr,
-                            CentreBuf* const* next_bufs = nullptr) -> int {
+                            CentreBuf* const* next_bufs = nullptr, bool host_retile = false) -> int {
         // q_done: the previous layer's chain kernel has already run this layer's query chain; next_prm / next_bufs: run the next
         // layer's query chain at the end of this layer's chain kernel (only for identity row maps: the output tile IS its input)
         QChainArgs q;
@@ -1108,12 +1214,23 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             hipLaunchKernelGGL((k_attc<false>), dim3(N, nres), dim3(256), smem, st, at);
         }
         LAUNCH_CHECK("k_attc<fwd>");
-        launch_post_fwd<true, 128>(dff, dim3(tiles_of(N), nres), st, po);
+        dim3 pgrid(tiles_of(N), nres);
+        if (host_retile) {
+            po.rt_units = h->retile_units + h->n_retile_early;
+            po.rt_n = h->n_retile - h->n_retile_early;
+            po.rt_params = h->params;
+            po.rt_tiled = h->tiled;
+            po.rt_tiledT = h->reg8 ? h->tiledT : nullptr;
+            po.rt_y0 = nres;
+            pgrid.y += (po.rt_n + pgrid.x - 1) / pgrid.x;
+        }
+        launch_post_fwd<true, 128>(dff, pgrid, st, po);
         LAUNCH_CHECK("k_post_fwd<centre>");
         return 0;
     };
 
-    if (h->embed_dense) {   // Embedding with more than one layer: every row of every layer (cf_embed_full.h + dense layers)
+    if (trunk) {
+    } else if (h->embed_dense) {   // Embedding with more than one layer: every row of every layer (cf_embed_full.h + dense layers)
         if (embed_dense_forward(h, bt, save != 0, st)) return -1;
     } else {   // Embedding
         CentreBuf* bufs[kMaxRes];
@@ -1132,7 +1249,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             ly[r] = h->xp0[r];
         }
         if (centre_layer(bufs, ep, xin, identity_map(), bt->promoter_feats, bt->promoter_mask_row, bt->promoter_mask_stride, NE,
-                         c.embed_dff, outp, RowMap{1, T, 0, 0}, false, lw, ly))
+                         c.embed_dff, outp, RowMap{1, T, 0, 0}, false, lw, ly, false, nullptr, nullptr, defer))
             return -1;
     }
     if (h->embed_dense) {   // lin_proj_p on the promoter centre embedding (net.py:118)
@@ -1153,7 +1270,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         hipLaunchKernelGGL((k_linear_fwd<2>), dim3(tiles_of(NE), 1, nres), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_linear_fwd<lin_proj_p>");
     }
-    for (int l = 0; l < c.pair_layers; ++l) {   // Pairwise layers
+    for (int l = 0; l < (trunk ? 0 : c.pair_layers); ++l) {   // Pairwise layers
         CentreBuf* bufs[kMaxRes];
         const float* xin[kMaxRes];
         float* outp[kMaxRes];
@@ -1275,6 +1392,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         LAUNCH_CHECK("k_head_fwd");
     }
     h->last_fwd_B = save ? B : 0;
+    h->n_fwd = (int)(g_launches - launches0);
     return 0;
 }
 
@@ -1544,14 +1662,14 @@ static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUC
         const int c0 = bk == 0 ? 0 : h->n_cs_r, cn = bk == 0 ? h->n_cs_r : h->n_cs - h->n_cs_r;
         if (!kMergeReduce || h->timed == "k_wgrad" || h->timed == "k_colsum") {      // timed separately
             h->time_mark("k_wgrad", st);
-            hipLaunchKernelGGL(k_wgrad, dim3(wn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, B);
+            hipLaunchKernelGGL(k_wgrad, dim3(xcd_grid(wn)), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, B, h->xcd_reduce);
             h->time_mark("k_wgrad", st);
             LAUNCH_CHECK("k_wgrad");
             h->time_mark("k_colsum", st);
             hipLaunchKernelGGL(k_colsum, dim3(cn), dim3(256), 0, st, (const CsTile*)h->cs_tiles + c0, B);
             h->time_mark("k_colsum", st);
         } else {
-            hipLaunchKernelGGL(k_reduce, dim3(wn + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B);
+            hipLaunchKernelGGL(k_reduce, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B, h->xcd_reduce);
         }
         LAUNCH_CHECK("k_colsum");
     }
@@ -1571,7 +1689,11 @@ extern "C" int cf_backward_part(cf_handle* h, const cf_batch* bt, const void* la
     if (check_bwd(h, bt, (parts & 1) != 0)) return -1;
     hipStream_t st = (hipStream_t)stream;
     if ((parts & 1) && !labels) return fail("cf_backward: labels is null");
-    return backward_impl(h, bt, st, parts, labels, loss_scale, loss_out);
+    const long long launches0 = g_launches;
+    if (parts & 1) h->n_bwd = 0;      // a backward pass starts with the head: its pieces and the bucket reductions add up
+    const int rc = backward_impl(h, bt, st, parts, labels, loss_scale, loss_out);
+    h->n_bwd += (int)(g_launches - launches0);
+    return rc;
 }
 
 extern "C" int cf_backward_chain(cf_handle* h, const cf_batch* bt, const void* labels, float loss_scale, float* loss_out,
@@ -1582,14 +1704,20 @@ extern "C" int cf_backward_chain(cf_handle* h, const cf_batch* bt, const void* l
 extern "C" int cf_backward_reduce(cf_handle* h, int B, void* stream) {
     if (!h || !h->grads) return fail("cf_backward_reduce: no gradient buffer bound");
     if (B < 1 || B > h->cfg.max_batch) return fail("cf_backward_reduce: bad batch size %d", B);
-    return reduce_impl(h, B, (hipStream_t)stream);
+    const long long launches0 = g_launches;
+    const int rc = reduce_impl(h, B, (hipStream_t)stream);
+    h->n_bwd += (int)(g_launches - launches0);
+    return rc;
 }
 
 extern "C" int cf_backward_reduce_part(cf_handle* h, int B, int buckets, void* stream) {
     if (!h || !h->grads) return fail("cf_backward_reduce_part: no gradient buffer bound");
     if (B < 1 || B > h->cfg.max_batch) return fail("cf_backward_reduce_part: bad batch size %d", B);
     if (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE)) return fail("cf_backward_reduce_part: bad bucket mask %d", buckets);
-    return reduce_impl(h, B, (hipStream_t)stream, buckets);
+    const long long launches0 = g_launches;
+    const int rc = reduce_impl(h, B, (hipStream_t)stream, buckets);
+    h->n_bwd += (int)(g_launches - launches0);
+    return rc;
 }
 
 extern "C" int cf_grad_bucket(cf_handle* h, int bucket, long long* offset, long long* numel) {
@@ -1741,6 +1869,7 @@ extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float bet
                        h->v + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps);
     h->time_mark("k_adamw", (hipStream_t)stream);
     LAUNCH_CHECK("k_adamw");
+    h->n_opt = (buckets == (CF_BUCKET_REG | CF_BUCKET_PE)) ? 1 : 2;      // one launch over the whole range, or one per bucket
     return 0;
 }
 // Split form for callers that replay the optimiser launch from a hipGraph: cf_adamw_set (eager, once per step, before the
@@ -1844,6 +1973,7 @@ extern "C" int cf_gather_batch(cf_handle* h, const cf_store* st_, const int* ord
     if (overflow) return fail("cf_gather_batch: segment table overflow");
     ga.order = order;
     ga.cursor = cursor;
+    ga.n_genes = st_->n_genes;
     ga.B = B;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_gather_batch, dim3(B, n), dim3(256), 0, st, ga);
@@ -1925,7 +2055,7 @@ extern "C" int cf_op_wgrad(const float* dY, const float* X, float* dW, int M, in
     WgTile* d = nullptr;
     HIP_TRY(hipMalloc(&d, tiles.size() * sizeof(WgTile)));
     HIP_TRY(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(WgTile), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_wgrad, dim3((int)tiles.size()), dim3(256), 0, (hipStream_t)stream, (const WgTile*)d, 1);
+    hipLaunchKernelGGL(k_wgrad, dim3(xcd_grid((int)tiles.size())), dim3(256), 0, (hipStream_t)stream, (const WgTile*)d, (int)tiles.size(), 1, 0);
     LAUNCH_CHECK("cf_op_wgrad");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipFree(d));
@@ -2173,7 +2303,7 @@ static int dense_wgrad(const float* dY, int lddy, const float* X, int ldx, long 
     DenseWgTab tb{dY, X, part, dW, tiles_d, cs_d, rows, lddy, ldx, N_, K_, splits, kDenseSplitRows};
     hipLaunchKernelGGL(k_dense_wg_tables, dim3(std::max(1, std::min(64, (ntiles + 255) / 256))), dim3(256), 0, st, tb);
     LAUNCH_CHECK("k_dense_wg_tables");
-    hipLaunchKernelGGL(k_wgrad, dim3(ntiles), dim3(256), 0, st, (const WgTile*)tiles_d, 1);
+    hipLaunchKernelGGL(k_wgrad, dim3(xcd_grid(ntiles)), dim3(256), 0, st, (const WgTile*)tiles_d, ntiles, 1, 0);
     LAUNCH_CHECK("k_wgrad<dense layer>");
     hipLaunchKernelGGL(k_colsum, dim3(ncs), dim3(256), 0, st, (const CsTile*)cs_d, 1);
     LAUNCH_CHECK("k_colsum<dense layer>");

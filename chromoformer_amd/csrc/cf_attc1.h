@@ -22,13 +22,12 @@ __host__ __device__ inline size_t attc1_smem(int L, int F) {
 
 #define CF_STAMP1(slot)                                                                                   \
     do {                                                                                                  \
-        if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                              \
+        if (a.tdbg && stamp_wg == 0 && threadIdx.x == 0)                                                   \
             a.tdbg[(BWD ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime();                               \
     } while (0)
 template <bool BWD>
-__global__ __launch_bounds__(kAT) void k_attc1(Attc2Args a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int r = gridDim.y - 1 - blockIdx.y, n = blockIdx.x, tid = threadIdx.x;      // long-sequence workgroups first
+__device__ __forceinline__ void attc1_body(const Attc2Args& a, const int r, const int n, float* smem, const int stamp_wg = -1) {
+    const int tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63;
     const int L = a.L[r], Lpad = a.Lpad[r], LT = a.LT[r], F = a.F, LS = Lpad + 4;
     float* vin_s = smem;                      // [2][128]   qt / dxbar
@@ -305,6 +304,11 @@ __global__ __launch_bounds__(kAT) void k_attc1(Attc2Args a) {
         stg(a.vout[r] + (size_t)n * 256 + tid, v);
     }
     CF_STAMP1(7);
+}
+template <bool BWD>
+__global__ __launch_bounds__(kAT) void k_attc1(Attc2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    attc1_body<BWD>(a, gridDim.y - 1 - blockIdx.y, blockIdx.x, smem, blockIdx.y * gridDim.x + blockIdx.x);      // long-sequence workgroups first
 }
 
 }  // namespace cf

@@ -46,7 +46,7 @@ struct Attc2Args {
 };
 #define CF_STAMP2(slot)                                                                                   \
     do {                                                                                                  \
-        if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)                       \
+        if (a.tdbg && stamp_wg == 0 && (threadIdx.x & 63) == 0)                                            \
             a.tdbg[(threadIdx.x >> 6) * 32 + (BWD ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime();      \
     } while (0)
 constexpr int kAGMax = 8;                                // regions per workgroup: 8, 4, 2 or 1 (template parameter AG)
@@ -94,27 +94,33 @@ __device__ __forceinline__ void frag_mma_nn_rt(FragNN<4, 8>& f, const float* As,
     }
 }
 
-template <bool BWD, int AG>
-__global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
+// LDS of the body: a SCRATCH part [sc | vin | red | u | w] that is dead when the body returns, and a PERSISTENT part
+// [Wlp | features | masks] that depends only on the regions (not on the layer or the direction): a caller that runs several
+// layers over the same regions (cf_trunk.h) stages it once and passes STAGED = true afterwards.
+__host__ __device__ inline size_t attc2_scratch_floats(int L) { return (size_t)kTile * (attc2_lpad(L) + 4) + 2 * kTile * (kD + 4) + 2 * kTile * 8; }
+__host__ __device__ inline size_t attc2_persist_bytes(int L, int F, int AG) {
+    return (size_t)(kD * 8 + AG * L * F + 8) * sizeof(float) + (size_t)AG * attc2_lpad(L);
+}
+template <bool BWD, int AG, bool STAGED = false>
+__device__ __forceinline__ void attc2_body(const Attc2Args& a, const int r, const int n0, const int N, float* scratch, float* persist,
+                                           const int stamp_wg = -1) {
     constexpr int kAG = AG;                   // rows 2*AG .. 15 of the MFMA tile are dead (zero operand rows)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // resolutions in reverse launch order: the long-sequence workgroups (last binsize) are dispatched first
-    const int r = gridDim.y - 1 - blockIdx.y, n0 = blockIdx.x * kAG, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-    const int L = a.L[r], Lpad = a.Lpad[r], LT = a.LT[r], F = a.F, LS = Lpad + 4, N = a.N;
+    const int L = a.L[r], Lpad = a.Lpad[r], LT = a.LT[r], F = a.F, LS = Lpad + 4;
     constexpr int LD = kD + 4, NW = kAT / 64;
-    float* sc_s = smem;                       // [16][LS]  scores -> p (fwd) / dp -> ds (bwd); zero for j >= L
+    float* sc_s = scratch;                    // [16][LS]  scores -> p (fwd) / dp -> ds (bwd); zero for j >= L
     float* vin_s = sc_s + kTile * LS;         // [16][LD]  qt / dxbar rows (m = 2*region + head)
     float* red_s = vin_s + kTile * LD;        // [16][LD]  K-split partial of the second table product
     float* u_s = red_s + kTile * LD;          // [16][8]
     float* w_s = u_s + kTile * 8;             // [16][8]
-    float* wlp_s = w_s + kTile * 8;           // [128][8]  Wlp, zero padded to 8 marks (all loops over marks run to 8)
+    float* wlp_s = persist;                   // [128][8]  Wlp, zero padded to 8 marks (all loops over marks run to 8)
     float* feats_s = wlp_s + kD * 8;          // [8][L][F] (+8 floats of slack: the padded mark loops read one past)
     uint8_t* mk_s = reinterpret_cast<uint8_t*>(feats_s + kAG * L * F + 8);   // [8][Lpad]
     const int nreg = min(kAG, N - n0);        // regions present in this workgroup
 
     CF_STAMP2(0);
-    if (a.tall && tid == 0) a.tall[(blockIdx.y * gridDim.x + blockIdx.x) * 2] = __builtin_amdgcn_s_memtime();
+    if (a.tall && tid == 0 && stamp_wg >= 0) a.tall[stamp_wg * 2] = __builtin_amdgcn_s_memtime();
     const int nblk = (L + 63) / 64;
     float* stat_s = red_s;                    // [2][16][16] per-(row, column block) softmax statistics (free until pass 5's reduction)
     static_assert(2 * kTile * 16 <= kTile * LD, "statistics fit in the K-split partial buffer");
@@ -138,10 +144,10 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
             const int m = tid >> 5, c4 = tid & 31;               // 16 rows x 32 float4
             if ((m >> 1) < nreg) vv = ldg4(a.vin[r] + (size_t)n0 * 256 + m * kD + c4 * 4);
         }
-        const float wl0 = (tid & 7) < F ? ldg(a.wlp[r] + (tid >> 3) * F + (tid & 7)) : 0.f;
-        const float wl1 = (tid & 7) < F ? ldg(a.wlp[r] + ((tid + kAT) >> 3) * F + (tid & 7)) : 0.f;      // kD * 8 = 2 * kAT entries
+        const float wl0 = !STAGED && (tid & 7) < F ? ldg(a.wlp[r] + (tid >> 3) * F + (tid & 7)) : 0.f;
+        const float wl1 = !STAGED && (tid & 7) < F ? ldg(a.wlp[r] + ((tid + kAT) >> 3) * F + (tid & 7)) : 0.f;      // kD * 8 = 2 * kAT entries
         uint32_t mwv[MW];
-        if (words) {
+        if (!STAGED && words) {
 #pragma unroll
             for (int k = 0; k < MW; ++k) {
                 const int idx = tid + k * kAT, sreg = idx / LW, jw = idx - sreg * LW;
@@ -153,10 +159,12 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         // operand rows take to arrive.  Always NFL feature loads, no branch around them and no select behind them: the wait counts
         // stay exact (strips past the end re-read the last one; when the 16-byte path does not apply the values are not used).
         {
-            const float* fa = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(fg) & ~(uintptr_t)15);
-            const int last4 = f16b ? (nf >> 2) - 1 : max((nf >> 2) - 2, 0);      // (aligned down: stay one strip inside)
+            if (!STAGED) {
+                const float* fa = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(fg) & ~(uintptr_t)15);
+                const int last4 = f16b ? (nf >> 2) - 1 : max((nf >> 2) - 2, 0);      // (aligned down: stay one strip inside)
 #pragma unroll
-            for (int u = 0; u < NFL; ++u) fv12[u] = ldg4(fa + (size_t)min(tid + u * kAT, last4) * 4);
+                for (int u = 0; u < NFL; ++u) fv12[u] = ldg4(fa + (size_t)min(tid + u * kAT, last4) * 4);
+            }
             const float* bm_ = a.pet[r] + min(w, nblk - 1) * 64;
             ft0.bp = bm_ + (size_t)(lq * 4) * LT + 4 * lr;
             ft0.ldb = LT;
@@ -171,9 +179,12 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         }
         *reinterpret_cast<float4*>(vin_s + (tid >> 5) * LD + (tid & 31) * 4) = vv;
         static_assert(kD * 8 == 2 * kAT, "wlp staging assumes two entries per thread");
-        wlp_s[tid] = wl0;
-        wlp_s[tid + kAT] = wl1;
-        if (words) {
+        if (!STAGED) {
+            wlp_s[tid] = wl0;
+            wlp_s[tid + kAT] = wl1;
+        }
+        if (STAGED) {
+        } else if (words) {
             uint32_t* mk_w = reinterpret_cast<uint32_t*>(mk_s);
 #pragma unroll
             for (int k = 0; k < MW; ++k)
@@ -253,7 +264,8 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
     }
     CF_STAMP2(8);
     // ---- features to LDS (behind the products)
-    if (f16b) {
+    if (STAGED) {
+    } else if (f16b) {
         const int n4 = (kAG * L * F) >> 2;
 #pragma unroll
         for (int u = 0; u < NFL; ++u) {
@@ -548,7 +560,15 @@ __global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
         }
     }
     CF_STAMP2(7);
-    if (a.tall && tid == 0) a.tall[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = __builtin_amdgcn_s_memtime();
+    if (a.tall && tid == 0 && stamp_wg >= 0) a.tall[stamp_wg * 2 + 1] = __builtin_amdgcn_s_memtime();
+}
+
+template <bool BWD, int AG>
+__global__ __launch_bounds__(kAT) void k_attc2(Attc2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // resolutions in reverse launch order: the long-sequence workgroups (last binsize) are dispatched first
+    const int r = gridDim.y - 1 - blockIdx.y;
+    attc2_body<BWD, AG>(a, r, blockIdx.x * AG, a.N, smem, smem + attc2_scratch_floats(a.L[r]), blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Regions per workgroup.  These kernels are latency-bound (a handful of workgroups per CU, dependent phases): the

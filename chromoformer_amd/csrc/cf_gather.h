@@ -18,14 +18,23 @@ struct GatherSeg {
 struct GatherArgs {
     GatherSeg seg[kGatherMaxSeg];
     const int* order;     // [n_batches * B] gene indices of the epoch, batch-major
-    const int* cursor;    // [0] = next batch
+    int* cursor;          // [0] = next batch, [1] = batches uploaded (bound), [2] = error flags (1: ran past the epoch, 2: bad gene index)
+    long long n_genes;    // genes in the store
     int B;
 };
 __global__ __launch_bounds__(256) void k_gather_batch(GatherArgs a) {
     const GatherSeg s = a.seg[blockIdx.y];
     const int b = blockIdx.x;
     const int cur = a.cursor[0];
+    if (cur < 0 || cur >= a.cursor[1]) {      // a step past the uploaded epoch: nothing is read (the batch buffers keep the last batch)
+        if (threadIdx.x == 0 && b == 0 && blockIdx.y == 0) a.cursor[2] |= 1;
+        return;
+    }
     const long long gene = a.order[(long long)cur * a.B + b];
+    if (gene < 0 || gene >= a.n_genes) {
+        if (threadIdx.x == 0) a.cursor[2] |= 2;      // (same value from every writer)
+        return;
+    }
     const char* src = s.src + gene * s.gene_bytes + s.off;
     char* dst = s.dst + (long long)b * s.gene_bytes + s.off;
     if ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)s.len) & 15) == 0) {
@@ -38,7 +47,9 @@ __global__ __launch_bounds__(256) void k_gather_batch(GatherArgs a) {
 }
 // The cursor is advanced by a launch of its own behind the gather (a ticket counter that lets the last workgroup do it
 // costs one device-scope atomic per workgroup on a single word: 17 us for 1,500 workgroups, 80 us for 2,900).
-__global__ void k_gather_advance(int* cursor) { cursor[0] += 1; }
+__global__ void k_gather_advance(int* cursor) {
+    if (cursor[0] < cursor[1]) cursor[0] += 1;
+}
 
 struct RecordArgs {
     const int* cursor;
@@ -52,7 +63,7 @@ struct RecordArgs {
 };
 __global__ __launch_bounds__(256) void k_record_step(RecordArgs a) {
     const long long row = (long long)a.cursor[0] - 1;
-    if (row < 0) return;
+    if (row < 0 || row >= a.cursor[1] || (a.cursor[2] & 1)) return;      // the logs hold cursor[1] rows; a step past the epoch logs nothing
     for (int i = threadIdx.x; i < a.B * a.n_out; i += 256) a.logits_log[row * a.B * a.n_out + i] = a.logits[i];
     for (int i = threadIdx.x; i < a.B * a.label_bytes; i += 256) a.labels_log[row * a.B * a.label_bytes + i] = a.labels[i];
     if (threadIdx.x == 0) a.loss_log[row] = a.loss[0];

@@ -537,9 +537,9 @@ __device__ __forceinline__ void embed_x0_row(const X0Args& a, int r, int n, int 
     const int L = a.L[r], c = L / 2, F = a.F;
     const float* f = a.feats[r] + ((size_t)n * L + c) * F;
     float acc = 0.f;
-    for (int i = 0; i < F; ++i) acc = fmaf(f[i], a.wlp[r][e * F + i], acc);
-    a.x0[r][(size_t)n * kD + e] = acc + a.pe[r][(size_t)c * kD + e];
-    if (e < 8) a.featc[r][(size_t)n * 8 + e] = e < F ? f[e] : 0.f;
+    for (int i = 0; i < F; ++i) acc = fmaf(ldg(f + i), ldg(a.wlp[r] + e * F + i), acc);
+    stg(a.x0[r] + (size_t)n * kD + e, acc + ldg(a.pe[r] + (size_t)c * kD + e));
+    if (e < 8) stg(a.featc[r] + (size_t)n * 8 + e, e < F ? ldg(f + e) : 0.f);
 }
 __global__ __launch_bounds__(128) void k_embed_x0(X0Args a) { embed_x0_row(a, blockIdx.y, blockIdx.x, threadIdx.x); }
 
@@ -557,13 +557,13 @@ struct QChainArgs {
     float* xcopy[kMaxRes];      // optional: the (row-mapped) input rows, materialised [N,128]
     int N;
 };
+// The chain kernels are written as BODIES over one 16-row tile (rows row0 .. row0 + 15 of resolution r, valid below N; LDS tiles
+// passed in) with thin __global__ wrappers: the fused centre-row kernels of cf_trunk.h run the same bodies back to back in one
+// workgroup per gene.
 template <int NWV>
-__global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
+__device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r, const int row0, float (*xs)[kD + 4], float (*qs)[kD + 4]) {
     constexpr int CW = kD / NWV, NTC = CW / 16;           // q columns per wave
     constexpr int EW = 256 / NWV, NTE = EW / 16;          // qt columns per wave (2 heads x 128)
-    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
-    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
-    const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
     TileReq<kD, NWV * 64> tx;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
     __syncthreads();
     if (a.xcopy[r])
         for (int i = threadIdx.x; i < kTile * kD; i += NWV * 64)
-            if (row0 + (i >> 7) < a.N) a.xcopy[r][(size_t)(row0 + (i >> 7)) * kD + (i & 127)] = xs[i >> 7][i & 127];
+            if (row0 + (i >> 7) < a.N) stg(a.xcopy[r] + (size_t)(row0 + (i >> 7)) * kD + (i & 127), xs[i >> 7][i & 127]);
     {
         f32x4 acc[NTC];
         zero_acc(acc);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 qs[row][col] = acc[t][i];
-                if (row0 + row < a.N) a.q[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+                if (row0 + row < a.N) stg(a.q[r] + (size_t)(row0 + row) * kD + col, acc[t][i]);
             }
     }
     __syncthreads();
@@ -608,6 +608,13 @@ __global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
     }
 }
 
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
+    qchain_fwd_body<NWV>(a, blockIdx.y, blockIdx.x * kTile, xs, qs);
+}
+
 struct QBwdArgs {
     const float* dqt[kMaxRes];   // [N,2,128]
     const float* dres[kMaxRes];  // [N,128] gradient arriving through the residual
@@ -618,11 +625,8 @@ struct QBwdArgs {
     int N;
 };
 template <int NWV>
-__global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
+__device__ __forceinline__ void qchain_bwd_body(const QBwdArgs& a, const int r, const int row0, float (*ds)[256 + 4], float (*qs)[kD + 4]) {
     constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / tiles per wave
-    __shared__ __attribute__((aligned(16))) float ds[kTile][256 + 4];
-    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
-    const int r = blockIdx.y, row0 = blockIdx.x * kTile;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int h = (w * CW) >> 6;
     TileReq<256, NWV * 64> td;
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 qs[row][col] = acc[t][i];
-                if (row0 + row < a.N) a.dq[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+                if (row0 + row < a.N) stg(a.dq[r] + (size_t)(row0 + row) * kD + col, acc[t][i]);
             }
     }
     __syncthreads();
@@ -666,6 +670,13 @@ __global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
             }
         }
     }
+}
+
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float ds[kTile][256 + 4];
+    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
+    qchain_bwd_body<NWV>(a, blockIdx.y, blockIdx.x * kTile, ds, qs);
 }
 
 // =======================================================================================
@@ -868,6 +879,43 @@ __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
     }
 }
 
+// (tiled weight copies: layout comment at k_retile below)
+struct RetileUnit {
+    long long off;     // float offset of the unit's first row in the flat parameter buffer
+    long long toff;    // float offset of the tensor
+    int K, N, n0, tr;  // row length, rows of the tensor, first row of the unit, emit the transposed tiling too
+};
+// tp: LDS patch of NWV x 16 x 20 floats (one 16 x 16 transpose per wave)
+template <int NWV>
+__device__ __forceinline__ void retile_unit_lds(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
+                                                const RetileUnit u, float (*tp)[16][20]) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const float* src = params + u.off + (size_t)r * u.K + q * 4;
+    float* dst = tiled + u.off + lane * 4;
+    const bool tr = u.tr && tiledT;
+    float* dstT = tiledT + u.toff + (size_t)(u.n0 / 16) * 256 + lane * 4;
+    for (int kt = w; kt < u.K / 16; kt += NWV) {
+        const float4 vv = ldg4(src + kt * 16);
+        stg4(dst + (size_t)kt * 256, vv);
+        if (tr) {      // 16 x 16 transpose through a wave-private LDS patch (LDS operations of a wave execute in order)
+            *reinterpret_cast<float4*>(&tp[w][r][q * 4]) = vv;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 o = make_float4(tp[w][q * 4][r], tp[w][q * 4 + 1][r], tp[w][q * 4 + 2][r], tp[w][q * 4 + 3][r]);
+            stg4(dstT + (size_t)kt * (u.N / 16) * 256, o);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+template <int NWV = 4>
+__device__ __forceinline__ void retile_unit(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
+                                            const RetileUnit u) {
+    __shared__ __attribute__((aligned(16))) float tp[NWV][16][20];
+    retile_unit_lds<NWV>(params, tiled, tiledT, u, tp);
+}
 // =======================================================================================
 // Post-attention chain on a 16-row tile:
 //   [a = xbar[h] Wv[h]^T]  ->  y1 = LN(x + a Wo^T + bo)  ->  h = relu(y1 W1^T + b1)
@@ -907,20 +955,28 @@ struct PostArgs {
     const float* nq_wk[kMaxRes] = {};   // next layer's Wk, row-major
     float* nq_q[kMaxRes] = {};          // [N,128]
     float* nq_qt[kMaxRes] = {};         // [N,2,128]
+    // optional: tiled-copy units riding in this launch (workgroups with blockIdx.y >= rt_y0; unit = (blockIdx.y - rt_y0) * gridDim.x
+    // + blockIdx.x).  The Embedding layer's chain kernel runs on a dozen workgroups: the Regulation + head weights, which nothing
+    // reads before the Regulation stack, are re-tiled on the idle CUs beside it instead of in front of the whole forward pass.
+    const RetileUnit* rt_units = nullptr;
+    const float* rt_params = nullptr;
+    float* rt_tiled = nullptr;
+    float* rt_tiledT = nullptr;
+    int rt_n = 0, rt_y0 = 1 << 30;
 };
 
 // NWV waves per workgroup (4 or 8): wave w owns 128 / NWV output columns of every product (DFF / NWV of the hidden layer), so with
 // eight waves two of them share a SIMD and one's operand waits hide behind the other's products; the LayerNorms run on waves 0..3.
+template <int DFF>
+struct PostFwdLds {      // LDS tiles of post_fwd_body
+    static constexpr int HW = (DFF > 256 ? DFF : 256);
+};
 template <bool VPROJ, int DM, int DFF, int NWV>
-__global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
-    constexpr int HW = (DFF > 256 ? DFF : 256);
+__device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, const int row0, const int N, float (*xs)[kD + 4],
+                                              float (*as_)[DM + 4], float (*ts)[kD + 4], float (*hs)[PostFwdLds<DFF>::HW + 4]) {
+    constexpr int HW = PostFwdLds<DFF>::HW;
     constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / column tiles per wave
     constexpr int CH = DFF / NWV, NT1 = CH / 16;          // hidden columns / tiles per wave
-    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
-    __shared__ __attribute__((aligned(16))) float as_[kTile][DM + 4];
-    __shared__ __attribute__((aligned(16))) float ts[kTile][kD + 4];
-    __shared__ __attribute__((aligned(16))) float hs[kTile][HW + 4];
-    const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     TileReq<kD, NWV * 64> tx;
     TileReq<256, NWV * 64> th;
@@ -949,7 +1005,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 as_[row][col] = acc[t][i];
-                if (a.save && row0 + row < N) a.a_out[r][(size_t)(row0 + row) * DM + col] = acc[t][i];
+                if (a.save && row0 + row < N) stg(a.a_out[r] + (size_t)(row0 + row) * DM + col, acc[t][i]);
             }
     } else {
         load_tile(&as_[0][0], DM + 4, a.ain[r], DM, DM, row0, N, identity_map());
@@ -964,7 +1020,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
-                ts[row][col] = acc[t][i] + a.bo[r][col] + xs[row][col];
+                ts[row][col] = acc[t][i] + ldg(a.bo[r] + col) + xs[row][col];
             }
     }
     FragNT<NT1, 8> f1;      // issued before the LayerNorm so the L2 latency hides behind it
@@ -982,9 +1038,9 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CH + col_nt(t, lr);
-                const float v = fmaxf(acc[t][i] + a.b1[r][col], 0.f);
+                const float v = fmaxf(acc[t][i] + ldg(a.b1[r] + col), 0.f);
                 hs[row][col] = v;
-                if (a.save && row0 + row < N) a.hdn[r][(size_t)(row0 + row) * DFF + col] = v;
+                if (a.save && row0 + row < N) stg(a.hdn[r] + (size_t)(row0 + row) * DFF + col, v);
             }
     }
     FragNT<NTC, DFF / 16> f2;
@@ -999,7 +1055,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
-                xs[row][col] = acc[t][i] + a.b2[r][col] + ts[row][col];
+                xs[row][col] = acc[t][i] + ldg(a.b2[r] + col) + ts[row][col];
             }
     }
     const bool lin = a.lin_w[r] != nullptr, nq = a.nq_wq[r] != nullptr;
@@ -1024,7 +1080,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                     ts[row][col] = acc[t][i];
-                    if (row0 + row < N) a.nq_q[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+                    if (row0 + row < N) stg(a.nq_q[r] + (size_t)(row0 + row) * kD + col, acc[t][i]);
                 }
         }
         __syncthreads();
@@ -1054,9 +1110,26 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
-                if (row0 + row < N) a.lin_y[r][(size_t)(row0 + row) * kD + col] = acc[t][i];
+                if (row0 + row < N) stg(a.lin_y[r] + (size_t)(row0 + row) * kD + col, acc[t][i]);
             }
     }
+}
+
+// RT: the instantiation that hosts tiled-copy units (PostArgs::rt_units) -- a template parameter, so that the other instantiations
+// keep their code (the extra path cost k_post_fwd<true, 128, 256, 8> 2.4 us per launch when it was a run-time branch in all of them)
+template <bool VPROJ, int DM, int DFF, int NWV, bool RT = false>
+__global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
+    constexpr int HW = PostFwdLds<DFF>::HW;
+    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float as_[kTile][DM + 4];
+    __shared__ __attribute__((aligned(16))) float ts[kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float hs[kTile][HW + 4];
+    if (RT && (int)blockIdx.y >= a.rt_y0) {      // a tiled-copy unit riding in this launch
+        const int u = ((int)blockIdx.y - a.rt_y0) * gridDim.x + blockIdx.x;
+        if (u < a.rt_n) retile_unit<NWV>(a.rt_params, a.rt_tiled, a.rt_tiledT, a.rt_units[u]);
+        return;
+    }
+    post_fwd_body<VPROJ, DM, DFF, NWV>(a, blockIdx.y, blockIdx.x * kTile, a.N, xs, as_, ts, hs);
 }
 
 // backward of the chain.  Per tile it also emits the column sums that make up the
@@ -1085,19 +1158,17 @@ struct PostBwdArgs {
 };
 __host__ __device__ constexpr int post_partial_width(int dff) { return 768 + dff; }
 
+// part_row: row of the partial buffer this tile's column sums go to (the tile index; the gene in the fused kernels)
 template <bool VPROJ, int DM, int DFF, int NWV>
-__global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
+__device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r, const int row0, const int N, const int part_row,
+                                              float (*ds)[kD + 4], float (*xh)[kD + 4], float (*t2)[kD + 4],
+                                              float (*wide)[(DFF > DM ? DFF : DM) + 4]) {
     constexpr int WW = (DFF > DM ? DFF : DM);
     constexpr int CW = kD / NWV, NTC = CW / 16;           // columns / tiles per wave of a 128-wide product
     constexpr int CH = DFF / NWV, NT2 = CH / 16;          // ... of the hidden layer
     constexpr int CO = DM / NWV, NTO = CO / 16;           // ... of the attention output
-    __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1 -> dt1
-    __shared__ __attribute__((aligned(16))) float xh[kTile][kD + 4];    // xhat2 -> xhat1
-    __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2
-    __shared__ __attribute__((aligned(16))) float wide[kTile][WW + 4];  // dpre1 -> da
-    const int r = blockIdx.y, row0 = blockIdx.x * kTile, N = a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    float* part = a.partial[r] + (size_t)blockIdx.x * post_partial_width(DFF);
+    float* part = a.partial[r] + (size_t)part_row * post_partial_width(DFF);
     // With eight waves the LayerNorm backwards run on waves 0..3 while waves 4..7 take the column sums of the same phase.
     constexpr bool SPLIT = NWV == 8;
     TileReq<kD, NWV * 64> td, tx, tx1;
@@ -1205,6 +1276,16 @@ __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
                 LdgN<NTE>::st(a.dxbar[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
         }
     }
+}
+
+template <bool VPROJ, int DM, int DFF, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
+    constexpr int WW = (DFF > DM ? DFF : DM);
+    __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1 -> dt1
+    __shared__ __attribute__((aligned(16))) float xh[kTile][kD + 4];    // xhat2 -> xhat1
+    __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2
+    __shared__ __attribute__((aligned(16))) float wide[kTile][WW + 4];  // dpre1 -> da
+    post_bwd_body<VPROJ, DM, DFF, NWV>(a, blockIdx.y, blockIdx.x * kTile, a.N, blockIdx.x, ds, xh, t2, wide);
 }
 
 // =======================================================================================
@@ -1664,7 +1745,25 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int batch) { wgrad_tile(tiles[blockIdx.x], batch); }
+// XCD-aware tile order.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with a private L2), and the tiles of one
+// weight-gradient job -- (n0, k0) blocks of the same dY^T X product, adjacent in the table -- share their operands: every X
+// column block is read by Nn / 64 tiles, every dY column block by Kk / 64.  With the table order as launch order a job's tiles
+// are spread over all eight L2s and each fetches its own copy (PMC: 2.6x the algorithmic bytes).  Workgroup b therefore takes
+// tile (b mod 8) * per + b / 8, per = ceil(n / 8): XCD x works through a contiguous eighth of the table, so a job's tiles meet
+// in one L2.  The launch has 8 * per workgroups; those past the table's end return.
+// MEASURED (round 3): slower -- k_reduce 38.4 -> 40.6 us per launch on a box whose other kernels ran 2.7 % faster: with a job's
+// tiles in one XCD all of them walk the same rows of the same arrays in lock step and queue on the same L2 channels, and the
+// re-reads the table order causes are served by the 256 MB Infinity Cache anyway (the arrays were written by the kernel in
+// front).  Off by default (`on` = 0: table order), CF_XCD_REDUCE=1 turns it on.
+__device__ __forceinline__ int xcd_tile(int b, int n, int on) {
+    const int per = (n + 7) >> 3;
+    return on ? (b & 7) * per + (b >> 3) : b;
+}
+__host__ __device__ inline int xcd_grid(int n) { return 8 * ((n + 7) >> 3); }
+__global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles, int n, int batch, int xcd) {
+    const int t = xcd_tile(blockIdx.x, n, xcd);
+    if (t < n) wgrad_tile(tiles[t], batch);
+}
 
 // Weight gradient of the 7-mark projections (lin_proj / lin_proj_pcre, [128, F]): too narrow
 // for an MFMA tile.  One workgroup sums a chunk of 8 genes into partial[chunk][128*F]; the
@@ -1734,9 +1833,14 @@ __global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles
 // Both reductions of a gradient bucket in ONE launch: workgroups [0, n_wg) take weight-gradient tiles, the rest column-sum
 // tiles (independent of each other; the bandwidth-bound column sums run beside the matrix products instead of behind them,
 // and one launch boundary goes)
-__global__ __launch_bounds__(256) void k_reduce(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int batch) {
-    if ((int)blockIdx.x < n_wg) wgrad_tile(wg[blockIdx.x], batch);
-    else colsum_tile(cs[blockIdx.x - n_wg], batch);
+__global__ __launch_bounds__(256) void k_reduce(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int batch, int xcd) {
+    const int nb = xcd_grid(n_wg);
+    if ((int)blockIdx.x < nb) {
+        const int t = xcd_tile(blockIdx.x, n_wg, xcd);
+        if (t < n_wg) wgrad_tile(wg[t], batch);
+    } else {
+        colsum_tile(cs[blockIdx.x - nb], batch);
+    }
 }
 
 // =======================================================================================
@@ -1805,41 +1909,12 @@ __global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const 
 }
 
 // =======================================================================================
-// Tiled copies of the Linear weights -- see FragNT.  One workgroup per 16-row unit of a tensor W[N][K]:
+// Tiled copies of the Linear weights -- see FragNT.  One workgroup per 16-row unit of a tensor W[N][K] (retile_unit, above):
 //   tiled:  block (n / 16, k / 16) at (n/16 * K/16 + k/16) * 256, element [q][r][m] = W[n0 + r][k0 + 4q + m]
 //           (B operand of the forward products  y = x W^T)
 //   tiledT: the same tiling of W^T[K][N]: block (k / 16, n / 16) at (k/16 * N/16 + n/16) * 256, element
 //           [q][r][m] = W[n0 + 4q + m][k0 + r]   (B operand of the backward products  dx = dy W; Regulation only)
 // =======================================================================================
-struct RetileUnit {
-    long long off;     // float offset of the unit's first row in the flat parameter buffer
-    long long toff;    // float offset of the tensor
-    int K, N, n0, tr;  // row length, rows of the tensor, first row of the unit, emit the transposed tiling too
-};
-__device__ __forceinline__ void retile_unit(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
-                                            const RetileUnit u) {
-    __shared__ __attribute__((aligned(16))) float tp[4][16][20];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const float* src = params + u.off + (size_t)r * u.K + q * 4;
-    float* dst = tiled + u.off + lane * 4;
-    const bool tr = u.tr && tiledT;
-    float* dstT = tiledT + u.toff + (size_t)(u.n0 / 16) * 256 + lane * 4;
-    for (int kt = w; kt < u.K / 16; kt += 4) {
-        const float4 vv = ldg4(src + kt * 16);
-        stg4(dst + (size_t)kt * 256, vv);
-        if (tr) {      // 16 x 16 transpose through a wave-private LDS patch (LDS operations of a wave execute in order)
-            *reinterpret_cast<float4*>(&tp[w][r][q * 4]) = vv;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float4 o = make_float4(tp[w][q * 4][r], tp[w][q * 4 + 1][r], tp[w][q * 4 + 2][r], tp[w][q * 4 + 3][r]);
-            stg4(dstT + (size_t)kt * (u.N / 16) * 256, o);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-}
 __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
                                                 const RetileUnit* __restrict__ units) {
     retile_unit(params, tiled, tiledT, units[blockIdx.x]);
@@ -1928,6 +2003,7 @@ __global__ __launch_bounds__(256) void k_dense_cs_tables(DenseCsTab a) {
 #include "cf_reg8.h"
 #include "cf_attc2.h"
 #include "cf_attc1.h"
+#include "cf_trunk.h"
 #include "cf_head.h"
 #include "cf_attn.h"
 #include "cf_bin.h"

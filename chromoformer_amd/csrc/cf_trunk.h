@@ -1,0 +1,303 @@
+// cf_trunk.h -- the centre-row trunk (Embedding layer + Pairwise stack) of ONE gene at one resolution in ONE workgroup
+// (included by cf_kernels.h behind the kernels whose bodies it runs).
+//
+// Every row of the centre-row stage belongs to one gene: the promoter's centre embedding (net.py:59), the query rows of its
+// i_max (promoter, pCRE) pairs through the Pairwise layers (modules.py:150-195, 205-206; net.py:105-139), and -- backwards --
+// the join of their gradients at the promoter embedding.  Nothing crosses genes before the weight-gradient reductions.  Round 2
+// ran the stage as 8 + 10 launches (query chain -> attention -> post chain per layer and direction, the join, the 7-mark
+// projection partials), each one wave of <= 192 workgroups that started with an HBM round trip for rows the launch in front
+// had just written.  Here workgroup (gene g, resolution r) walks the whole chain itself:
+//
+//   forward   x0 -> [q chain -> attention (1 region, vector ALUs) -> post chain + lin_proj_p]             Embedding layer
+//                -> [q chain] -> { attention (S regions, matrix cores) -> post chain (+ next layer's q chain) } x layers
+//   backward  { post chain -> attention -> q chain } x layers (last to first) -> join + lin_proj_p backward
+//                -> [post chain -> attention -> q chain] of the Embedding layer -> 7-mark projection partials of the gene
+//
+// The phases are the BODIES of the stand-alone kernels (cf_kernels.h, cf_attc1.h, cf_attc2.h), unchanged arithmetic in
+// unchanged order: activations of the forward pass are bit-identical to the unfused path.  Between two phases the rows travel
+// through global memory exactly as between two launches -- but written and read by the same workgroup, i.e. out of the CU's
+// own L1 / the XCD's L2 behind a workgroup barrier (workgroup-scope release / acquire: all waves of a workgroup share the L1)
+// instead of across a launch boundary -- and the S regions' features, masks and Wlp are staged in LDS ONCE for all Pairwise
+// layers of a direction (x_pcre is never updated, modules.py:218-219).
+#pragma once
+
+namespace cf {
+
+constexpr int kMaxPairLayers = 4;      // = kLpMaxSeg / 2
+
+// one centre-row layer of one resolution: operands, saved activations, gradient buffers (device pointers, fixed at cf_bind)
+struct CentreLayerDev {
+    const float *wq_t, *wk, *wv_t, *wo_t, *bo, *g1, *be1, *w1_t, *b1, *w2_t, *b2, *g2, *be2;      // forward (_t: tiled copies)
+    const float *wq, *wk_t, *wv, *wo, *w1, *w2;                                                     // backward
+    float *q, *qt, *p, *w, *xbar, *a, *xh1, *rs1, *y1, *hdn, *xh2, *rs2, *out, *xin;
+    float *dt2, *dpre1, *dt1, *da, *dxbar, *dqt, *du, *dq, *dx, *partial;
+};
+struct TrunkResDev {
+    CentreLayerDev E, P[kMaxPairLayers];
+    const float *pe, *pe2, *pet2;      // positional table [L][128]; padded layouts of the attention bodies (cf_attc2.h)
+    const float *wlp_e, *wlp_p;        // lin_proj / lin_proj_pcre  [128, F]
+    const float *lin_p_t, *lin_p;      // lin_proj_p [128, 128]: tiled copy (forward), row-major (backward)
+    float *ex0, *featc, *xp0, *dxp0, *edout, *rx0, *drx0;
+    float *lp_part_e, *lp_part_p;
+    int L, Lpad, LT, pad_;
+};
+struct TrunkArgs {
+    const TrunkResDev* tab;            // [n_res]
+    const float* pfeats[kMaxRes];
+    const uint8_t* pmask[kMaxRes];
+    long long pmstride[kMaxRes];
+    const float* cfeats[kMaxRes];
+    const uint8_t* cmask[kMaxRes];
+    long long cmstride[kMaxRes];
+    const float* dhin;                 // [B, n_res * 128]   (backward)
+    int B, S, T, F, n_res, pair_layers, save;
+    float scale, rscale;
+    // tiled-copy units riding in the forward launch (workgroups of the row blockIdx.y == n_res loop over them): the Regulation +
+    // head weights, which nothing reads before the Regulation stack
+    const RetileUnit* rt_units;
+    const float* rt_params;
+    float* rt_tiled;
+    float* rt_tiledT;
+    int rt_n;
+};
+
+// a table field through the constant address space: the pointer stays in SGPRs (cf_reg8.h, load_layer)
+template <class T>
+__device__ __forceinline__ T ldc(const T* p) {
+    static_assert(sizeof(T) == 8 || sizeof(T) == 4, "pointer or int fields");
+    if constexpr (sizeof(T) == 8) {
+        const unsigned long long v = *(const __attribute__((address_space(4))) unsigned long long*)p;
+        return __builtin_bit_cast(T, v);
+    } else {
+        const unsigned v = *(const __attribute__((address_space(4))) unsigned*)p;
+        return __builtin_bit_cast(T, v);
+    }
+}
+#define TF(field) ldc(&R->field)
+
+// LDS of the trunk kernels: [scratch | persistent attention part]; the chain bodies' tiles and the one-region attention (which
+// runs before / after everything that needs the persistent part) lie over it from the start.
+__host__ __device__ inline size_t trunk_scratch_floats(int L, int dff_max) {
+    const size_t chain = (size_t)3 * kTile * (kD + 4) + (size_t)kTile * ((dff_max > 256 ? dff_max : 256) + 4);      // post_fwd / post_bwd tiles
+    const size_t att = attc2_scratch_floats(L);
+    return (chain > att ? chain : att) + 4;
+}
+__host__ __device__ inline size_t trunk_smem(int L, int F, int S, int dff_max) {
+    const size_t two = trunk_scratch_floats(L, dff_max) * sizeof(float) + attc2_persist_bytes(L, F, kAGMax);
+    const size_t one = attc1_smem(L, F);
+    const size_t rt = (size_t)(kAT / 64) * 16 * 20 * sizeof(float);
+    (void)S;
+    return (two > one ? two : one) > rt ? (two > one ? two : one) : rt;
+}
+
+// Every phase is a NOINLINE device function: inlined into one kernel the eight bodies share one register allocation and the
+// compiler hoists the table loads of all phases to the top (measured: 1.8 KB of scratch per lane, 477 spilled VGPRs); as calls
+// each body keeps the allocation it has as a stand-alone kernel and the kernel's budget is the maximum over the phases.
+#define CF_PHASE __device__ __attribute__((noinline))
+
+struct TrunkCtx {      // what every phase needs, by value (uniform: lives in SGPRs)
+    const TrunkResDev* R;
+    const float* feats;        // the phase's feature array (promoter or pCRE) of resolution r
+    const uint8_t* mask;
+    long long mstride;
+    int g, S, T, F, save;
+    float scale, rscale;
+};
+__device__ __forceinline__ void trunk_attc_args(Attc2Args& at, const TrunkCtx& c, const float* wlp, const float* vin, float* p, float* w, float* vout,
+                                                int N) {
+    const TrunkResDev* R = c.R;
+    at.feats[0] = c.feats;
+    at.mask[0] = c.mask;
+    at.mstride[0] = c.mstride;
+    at.pe[0] = TF(pe2);
+    at.pet[0] = TF(pet2);
+    at.wlp[0] = wlp;
+    at.vin[0] = vin;
+    at.p[0] = p;
+    at.w[0] = w;
+    at.vout[0] = vout;
+    at.L[0] = TF(L);
+    at.Lpad[0] = TF(Lpad);
+    at.LT[0] = TF(LT);
+    at.N = N;
+    at.F = c.F;
+    at.scale = c.scale;
+    at.rscale = c.rscale;
+    at.tdbg = nullptr;
+    at.tall = nullptr;
+}
+// chain tiles over the scratch part of the LDS
+#define CF_CHAIN_TILES(scratch)                                                                       \
+    float (*xs)[kD + 4] = reinterpret_cast<float (*)[kD + 4]>(scratch);                               \
+    float (*as_)[kD + 4] = reinterpret_cast<float (*)[kD + 4]>((scratch) + kTile * (kD + 4));         \
+    float (*ts)[kD + 4] = reinterpret_cast<float (*)[kD + 4]>((scratch) + 2 * kTile * (kD + 4));      \
+    float* wide_raw = (scratch) + 3 * kTile * (kD + 4);                                               \
+    (void)xs, (void)as_, (void)ts, (void)wide_raw
+
+// ---- forward phases
+CF_PHASE void trunk_x0_qchain_e(TrunkCtx c, float* smem) {
+    const TrunkResDev* R = c.R;
+    const int g = c.g, tid = threadIdx.x;
+    CF_CHAIN_TILES(smem);
+    if (tid < kD) {
+        X0Args x;
+        x.feats[0] = c.feats;
+        x.pe[0] = TF(pe);
+        x.wlp[0] = TF(wlp_e);
+        x.x0[0] = TF(ex0);
+        x.featc[0] = TF(featc);
+        x.L[0] = TF(L);
+        x.F = c.F;
+        embed_x0_row(x, 0, g, tid);
+    }
+    __syncthreads();
+    QChainArgs q;
+    q.x[0] = TF(ex0);
+    q.xmap = identity_map();
+    q.wq[0] = TF(E.wq_t);
+    q.wk[0] = TF(E.wk);
+    q.q[0] = TF(E.q);
+    q.qt[0] = TF(E.qt);
+    q.xcopy[0] = nullptr;
+    q.N = g + 1;
+    qchain_fwd_body<kAT / 64>(q, 0, g, xs, as_);
+}
+template <bool BWD>
+CF_PHASE void trunk_attc1_e(TrunkCtx c, float* smem) {
+    const TrunkResDev* R = c.R;
+    Attc2Args at;
+    if (!BWD) trunk_attc_args(at, c, TF(wlp_e), TF(E.qt), TF(E.p), TF(E.w), TF(E.xbar), c.g + 1);
+    else trunk_attc_args(at, c, TF(wlp_e), TF(E.dxbar), TF(E.p), TF(E.du), TF(E.dqt), c.g + 1);
+    attc1_body<BWD>(at, 0, c.g, smem);
+}
+__device__ __forceinline__ void trunk_post_args(PostArgs& po, const CentreLayerDev* P, int save) {
+    po.ain[0] = ldc(&P->xbar);
+    po.wv[0] = ldc(&P->wv_t);
+    po.wo[0] = ldc(&P->wo_t);
+    po.bo[0] = ldc(&P->bo);
+    po.g1[0] = ldc(&P->g1);
+    po.be1[0] = ldc(&P->be1);
+    po.w1[0] = ldc(&P->w1_t);
+    po.b1[0] = ldc(&P->b1);
+    po.w2[0] = ldc(&P->w2_t);
+    po.b2[0] = ldc(&P->b2);
+    po.g2[0] = ldc(&P->g2);
+    po.be2[0] = ldc(&P->be2);
+    po.a_out[0] = ldc(&P->a);
+    po.xh1[0] = ldc(&P->xh1);
+    po.rs1[0] = ldc(&P->rs1);
+    po.y1[0] = ldc(&P->y1);
+    po.hdn[0] = ldc(&P->hdn);
+    po.xh2[0] = ldc(&P->xh2);
+    po.rs2[0] = ldc(&P->rs2);
+    po.save = save;
+    po.lin_w[0] = nullptr;
+    po.nq_wq[0] = nullptr;
+}
+template <int DFF>
+CF_PHASE void trunk_post_e(TrunkCtx c, float* smem) {
+    const TrunkResDev* R = c.R;
+    const int g = c.g;
+    CF_CHAIN_TILES(smem);
+    PostArgs po;
+    trunk_post_args(po, &R->E, c.save);
+    po.x[0] = TF(ex0);
+    po.xmap = identity_map();
+    po.out[0] = TF(rx0);
+    po.omap = RowMap{1, c.T, 0, 0};        // token 0 of the gene's Regulation input
+    po.N = g + 1;
+    po.lin_w[0] = TF(lin_p_t);             // lin_proj_p on the centre embedding (net.py:118)
+    po.lin_y[0] = TF(xp0);
+    post_fwd_body<true, 128, DFF, kAT / 64>(po, 0, g, g + 1, xs, as_, ts, reinterpret_cast<float (*)[PostFwdLds<DFF>::HW + 4]>(wide_raw));
+}
+CF_PHASE void trunk_qchain_p0(TrunkCtx c, float* smem) {
+    const TrunkResDev* R = c.R;
+    CF_CHAIN_TILES(smem);
+    const CentreLayerDev* P0 = &R->P[0];
+    QChainArgs q;
+    q.x[0] = TF(xp0);
+    q.xmap = RowMap{c.S, 1, 0, 0};         // the promoter row, once per pair (net.py:114-118)
+    q.wq[0] = ldc(&P0->wq_t);
+    q.wk[0] = ldc(&P0->wk);
+    q.q[0] = ldc(&P0->q);
+    q.qt[0] = ldc(&P0->qt);
+    q.xcopy[0] = ldc(&P0->xin);
+    q.N = c.g * c.S + c.S;
+    qchain_fwd_body<kAT / 64>(q, 0, c.g * c.S, xs, as_);
+}
+// attention of Pairwise layer l over the gene's S regions; STAGED: features, masks and Wlp are in the persistent LDS part already
+template <bool BWD, bool STAGED>
+CF_PHASE void trunk_attc2_p(TrunkCtx c, int l, float* scratch, float* persist) {
+    const TrunkResDev* R = c.R;
+    const CentreLayerDev* P = &R->P[l];
+    const int row0 = c.g * c.S, NB = row0 + c.S;
+    Attc2Args at;
+    if (!BWD) trunk_attc_args(at, c, TF(wlp_p), ldc(&P->qt), ldc(&P->p), ldc(&P->w), ldc(&P->xbar), NB);
+    else trunk_attc_args(at, c, TF(wlp_p), ldc(&P->dxbar), ldc(&P->p), ldc(&P->du), ldc(&P->dqt), NB);
+    attc2_body<BWD, kAGMax, STAGED>(at, 0, row0, NB, scratch, persist);
+}
+template <int DFF>
+CF_PHASE void trunk_post_p(TrunkCtx c, int l, int n_layers, float* smem) {
+    const TrunkResDev* R = c.R;
+    const CentreLayerDev* P = &R->P[l];
+    const bool last = l + 1 == n_layers;
+    const int S = c.S, row0 = c.g * S, NB = row0 + S;
+    CF_CHAIN_TILES(smem);
+    PostArgs po;
+    trunk_post_args(po, P, c.save);
+    po.x[0] = l == 0 ? (const float*)TF(xp0) : (const float*)ldc(&R->P[l > 0 ? l - 1 : 0].out);
+    po.xmap = l == 0 ? RowMap{S, 1, 0, 0} : identity_map();
+    po.out[0] = last ? TF(rx0) : ldc(&P->out);
+    po.omap = last ? RowMap{S, c.T, 1, 1} : identity_map();      // tokens 1 .. S of the gene's Regulation input
+    po.N = NB;
+    if (!last) {      // the next layer's query chain on the tile the chain still holds
+        const CentreLayerDev* Pn = &R->P[l + 1];
+        po.nq_wq[0] = ldc(&Pn->wq_t);
+        po.nq_wk[0] = ldc(&Pn->wk);
+        po.nq_q[0] = ldc(&Pn->q);
+        po.nq_qt[0] = ldc(&Pn->qt);
+    }
+    post_fwd_body<true, 128, DFF, kAT / 64>(po, 0, row0, NB, xs, as_, ts, reinterpret_cast<float (*)[PostFwdLds<DFF>::HW + 4]>(wide_raw));
+}
+
+template <int DFF_E, int DFF_P>
+__global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NWV = kAT / 64;
+    if ((int)blockIdx.y >= a.n_res) {      // tiled-copy units on the CUs the trunk leaves idle
+        float (*tp)[16][20] = reinterpret_cast<float (*)[16][20]>(smem);
+        for (int u = blockIdx.x; u < a.rt_n; u += gridDim.x) {
+            retile_unit_lds<NWV>(a.rt_params, a.rt_tiled, a.rt_tiledT, a.rt_units[u], tp);
+            __syncthreads();
+        }
+        return;
+    }
+    // resolutions in reverse launch order: the long-sequence workgroups (last binsize) are dispatched first
+    const int r = a.n_res - 1 - (int)blockIdx.y;
+    const TrunkResDev* R = a.tab + r;
+    constexpr int DFF_MAX = DFF_E > DFF_P ? DFF_E : DFF_P;
+    float* persist = smem + trunk_scratch_floats(TF(L), DFF_MAX);
+    TrunkCtx c{R, a.pfeats[r], a.pmask[r], a.pmstride[r], (int)blockIdx.x, a.S, a.T, a.F, a.save, a.scale, a.rscale};
+    // ---------------------------------------------------------------- Embedding layer: one row (the promoter's centre bin)
+    trunk_x0_qchain_e(c, smem);
+    __syncthreads();
+    trunk_attc1_e<false>(c, smem);
+    __syncthreads();
+    trunk_post_e<DFF_E>(c, smem);
+    __syncthreads();
+    // ---------------------------------------------------------------- Pairwise stack: S rows (the gene's pairs)
+    c.feats = a.cfeats[r];
+    c.mask = a.cmask[r];
+    c.mstride = a.cmstride[r];
+    trunk_qchain_p0(c, smem);
+    __syncthreads();
+    for (int l = 0; l < a.pair_layers; ++l) {
+        if (l == 0) trunk_attc2_p<false, false>(c, l, smem, persist);
+        else trunk_attc2_p<false, true>(c, l, smem, persist);
+        __syncthreads();
+        trunk_post_p<DFF_P>(c, l, a.pair_layers, smem);
+        __syncthreads();
+    }
+}
+
+}  // namespace cf

@@ -27,6 +27,10 @@ def _pmc_traffic(kernel):
         return None
 
 
+_TRAFFIC_SOURCE = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command "
+                   "(committed constant, not measured in this run)")
+
+
 class Slot:
     """One batch resident in HBM at fixed addresses (what a captured graph reads)."""
 
@@ -103,7 +107,9 @@ class EpochFeed:
         self.cap = max_batches or (len(store) // bsz + 1)
         self.order = torch.zeros(self.cap * bsz, dtype=torch.int32, device=dev)
         self._order_host = torch.zeros(self.cap * bsz, dtype=torch.int32).pin_memory()
-        self.cursor = torch.zeros(2, dtype=torch.int32, device=dev)          # [next batch, arrival counter of the gather launch]
+        self.cursor = torch.zeros(4, dtype=torch.int32, device=dev)          # [next batch, batches uploaded, error flags, reserved]
+        self._cursor_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.taken = 0                                                        # steps issued since begin_epoch (host-side guard)
         # the step logs live in pinned HOST memory (device-addressable): cf_record_step writes a KB per step straight into
         # it, the loop reads it once an event says the window is complete -- no device-to-host copy, which would queue
         # behind the replayed graphs (1.6 ms per copy on a busy GPU)
@@ -126,11 +132,30 @@ class EpochFeed:
         n = len(batches) * self.B
         if n:
             self._order_host[:n] = torch.from_numpy(np.asarray(batches, dtype=np.int32).reshape(-1))
+        flags = self.check(stream)                         # of the epoch that just ended (waits for its last steps on `stream`)
+        self._cursor_host[0], self._cursor_host[1], self._cursor_host[2] = 0, len(batches), 0
         with torch.cuda.stream(stream):
             if n:
                 self.order[:n].copy_(self._order_host[:n], non_blocking=True)
-            self.cursor.zero_()
-        self.n_batches = len(batches)
+            self.cursor.copy_(self._cursor_host, non_blocking=True)
+        self.n_batches, self.taken = len(batches), 0
+        if flags:
+            raise RuntimeError("EpochFeed: the previous epoch set error flags %d on the device (1: a step past the epoch, "
+                               "2: a gene index outside the store)" % flags)
+
+    def check(self, stream=None):
+        """Error flags the gather kernel has set (cursor[2]); read behind the work queued on `stream` (the trainer's: it does
+        not synchronise with the current stream), which it waits for."""
+        if stream is None:
+            torch.cuda.synchronize(self.cursor.device)
+            return int(self.cursor[2].item())
+        with torch.cuda.stream(stream):
+            return int(self.cursor[2].item())
+
+    def rewind(self):
+        """Back to the first batch of the uploaded epoch (the eager validation pass before a capture consumed one)."""
+        self.cursor[0] = 0                                 # (on the current stream: the caller synchronises before capturing)
+        self.taken = 0
 
     def window(self, lo, hi):
         """(logits [n, n_out], labels [n], losses [hi - lo]) of steps lo .. hi - 1 of the epoch, on the host (the caller has
@@ -272,13 +297,19 @@ class Trainer:
     def _step(self, slot):
         m, L = self.model, self._L
         st = self._stream()
+        feed = getattr(slot, "feed", None)
+        if feed is not None:
+            if feed.taken >= feed.n_batches:           # the device-side bound would skip the gather; refuse on the host, loudly
+                raise RuntimeError("Trainer.step: the feed's epoch of %d batches is exhausted (call begin_epoch)" % feed.n_batches)
         if self.use_graph and slot.graph is None:
             self._seq_all(slot, st, opt=False)         # eager once (validates the arguments before anything is captured)
             if getattr(slot, "feed", None) is not None:
-                slot.feed.cursor.zero_()               # the validation pass consumed a batch: rewind (no parameter was updated)
+                slot.feed.rewind()                     # the validation pass consumed a batch: rewind (no parameter was updated)
             torch.cuda.synchronize()
             first = self._seq_early if self.dp else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph))
             slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
+        if feed is not None:
+            feed.taken += 1
         oig = self.opt_in_graph
         if oig:      # this step's AdamW scalars go to device memory before anything is replayed
             m._step += 1
@@ -342,6 +373,36 @@ class Trainer:
             _lib.check(self._L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 0, self._stream()), "cf_forward")
         return slot.logits
 
+    def evaluate_store(self, store, bsz):
+        """Forward-only pass over ALL genes of a device-resident store in store order (validation, train.py:236-275; prediction,
+        demo/run_demo.py:98-114) -> logits [len(store), n_out] on the device.  Per batch: one cf_gather_batch out of the
+        resident arrays (the same launch the training graph starts with) and cf_forward writing its logits straight into the
+        result -- instead of ~17 ATen index / copy launches per batch; the tail batch is kept (train.py:140)."""
+        m, L = self.model, self._L
+        n = len(store)
+        out = torch.empty(n, m.n_out, device=m._device)
+        if n == 0:
+            return out
+        struct = store.struct()                                   # raises for a host-side store
+        cache = self.__dict__.setdefault("_eval_slots", {})
+        with torch.cuda.stream(self.stream):
+            order = torch.arange(n, dtype=torch.int32, device=m._device)
+            n_full = n // bsz
+            for B, lo, nb in ((bsz, 0, n_full), (n - n_full * bsz, n_full * bsz, 1)):
+                if B == 0 or nb == 0:
+                    continue
+                slot = cache.get(B)
+                if slot is None:
+                    slot = cache[B] = Slot(m, B)
+                cursor = torch.tensor([0, nb, 0, 0], dtype=torch.int32).to(m._device)
+                st = self._stream()
+                for k in range(nb):
+                    _lib.check(L.cf_gather_batch(m._handle, C.byref(struct), order[lo:].data_ptr(), cursor.data_ptr(), C.byref(slot.struct),
+                                                 slot.label.data_ptr(), st), "cf_gather_batch")
+                    _lib.check(L.cf_forward(m._handle, C.byref(slot.struct), out[lo + k * B:].data_ptr(), 0, st), "cf_forward")
+            self.stream.synchronize()                             # `order` / `cursor` may be released; the result is complete
+        return out
+
     def scheduler_step(self):
         """StepLR(step_size=1, gamma) (train.py:158, 344)."""
         self.lr *= self.gamma
@@ -374,12 +435,13 @@ class Trainer:
             flops = self._L.cf_kernel_flops(self.model._handle, kernel.encode(), B)
             ach = flops / avg_s / 1e12
             return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": round(ach / 157.3, 4), "traffic": _pmc_traffic(kernel), "avg_launch_us": round(avg_s * 1e6, 2),
-                    "algorithmic_gflop_per_launch": round(flops / 1e9, 4)}
+                    "frac": round(ach / 157.3, 4), "traffic": _pmc_traffic(kernel), "traffic_source": _TRAFFIC_SOURCE,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_gflop_per_launch": round(flops / 1e9, 4)}
         if kernel == "k_adamw":
             nbytes = 7.0 * 4.0 * self.model._layout.n_active
             ach = nbytes / avg_s / 1e9
             return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 4), "traffic": _pmc_traffic(kernel), "avg_launch_us": round(avg_s * 1e6, 2),
+                    "frac": round(ach / 8000.0, 4), "traffic": _pmc_traffic(kernel), "traffic_source": _TRAFFIC_SOURCE,
+                    "avg_launch_us": round(avg_s * 1e6, 2),
                     "algorithmic_mb_per_launch": round(nbytes / 1e6, 3)}
         return {"kernel": kernel, "avg_launch_us": round(avg_s * 1e6, 2)}

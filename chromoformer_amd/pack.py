@@ -38,13 +38,46 @@ def signature(binsizes, i_max, w_prom, w_max, n_feats):
     return {"binsizes": [int(b) for b in binsizes], "i_max": int(i_max), "w_prom": int(w_prom), "w_max": int(w_max), "n_feats": int(n_feats)}
 
 
-def pack(meta, npy_dir, out, binsizes=(2000, 500, 100), i_max=8, w_prom=40000, w_max=40000, n_feats=7, device=None, progress=False):
-    """Bin every gene of `meta` (file order) and write the packed store to `out`.  -> number of genes."""
+def gene_digests(table, npy_dir, genes=None):
+    """{gene_id: digest} over everything of a metadata row that ends up in the store -- label, expression, TSS window, strand,
+    partner regions and their scores -- and the byte sizes of the region files it names (a re-extracted signal file of another
+    length changes it; contents are not re-read: that is what the store exists to avoid).  `table`: DataFrame of the metadata."""
+    import hashlib
+    want = None if genes is None else set(genes)
+    out = {}
+    cols = [c for c in ("label", "expression", "chrom", "start", "end", "strand", "neighbors", "scores") if c in table.columns]
+
+    def size(name):
+        try:
+            return os.path.getsize(os.path.join(npy_dir, name + ".npy"))
+        except OSError:
+            return -1
+
+    for r in table.to_dict("records"):
+        g = r["gene_id"]
+        if want is not None and g not in want:
+            continue
+        parts = []
+        for c in cols:
+            v = r[c]
+            parts.append("" if isinstance(v, float) and np.isnan(v) else (repr(float(v)) if isinstance(v, (float, np.floating)) else str(v)))
+        files = ["%s:%d-%d" % (r["chrom"], int(r["start"]) - 20000, int(r["start"]) + 20000)]
+        if isinstance(r.get("neighbors"), str) and r["neighbors"]:
+            files += r["neighbors"].split(";")
+        parts += ["%s=%d" % (f, size(f)) for f in files]
+        out[g] = hashlib.sha1("|".join(parts).encode()).hexdigest()[:20]
+    return out
+
+
+def pack(meta, npy_dir, out, binsizes=(2000, 500, 100), i_max=8, w_prom=40000, w_max=40000, n_feats=7, device="auto", progress=False):
+    """Bin every gene of `meta` (file order) and write the packed store to `out`.  -> number of genes.
+    device: "auto" = the current GPU when one is visible, None = bin on the host, or a torch.device."""
     table = pd.read_csv(meta)
     genes = table.gene_id.tolist()
-    ds = ChromoformerDataset(meta, npy_dir, genes, n_feats, i_max, list(binsizes), w_prom, w_max, regression=False)
-    if device is None and torch.cuda.is_available():
-        device = torch.device("cuda", torch.cuda.current_device())
+    # metadata with only an `expression` column (a regression-only cell line) packs too: the class labels are then zeros
+    ds = ChromoformerDataset(meta, npy_dir, genes, n_feats, i_max, list(binsizes), w_prom, w_max, regression="label" not in table.columns)
+    if isinstance(device, str) and device == "auto":
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
     store = GeneStore(ds, pin=False, progress=progress, device=device, resident=False) if device is not None else GeneStore(ds, pin=False, progress=progress)
     arrays = {}
     for r in range(len(store.binsizes)):
@@ -57,14 +90,17 @@ def pack(meta, npy_dir, out, binsizes=(2000, 500, 100), i_max=8, w_prom=40000, w
         arrays["label_reg"] = torch.full((len(genes),), float("nan"))
     if "label" not in table.columns:
         arrays["label_cls"] = torch.zeros(len(genes), dtype=torch.int64)
-    write(out, genes, signature(binsizes, i_max, w_prom, w_max, n_feats), arrays)
+    write(out, genes, signature(binsizes, i_max, w_prom, w_max, n_feats), arrays, gene_digests(table, npy_dir))
     return len(genes)
 
 
-def write(out, genes, sig, arrays):
-    """Write a packed store from already-binned arrays (torch tensors, any device)."""
+def write(out, genes, sig, arrays, digests=None):
+    """Write a packed store from already-binned arrays (torch tensors, any device).  `digests`: gene_digests() of the
+    metadata the arrays were made from (a store without them is never picked up automatically)."""
     np_arrays = {k: v.detach().cpu().contiguous().numpy() for k, v in arrays.items()}
     header = {"version": 1, "n_genes": len(genes), "genes": list(genes), "signature": sig, "arrays": {}}
+    if digests is not None:
+        header["gene_sha"] = [digests[g] for g in genes]
     off = 0
     for k, a in np_arrays.items():                        # offsets are relative to the first page boundary behind the header
         header["arrays"][k] = [str(a.dtype), list(a.shape), off]
@@ -96,6 +132,7 @@ class PackedStore:
             self.header = json.loads(f.read(n).decode())
         self.genes = self.header["genes"]
         self.signature = self.header["signature"]
+        self.gene_sha = dict(zip(self.genes, self.header["gene_sha"])) if "gene_sha" in self.header else None
         self._row = {g: i for i, g in enumerate(self.genes)}
         base = (16 + n + _ALIGN - 1) // _ALIGN * _ALIGN
         self.arrays = {k: (np.memmap(path, dtype=np.dtype(dt), mode="r", offset=base + off, shape=tuple(shape)) if int(np.prod(shape)) else
@@ -104,6 +141,14 @@ class PackedStore:
 
     def matches(self, binsizes, i_max, w_prom, w_max, n_feats):
         return self.signature == signature(binsizes, i_max, w_prom, w_max, n_feats)
+
+    def stale(self, table, npy_dir, genes):
+        """Genes (of `genes`) whose metadata row or signal-file sizes differ from what the store was packed from; all of
+        them when the store carries no digests."""
+        if self.gene_sha is None:
+            return list(genes)
+        now = gene_digests(table, npy_dir, genes)
+        return [g for g in genes if self.gene_sha.get(g) != now.get(g)]
 
     def rows(self, genes):
         try:
@@ -143,9 +188,12 @@ class PackedStore:
         return st
 
 
-def find(npy_dir, explicit, binsizes, i_max, w_prom, w_max, n_feats, genes=None):
+def find(npy_dir, explicit, binsizes, i_max, w_prom, w_max, n_feats, genes=None, meta=None):
     """The packed store a run should use: `explicit` if given (must match, else an error), else `<npy_dir>/chromoformer.cfstore`
-    when it exists, matches the binning configuration and holds all `genes`; None otherwise."""
+    when it exists, matches the binning configuration, holds all `genes` AND was packed from the metadata rows and signal
+    files the run sees now (`meta`: the run's metadata file or DataFrame; labels, expression, partner sets, scores and TSS
+    windows are frozen at pack time, so a store that no longer agrees with them is stale: an automatic pick-up skips it with
+    a warning, an explicit --store is an error); None otherwise."""
     path = explicit or os.path.join(npy_dir, DEFAULT_NAME)
     if not os.path.exists(path):
         if explicit:
@@ -157,6 +205,17 @@ def find(npy_dir, explicit, binsizes, i_max, w_prom, w_max, n_feats, genes=None)
         if explicit:
             raise ValueError("%s was packed for %s, the run needs %s" % (path, ps.signature, signature(binsizes, i_max, w_prom, w_max, n_feats)))
         return None
+    if meta is not None:
+        table = pd.read_csv(meta) if isinstance(meta, (str, os.PathLike)) else meta
+        stale = ps.stale(table, npy_dir, genes if genes is not None else table.gene_id.tolist())
+        if stale:
+            why = ("%s carries no content digests (packed by an older version)" % path if ps.gene_sha is None else
+                   "%s is stale: the metadata rows / signal files of %d genes (first: %s) changed since it was packed" % (path, len(stale), stale[0]))
+            if explicit:
+                raise ValueError(why + "; re-run `python -m chromoformer_amd.pack`")
+            import warnings
+            warnings.warn(why + "; ignoring it and binning the raw .npy files (re-run `python -m chromoformer_amd.pack`)")
+            return None
     return ps
 
 
@@ -173,7 +232,7 @@ def main(argv=None):
     ap.add_argument("--host", action="store_true", help="bin on the host even if a GPU is visible")
     args = ap.parse_args(argv)
     out = args.output or os.path.join(args.npy_dir, DEFAULT_NAME)
-    dev = None if args.host or not torch.cuda.is_available() else torch.device("cuda", 0)
+    dev = None if args.host else "auto"
     n = pack(args.meta, args.npy_dir, out, args.binsizes, args.i_max, args.w_prom, args.w_max, args.n_feats, device=dev, progress=True)
     print("packed %d genes -> %s (%.1f MB)" % (n, out, os.path.getsize(out) / 1e6))
     return 0

@@ -53,12 +53,13 @@ def predict(meta_path, npy_dir, weights=None, regression=False, bsz=32, seed=123
     meta = pd.read_csv(meta_path)
     genes = meta.gene_id.tolist()
     from . import pack
-    packed = pack.find(npy_dir, store_path, list(binsizes), i_max, w_prom, w_max, 7, genes)
+    packed = pack.find(npy_dir, store_path, list(binsizes), i_max, w_prom, w_max, 7, genes, meta=meta)
+    dev = torch.device("cuda", torch.cuda.current_device())
     if packed is not None:
-        store = packed.store(genes, regression=False)          # labels are not used for prediction
+        store = packed.store(genes, device=dev, regression=False)          # labels are not used for prediction
     else:
         ds = ChromoformerDataset(meta_path, npy_dir, genes, 7, i_max, list(binsizes), w_prom, w_max, regression=regression)
-        store = GeneStore(ds, progress=progress)
+        store = GeneStore(ds, progress=progress, device=dev, resident=True)      # binned on the GPU, resident (126 KB per gene)
     Model = ChromoformerRegressor if regression else ChromoformerClassifier
     model = Model(7, 128, 128, dict(n_layers=1, n_heads=2, d_model=128, d_ff=128), dict(n_layers=2, n_heads=2, d_model=128, d_ff=256),
                   dict(n_layers=6, n_heads=8, d_model=256, d_ff=256), binsizes=list(binsizes), seed=seed, i_max=i_max, w_max=w_max,
@@ -68,19 +69,8 @@ def predict(meta_path, npy_dir, weights=None, regression=False, bsz=32, seed=123
         model.load_state_dict(modernise_keys(ckpt["net"] if "net" in ckpt else ckpt))
     model.cuda()
     trainer = Trainer(model, use_graph=False)
-    slots = {}
-    preds = []
-    for s in range(0, len(store), bsz):
-        idx = list(range(s, min(s + bsz, len(store))))
-        slot = slots.get(len(idx))
-        if slot is None:
-            slot = slots[len(idx)] = Slot(model, len(idx))
-        trainer.stage(store.batch(idx), slot)
-        with torch.cuda.stream(trainer.stream):
-            out = trainer.evaluate(slot).clone()
-        trainer.stream.synchronize()
-        out = out.cpu()
-        preds.append(out.numpy().reshape(-1) if regression else torch.sigmoid(out).numpy()[:, 1])
+    out = trainer.evaluate_store(store, bsz).cpu()          # device gather + forward per batch, logits in store order
+    preds = [out.numpy().reshape(-1) if regression else torch.sigmoid(out).numpy()[:, 1]]
     return meta, np.concatenate(preds).astype(np.float32)
 
 

@@ -31,7 +31,7 @@ import torch.nn as nn
 import yaml
 
 from .data import ChromoformerDataset, GeneStore, shard_indices, static_epoch_batches, static_shard
-from .engine import EpochFeed, Slot, Trainer
+from .engine import EpochFeed, Trainer
 from .net import ChromoformerClassifier, ChromoformerRegressor
 from .util import seed_everything
 
@@ -156,7 +156,7 @@ def main(argv=None):
     say(len(train_genes), len(val_genes))
 
     from . import pack
-    packed = pack.find(args.npy_dir, args.store, args.binsizes, i_max, w_prom, w_max, n_feats, train_genes + val_genes)
+    packed = pack.find(args.npy_dir, args.store, args.binsizes, i_max, w_prom, w_max, n_feats, train_genes + val_genes, meta=meta)
     say("packed store:", packed.path if packed is not None else "none (binning the raw .npy files)")
 
     def store_of(genes):
@@ -330,17 +330,7 @@ def _validate(model, trainer, store, n_total, bsz, world):
     consecutive genes per rank; the tail batch is kept, train.py:140); returns the CPU logits [n_total, n_out] of ALL
     validation genes in dataset order on every rank."""
     per = (n_total + world - 1) // world
-    outs = []
-    slot_cache = {}
-    for s in range(0, len(store), bsz):
-        idx = list(range(s, min(len(store), s + bsz)))
-        slot = slot_cache.get(len(idx)) or Slot(model, len(idx))
-        slot_cache[len(idx)] = slot
-        with torch.cuda.stream(trainer.stream):
-            slot.fill(model, store.batch(idx))
-            outs.append(trainer.evaluate(slot).clone())
-    torch.cuda.synchronize()
-    mine = torch.cat(outs) if outs else torch.zeros(0, model.n_out, device=model._device)
+    mine = trainer.evaluate_store(store, bsz)         # one cf_gather_batch + cf_forward per batch, from the resident slice
     if world > 1:
         pad = torch.zeros(per, model.n_out, device=model._device)
         pad[: mine.shape[0]] = mine

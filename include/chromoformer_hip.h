@@ -202,7 +202,9 @@ double cf_kernel_flops(cf_handle* h, const char* kernel, int B);
 int cf_debug_copy(cf_handle* h, const char* name, float* dst, long long* n_floats, void* stream);
 /* Names of all workspace buffers, '\n' separated (host string owned by the handle). */
 const char* cf_debug_names(cf_handle* h);
-/* Number of kernels one forward / backward / optimiser call launches. */
+/* Number of kernels the LAST forward / backward (chain pieces + bucket reductions) / optimiser step launched, counted at the
+ * launch sites (zero before the first call; calls replayed from a graph do not pass the host code and leave the counts
+ * of the capture pass). */
 int cf_launch_counts(cf_handle* h, int* fwd, int* bwd, int* opt);
 
 /* ---- standalone operators (same kernels, for unit tests and micro-benchmarks) ------ */
@@ -283,13 +285,16 @@ typedef struct cf_store {
 /* The DataLoader and the per-tensor .cuda() copies of a step (train.py:137-140, 171-177) as ONE capturable launch:
  * copies genes order[cursor[0] * B ... + B) of `store` into the batch buffers `dst` (which must use compact mask
  * rows, stride L, and are written despite the const in cf_batch) and their labels into labels_dst, then advances
- * cursor[0] (a second, one-thread launch).  `order` (int32, batch-major) and `cursor` (int32[2], second word
- * reserved; zero it whenever a new order is uploaded) are device memory: a replayed graph walks the epoch without
- * any host involvement. */
+ * cursor[0] (a second, one-thread launch).  `order` (int32, batch-major) and `cursor` (int32[4]) are device memory: a
+ * replayed graph walks the epoch without any host involvement.  cursor[0] = next batch (zero it whenever a new order is
+ * uploaded), cursor[1] = number of batches in `order` (the bound: a call with cursor[0] >= cursor[1] copies nothing, does
+ * not advance and sets bit 0 of cursor[2]; a gene index outside [0, store->n_genes) is skipped and sets bit 1),
+ * cursor[2] = error flags (sticky until the caller clears them), cursor[3] reserved. */
 int cf_gather_batch(cf_handle* h, const cf_store* store, const int* order, int* cursor, const cf_batch* dst,
                     void* labels_dst, void* stream);
 /* Appends the step's logits [B, n_out], labels [B] and loss to per-epoch device logs at row cursor[0] - 1 (capturable;
- * what the loop's running metrics, train.py:198-232, read every tenth step instead of cloning tensors every step). */
+ * what the loop's running metrics, train.py:198-232, read every tenth step instead of cloning tensors every step).
+ * The logs must hold cursor[1] rows; nothing is written for a step past the epoch (cursor[2] bit 0). */
 int cf_record_step(cf_handle* h, const int* cursor, const float* logits, const void* labels, const float* loss, int B,
                    float* logits_log, void* labels_log, float* loss_log, void* stream);
 

@@ -30,13 +30,62 @@ def test_gather_walks_the_epoch_order_bit_exactly():
             _lib.check(L.cf_gather_batch(model._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
                                          C.byref(slot.struct), slot.label.data_ptr(), trainer.stream.cuda_stream), "cf_gather_batch")
         trainer.stream.synchronize()
-        assert feed.cursor.tolist() == [k + 1, 0]
+        assert feed.cursor.tolist() == [k + 1, 5, 0, 0]
         ii = torch.tensor(idx, device=store.freq.device)
         for r in range(3):
             assert torch.equal(slot.pf[r], store.pf[r][ii]) and torch.equal(slot.cf[r], store.cf[r][ii])
             assert torch.equal(slot.pm[r], store.pm[r][ii]) and torch.equal(slot.cm[r], store.cm[r][ii])
             assert torch.equal(slot.im[r], store.im[ii])
         assert torch.equal(slot.freq, store.freq[ii]) and torch.equal(slot.label, store.label[ii])
+
+
+def test_a_step_past_the_epoch_or_a_bad_gene_index_touches_nothing():
+    """The gather and the step log are bounded on the device (cursor[1] batches, store.n_genes genes) and on the host
+    (Trainer.step refuses an exhausted feed): one call too many neither reads the order / the store out of bounds nor writes
+    past the pinned host logs."""
+    import ctypes as C
+    from chromoformer_amd import _lib
+    model, store, trainer, feed = _setup(n_genes=40)
+    batches = [list(range(8)), list(range(8, 16))]
+    feed.begin_epoch(batches, trainer.stream)
+    L, slot, st = _lib.lib(), feed.slot, trainer.stream.cuda_stream
+
+    def gather():
+        with torch.cuda.stream(trainer.stream):
+            _lib.check(L.cf_gather_batch(model._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
+                                         C.byref(slot.struct), slot.label.data_ptr(), st), "cf_gather_batch")
+        trainer.stream.synchronize()
+
+    gather()
+    gather()
+    assert feed.cursor.tolist() == [2, 2, 0, 0]
+    before = [t.clone() for t in slot.cf] + [slot.freq.clone(), slot.label.clone()]
+    log_before = feed.logits_log.clone()
+    gather()                                                    # a third batch that does not exist
+    with torch.cuda.stream(trainer.stream):
+        _lib.check(L.cf_record_step(model._handle, feed.cursor.data_ptr(), slot.logits.data_ptr(), slot.label.data_ptr(), slot.loss.data_ptr(),
+                                    slot.B, feed.logits_log.data_ptr(), feed.labels_log.data_ptr(), feed.loss_log.data_ptr(), st), "cf_record_step")
+    trainer.stream.synchronize()
+    assert feed.cursor.tolist() == [2, 2, 1, 0] and feed.check() == 1
+    assert all(torch.equal(a, b) for a, b in zip(before, [t for t in slot.cf] + [slot.freq, slot.label]))
+    assert torch.equal(feed.logits_log, log_before)
+    with pytest.raises(RuntimeError, match="error flags 1"):
+        feed.begin_epoch(batches, trainer.stream)
+    # a gene index outside the store: skipped and flagged
+    feed.begin_epoch([[0, 1, 2, 3, 4, 5, 6, 40]], trainer.stream)
+    gather()
+    assert feed.check() == 2
+    ii = torch.arange(7, device=store.freq.device)
+    assert torch.equal(slot.freq[:7], store.freq[ii])
+    feed.cursor[2] = 0
+    # host-side guard of the training loop
+    feed.begin_epoch(batches, trainer.stream)
+    trainer.step(slot)
+    trainer.step(slot)
+    with pytest.raises(RuntimeError, match="exhausted"):
+        trainer.step(slot)
+    torch.cuda.synchronize()
+    assert feed.check() == 0
 
 
 def test_feed_steps_equal_staged_steps_and_log_every_step():

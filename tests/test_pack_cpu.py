@@ -65,3 +65,56 @@ def test_packed_items_equal_the_reference_items_of_golden_g5(tmp_path):
             assert np.array_equal(store.cm[r][slot].numpy().astype(bool), z["%s.pcre_pad_masks.%d" % (tag, b)][:, 0, L // 2])
             assert np.array_equal(store.pm[r][slot].numpy().astype(bool), z["%s.promoter_pad_masks.%d" % (tag, b)][0, 0, L // 2])
         assert int(store.label[slot]) == int(z["%s.label" % tag])
+
+
+def test_a_store_that_no_longer_agrees_with_the_metadata_is_not_used(tmp_path):
+    """Labels, expression, partner sets and TSS windows are frozen at pack time: find() compares per-gene digests of the run's
+    metadata rows (+ signal-file sizes) with the ones in the header, skips a stale store with a warning when it was picked up
+    by default name and refuses it when it was named explicitly."""
+    d = str(tmp_path / "npy")
+    meta = make_dataset(d, n_genes=12, seed=4)
+    out = os.path.join(d, pack.DEFAULT_NAME)
+    pack.pack(meta, d, out, device=None)
+    table = pd.read_csv(meta)
+    genes = table.gene_id.tolist()
+    cfg = ([2000, 500, 100], 8, 40000, 40000, 7)
+    assert pack.find(d, None, *cfg, genes, meta=meta) is not None and pack.find(d, None, *cfg, genes, meta=table) is not None
+    # (1) a label flips
+    t2 = table.copy()
+    t2.loc[3, "label"] = 1 - int(t2.loc[3, "label"])
+    with pytest.warns(UserWarning, match="stale"):
+        assert pack.find(d, None, *cfg, genes, meta=t2) is None
+    with pytest.raises(ValueError, match="stale"):
+        pack.find(d, out, *cfg, genes, meta=t2)
+    assert pack.find(d, None, *cfg, [g for g in genes if g != genes[3]], meta=t2) is not None      # the other genes are still good
+    # (2) a gene loses a partner region
+    t3 = table.copy()
+    k = int(np.flatnonzero(t3.neighbors.notna().to_numpy())[0])
+    t3.loc[k, "neighbors"], t3.loc[k, "scores"] = np.nan, np.nan
+    with pytest.warns(UserWarning):
+        assert pack.find(d, None, *cfg, genes, meta=t3) is None
+    # (3) a signal file is re-extracted with another length
+    r = table.iloc[0]
+    f = os.path.join(d, "%s:%d-%d.npy" % (r.chrom, r.start - 20000, r.start + 20000))
+    np.save(f, np.zeros((7, 39000), np.float16))
+    with pytest.warns(UserWarning):
+        assert pack.find(d, None, *cfg, genes, meta=table) is None
+    # (4) a store written without digests is never picked up silently
+    ps = pack.PackedStore(out)
+    bare = str(tmp_path / "bare.cfstore")
+    pack.write(bare, ps.genes, ps.signature, {k2: torch.from_numpy(np.array(v)) for k2, v in ps.arrays.items()})
+    with pytest.raises(ValueError, match="no content digests"):
+        pack.find(d, bare, *cfg, genes, meta=table)
+
+
+def test_regression_only_metadata_packs(tmp_path):
+    d = str(tmp_path / "npy")
+    meta = make_dataset(d, n_genes=6, seed=8)
+    t = pd.read_csv(meta).drop(columns=["label"])
+    t.to_csv(meta, index=False)
+    out = os.path.join(d, pack.DEFAULT_NAME)
+    assert pack.main(["-m", meta, "-d", d, "--host"]) == 0
+    ps = pack.PackedStore(out)
+    st = ps.store(ps.genes, regression=True)
+    assert torch.allclose(st.label, torch.from_numpy(np.log2(t.expression.to_numpy() + 1).astype(np.float32)))
+    assert int(ps.store(ps.genes).label.abs().sum()) == 0
