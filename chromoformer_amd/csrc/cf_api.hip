@@ -95,8 +95,13 @@ static void add_ffn(std::vector<PDesc>& v, const std::string& pre, int d_emb, in
 }
 
 static int check_config(const cf_config& c) {
-    if (c.d_emb != kD) return fail("d_emb must be 128 (got %d)", c.d_emb);
-    if (c.d_head != kD) return fail("d_head must be 128 (got %d)", c.d_head);
+    // (net.py:277-278 leave d_emb and d_head free; every kernel of this library is written for 128-wide rows -- one MFMA row tile
+    //  of 16 x 128 in LDS, eight waves x 16 columns -- so other widths are refused here, by name, instead of failing later)
+    if (c.d_emb != kD)
+        return fail("d_emb = %d is not supported: the HIP path implements d_emb = 128 only (the reference's default, net.py:277; "
+                    "configs/default.yaml embed.d_model); use the reference implementation for other widths", c.d_emb);
+    if (c.d_head != kD)
+        return fail("d_head = %d is not supported: the HIP path implements d_head = 128 only (the reference's default, net.py:278)", c.d_head);
     if (c.n_feats < 1 || c.n_feats > 8) return fail("n_feats must be in 1..8 (got %d)", c.n_feats);
     if (c.n_out != 1 && c.n_out != 2) return fail("n_out must be 1 or 2");
     if (c.n_res != 3) return fail("exactly 3 resolutions are supported (fc_head is Linear(3*d_emb, .), net.py:327)");
@@ -222,6 +227,8 @@ struct cf_handle {
     TrunkResDev* trunk_tab = nullptr;          // fused centre-row trunk (cf_trunk.h): device table, one entry per resolution
     bool trunk = false;                        // the Embedding + Pairwise stage runs as k_trunk_fwd / k_trunk_bwd (CF_TRUNK=0: the stand-alone kernels)
     size_t trunk_smem_bytes = 0;
+    bool head_deferred = false;                // cf_forward(save = 2) left the head to cf_backward_part (k_head_train)
+    float* deferred_logits_user = nullptr;
     int xcd_reduce = 0;                        // XCD-aware order of the weight-gradient tiles (measured slower: cf_kernels.h, xcd_tile)
     int defer_retile = 1;                      // Regulation + head units ride in the Embedding layer's chain launch (CF_DEFER_RETILE=0: all in the prologue)
     // workspace
@@ -342,7 +349,7 @@ static void plan_centre(cf_handle* h, CentreBuf& b, const std::string& pre, size
     b.du = h->ws_get(d + "u", N * 16);
     b.dq = h->ws_get(d + "q", N * kD);
     b.dx = h->ws_get(d + "x", N * kD);
-    b.partial = h->ws_get(d + "partial", tiles * post_partial_width(dff));
+    b.partial = h->ws_get(d + "partial", std::max(tiles, (size_t)h->cfg.max_batch) * post_partial_width(dff));      // (the fused trunk writes one row per gene)
 }
 
 // executed twice: once to size the arena, once to hand out pointers
@@ -450,16 +457,17 @@ static void push_cs(std::vector<CsTile>& out, const float* src, int ld, int ncol
     for (int c0 = 0; c0 < ncols; c0 += 64) out.push_back(CsTile{src, dst, ld, ncols, c0, rpg, div, src2});
 }
 // the bias / LayerNorm gradients carried by one post-chain partial buffer
+// (rows of the partial buffer: one per 16-row tile, M = ceil(rpg * batch / 16); one per gene with the fused trunk: rpg = div = 1)
 static void push_post_cs(std::vector<CsTile>& out, const cf_handle* h, const float* part, int dff, int rpg,
-                         const std::string& att_pre, const std::string& ff_pre) {
+                         const std::string& att_pre, const std::string& ff_pre, int div = kTile) {
     const int pw = post_partial_width(dff);
-    push_cs(out, part + 0, pw, kD, rpg, kTile, h->G_(ff_pre + "ln.weight"));
-    push_cs(out, part + 128, pw, kD, rpg, kTile, h->G_(ff_pre + "ln.bias"));
-    push_cs(out, part + 256, pw, kD, rpg, kTile, h->G_(ff_pre + "l2.bias"));
-    push_cs(out, part + 384, pw, dff, rpg, kTile, h->G_(ff_pre + "l1.bias"));
-    push_cs(out, part + 384 + dff, pw, kD, rpg, kTile, h->G_(att_pre + "ln.weight"));
-    push_cs(out, part + 512 + dff, pw, kD, rpg, kTile, h->G_(att_pre + "ln.bias"));
-    push_cs(out, part + 640 + dff, pw, kD, rpg, kTile, h->G_(att_pre + "ff.bias"));
+    push_cs(out, part + 0, pw, kD, rpg, div, h->G_(ff_pre + "ln.weight"));
+    push_cs(out, part + 128, pw, kD, rpg, div, h->G_(ff_pre + "ln.bias"));
+    push_cs(out, part + 256, pw, kD, rpg, div, h->G_(ff_pre + "l2.bias"));
+    push_cs(out, part + 384, pw, dff, rpg, div, h->G_(ff_pre + "l1.bias"));
+    push_cs(out, part + 384 + dff, pw, kD, rpg, div, h->G_(att_pre + "ln.weight"));
+    push_cs(out, part + 512 + dff, pw, kD, rpg, div, h->G_(att_pre + "ln.bias"));
+    push_cs(out, part + 640 + dff, pw, kD, rpg, div, h->G_(att_pre + "ff.bias"));
 }
 // weight gradients of one centre-row layer (q / k / v projections, out-projection, FFN)
 static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const CentreBuf& b, const float* xin, int ldxin,
@@ -580,7 +588,8 @@ static int build_tables(cf_handle* h) {
             float* gatt = h->G_(lp + "self_att.att.weight");
             push_centre_wg(wg, h, b, h->ex0[r], kD, 1, c.embed_dff, gatt, gatt + (size_t)kD * kD, gatt + (size_t)2 * kD * kD,
                            lp + "self_att.", lp + "ff.");
-            push_post_cs(cs, h, b.partial, c.embed_dff, 1, lp + "self_att.", lp + "ff.");
+            if (h->trunk) push_post_cs(cs, h, b.partial, c.embed_dff, 1, lp + "self_att.", lp + "ff.", 1);
+            else push_post_cs(cs, h, b.partial, c.embed_dff, 1, lp + "self_att.", lp + "ff.");
         }
         {   // Pairwise
             const std::string pre = fmt("pairwise_interaction.%d.", bs);
@@ -605,7 +614,8 @@ static int build_tables(cf_handle* h) {
                 float* gc = h->G_(lp + "self_att.c_att.weight");
                 push_centre_wg(wg, h, b, xin, kD, S, c.pair_dff, h->G_(lp + "self_att.p_att.weight"), gc, gc + (size_t)kD * kD,
                                lp + "self_att.", lp + "ff.");
-                push_post_cs(cs, h, b.partial, c.pair_dff, S, lp + "self_att.", lp + "ff.");
+                if (h->trunk) push_post_cs(cs, h, b.partial, c.pair_dff, 1, lp + "self_att.", lp + "ff.", 1);
+                else push_post_cs(cs, h, b.partial, c.pair_dff, S, lp + "self_att.", lp + "ff.");
             }
         }
         for (int l = 0; l < c.reg_layers; ++l) {   // Regulation
@@ -948,9 +958,9 @@ static CentreParams pair_params(const cf_handle* h, int r, int l) {
 }
 
 // device table of the fused centre-row trunk (cf_trunk.h)
-static const void* trunk_kernel(bool bwd, int dff_e, int dff_p) {
-    if (dff_e == 128 && dff_p == 256) return bwd ? (const void*)nullptr : (const void*)k_trunk_fwd<128, 256>;
-    return nullptr;
+static const void* trunk_kernel(bool bwd, int dff_e, int dff_p, int pair_layers) {
+    if (dff_e == 128 && dff_p == 256 && pair_layers == 2) return bwd ? (const void*)k_trunk_bwd<128, 256, 2> : (const void*)k_trunk_fwd<128, 256, 2>;
+    return nullptr;      // (other shapes run the stand-alone kernels)
 }
 static void fill_centre_dev(CentreLayerDev& d, const CentreParams& p, const CentreBuf& b) {
     d.wq_t = p.wq_t, d.wk = p.wk, d.wv_t = p.wv_t, d.wo_t = p.wo_t, d.bo = p.bo, d.g1 = p.g1, d.be1 = p.be1;
@@ -965,15 +975,15 @@ static int build_trunk_table(cf_handle* h) {
     const cf_config& c = h->cfg;
     h->trunk = false;
     if (h->embed_dense || !h->attc2 || c.i_max > kAGMax || c.pair_layers > kMaxPairLayers || kPostWaves != 8) return 0;
-    if (!trunk_kernel(false, c.embed_dff, c.pair_dff)) return 0;
-    {   // (opt-in until the fused backward exists and both are verified on the GPU)
-        const char* e = getenv("CF_TRUNK");
-        if (!e || atoi(e) == 0) return 0;
-    }
+    if (!trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers)) return 0;
+    if (const char* e = getenv("CF_TRUNK"))      // CF_TRUNK=0: the stand-alone kernels (A/B runs, cross-checks in the tests)
+        if (atoi(e) == 0) return 0;
     size_t need = 0;
     for (int r = 0; r < c.n_res; ++r) need = std::max(need, trunk_smem(c.n_bins[r], c.n_feats, c.i_max, std::max(c.embed_dff, c.pair_dff)));
     if (need > 160 * 1024) return 0;
-    if (hipFuncSetAttribute(trunk_kernel(false, c.embed_dff, c.pair_dff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return 0;
+    if (hipFuncSetAttribute(trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
+        hipFuncSetAttribute(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
+        return 0;
     std::vector<TrunkResDev> tab(c.n_res);
     for (int r = 0; r < c.n_res; ++r) {
         TrunkResDev& t = tab[r];
@@ -1050,6 +1060,26 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
     return 0;
 }
 
+static void head_fwd_args(const cf_handle* h, int B, float* logits_user, HeadFwdArgs& a) {
+    const cf_config& c = h->cfg;
+    for (int r = 0; r < c.n_res; ++r) {
+        a.xl[r] = h->Rx[r][c.reg_layers];
+        a.x0[r] = h->Rx[r][0];
+    }
+    a.w1_t = h->T_("fc_head.0.weight");
+    a.b1 = h->P_("fc_head.0.bias");
+    a.w2 = h->P_("fc_head.2.weight");
+    a.b2 = h->P_("fc_head.2.bias");
+    a.hin = h->hin;
+    a.h1 = h->h1;
+    a.logits = h->logits;
+    a.logits_user = logits_user;
+    a.B = B;
+    a.T = c.i_max + 1;
+    a.n_res = c.n_res;
+    a.n_out = c.n_out;
+}
+
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
@@ -1094,7 +1124,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             ta.rt_tiledT = h->reg8 ? h->tiledT : nullptr;
         }
         void* kargs[] = {&ta};
-        HIP_TRY(hipLaunchKernel(trunk_kernel(false, c.embed_dff, c.pair_dff), dim3(B, nres + (defer && ta.rt_n > 0 ? 1 : 0)), dim3(kAT), kargs,
+        HIP_TRY(hipLaunchKernel(trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + (defer && ta.rt_n > 0 ? 1 : 0)), dim3(kAT), kargs,
                                 h->trunk_smem_bytes, st));
         LAUNCH_CHECK("k_trunk_fwd");
     }
@@ -1370,24 +1400,11 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         launch_post_fwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         LAUNCH_CHECK("k_post_fwd<reg>");
     }
-    {   // head
+    h->head_deferred = save == 2;
+    h->deferred_logits_user = logits;
+    if (save != 2) {   // head (save = 2: together with the loss and its backward in cf_backward_part, one launch)
         HeadFwdArgs a;
-        for (int r = 0; r < nres; ++r) {
-            a.xl[r] = h->Rx[r][c.reg_layers];
-            a.x0[r] = h->Rx[r][0];
-        }
-        a.w1_t = h->T_("fc_head.0.weight");
-        a.b1 = h->P_("fc_head.0.bias");
-        a.w2 = h->P_("fc_head.2.weight");
-        a.b2 = h->P_("fc_head.2.bias");
-        a.hin = h->hin;
-        a.h1 = h->h1;
-        a.logits = h->logits;
-        a.logits_user = logits;
-        a.B = B;
-        a.T = T;
-        a.n_res = nres;
-        a.n_out = c.n_out;
+        head_fwd_args(h, B, logits, a);
         hipLaunchKernelGGL(k_head_fwd, dim3(tiles_of(B)), dim3(kHeadThreads), 0, st, a);
         LAUNCH_CHECK("k_head_fwd");
     }
@@ -1425,8 +1442,17 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         a.T = T;
         a.n_res = nres;
         a.n_out = c.n_out;
-        hipLaunchKernelGGL(k_head_bwd, dim3(tiles_of(B)), dim3(kHeadThreads), 0, st, a);
-        LAUNCH_CHECK("k_head_bwd");
+        if (h->head_deferred) {      // the forward pass left the head to this call: forward, loss, backward in one launch
+            if (!labels) return fail("cf_backward: cf_forward(save_for_backward = 2) needs the fused loss (labels)");
+            HeadFwdArgs f;
+            head_fwd_args(h, B, h->deferred_logits_user, f);
+            hipLaunchKernelGGL(k_head_train, dim3(tiles_of(B)), dim3(kHeadThreads), 0, st, f, a);
+            LAUNCH_CHECK("k_head_train");
+            h->head_deferred = false;
+        } else {
+            hipLaunchKernelGGL(k_head_bwd, dim3(tiles_of(B)), dim3(kHeadThreads), 0, st, a);
+            LAUNCH_CHECK("k_head_bwd");
+        }
     }
     if ((parts & 2) && h->reg_fused) {
         RegArgs ra;
@@ -1501,6 +1527,15 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         LAUNCH_CHECK("k_dgrad<qkvg>");
     }
     if (!(parts & 4)) return 0;
+    if (h->trunk) {      // Pairwise + Embedding backward, the join and the 7-mark projection partials: one launch (cf_trunk.h)
+        TrunkArgs ta;
+        trunk_args(h, bt, ta, 1);
+        ta.lp_jobs = h->lp_jobs;
+        void* kargs[] = {&ta};
+        HIP_TRY(hipLaunchKernel(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres), dim3(kAT), kargs, h->trunk_smem_bytes, st));
+        LAUNCH_CHECK("k_trunk_bwd");
+        return 0;
+    }
     // one centre-row layer backward: post chain -> attention -> query chain
     auto centre_bwd = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* dout, RowMap dmap,
                           const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff) -> int {
@@ -1652,7 +1687,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
 constexpr bool kMergeReduce = CF_MERGE_REDUCE;
 // deferred weight / bias gradients: one launch per bucket over the two tile tables
 static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUCKET_REG | CF_BUCKET_PE) {
-    if (buckets & CF_BUCKET_PE) {
+    if ((buckets & CF_BUCKET_PE) && !h->trunk) {      // (the fused trunk backward writes these partials itself)
         hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
         LAUNCH_CHECK("k_wgrad_lp");
     }

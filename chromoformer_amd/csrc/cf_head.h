@@ -19,7 +19,7 @@ struct HeadFwdArgs {
     int B, T, n_res, n_out;
 };
 constexpr int kHeadThreads = 512;      // eight waves: wave w owns 16 of the 128 hidden columns
-__global__ __launch_bounds__(kHeadThreads) void k_head_fwd(HeadFwdArgs a) {
+__device__ __forceinline__ void head_fwd_body(const HeadFwdArgs& a) {
     // all n_res resolution chunks of the concatenated input are fetched at once into one [16][n_res*128] tile (one barrier), then
     // every wave runs ONE product over the whole reduction range with a continuous operand ring
     constexpr int KMAX = kMaxRes * kD;
@@ -92,6 +92,8 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_fwd(HeadFwdArgs a) {
     }
 }
 
+__global__ __launch_bounds__(kHeadThreads) void k_head_fwd(HeadFwdArgs a) { head_fwd_body(a); }
+
 struct HeadBwdArgs {
     const float* logits;         // [B, n_out]
     const void* labels;          // int64 [B] (n_out = 2) / float [B] (n_out = 1); null: dlogits is given
@@ -105,7 +107,7 @@ struct HeadBwdArgs {
     float gscale;
     int B, T, n_res, n_out;
 };
-__global__ __launch_bounds__(kHeadThreads) void k_head_bwd(HeadBwdArgs a) {
+__device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
     __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];
     __shared__ float dl[kTile][2];
     __shared__ float li[kTile];
@@ -184,6 +186,16 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_bwd(HeadBwdArgs a) {
             *counter = 0u;
         }
     }
+}
+
+__global__ __launch_bounds__(kHeadThreads) void k_head_bwd(HeadBwdArgs a) { head_bwd_body(a); }
+// Training step: head forward, loss and head backward of a 16-gene tile in ONE launch -- nothing of the backward half depends on
+// another tile (the mean loss is only reported), and the two launches were 12 + 13 us of latency for a few MFLOP.  The logits
+// and the hidden layer travel through global memory (they are saved anyway) behind a workgroup barrier.
+__global__ __launch_bounds__(kHeadThreads) void k_head_train(HeadFwdArgs f, HeadBwdArgs b) {
+    head_fwd_body(f);
+    __syncthreads();
+    head_bwd_body(b);
 }
 
 }  // namespace cf

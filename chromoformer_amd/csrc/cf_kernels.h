@@ -1776,11 +1776,11 @@ struct LpJob {
     int F;
 };
 constexpr int kLpGenes = 1;
-__global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs, int batch) {
-    const LpJob& j = jobs[blockIdx.y];
-    const int g0 = blockIdx.x * kLpGenes, g1 = min(batch, g0 + kLpGenes);
+// the partial of genes [g0, g0 + kLpGenes) of one job, by 256 threads (t256 = 0 .. 255)
+__device__ __forceinline__ void wgrad_lp_body(const LpJob& j, const int chunk, const int batch, const int t256) {
+    const int g0 = chunk * kLpGenes, g1 = min(batch, g0 + kLpGenes);
     if (g0 >= batch) return;
-    const int e = threadIdx.x & 127, fh = threadIdx.x >> 7;
+    const int e = t256 & 127, fh = t256 >> 7;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < j.nseg; ++s) {
         const WgSeg& sg = j.seg[s];
@@ -1795,10 +1795,13 @@ __global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs
             acc[3] = fmaf(av, bv.w, acc[3]);
         }
     }
-    float* out = j.partial + (size_t)blockIdx.x * (kD * j.F) + e * j.F;
+    float* out = j.partial + (size_t)chunk * (kD * j.F) + e * j.F;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (fh * 4 + k < j.F) stg(out + fh * 4 + k, acc[k]);
+}
+__global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs, int batch) {
+    wgrad_lp_body(jobs[blockIdx.y], blockIdx.x, batch, threadIdx.x);
 }
 
 // Deferred column sums (bias / LayerNorm / gamma gradients): out[c] = sum_m src[m][c] (* src2[m][c])

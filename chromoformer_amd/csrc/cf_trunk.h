@@ -59,6 +59,7 @@ struct TrunkArgs {
     float* rt_tiled;
     float* rt_tiledT;
     int rt_n;
+    const LpJob* lp_jobs;              // backward: the 7-mark projection jobs, [2 r] = Embedding, [2 r + 1] = Pairwise of resolution r
 };
 
 // a table field through the constant address space: the pointer stays in SGPRs (cf_reg8.h, load_layer)
@@ -90,10 +91,18 @@ __host__ __device__ inline size_t trunk_smem(int L, int F, int S, int dff_max) {
     return (two > one ? two : one) > rt ? (two > one ? two : one) : rt;
 }
 
-// Every phase is a NOINLINE device function: inlined into one kernel the eight bodies share one register allocation and the
-// compiler hoists the table loads of all phases to the top (measured: 1.8 KB of scratch per lane, 477 spilled VGPRs); as calls
-// each body keeps the allocation it has as a stand-alone kernel and the kernel's budget is the maximum over the phases.
-#define CF_PHASE __device__ __attribute__((noinline))
+// How the phases are put together matters more than anything in them:
+//   * inlined one behind the other, the compiler hoists and merges the table loads of all phases and allocates registers for the
+//     lot: 1.8 KB of scratch per lane, 477 spilled VGPRs;
+//   * as NOINLINE calls each body keeps the allocation it has as a stand-alone kernel -- but the callee saves the 108
+//     callee-saved VGPRs of the calling convention it uses (every body of 256 registers: 108 scratch stores + loads per lane and
+//     call, ~0.4 MB per workgroup and phase): the fused forward kernel took 134 us against 122 us for the eight launches;
+//   * so they ARE inlined, in straight-line code (the number of Pairwise layers is a template parameter) -- 
+//     With one more thing: the phases compute the same address arithmetic from the same uniform inputs, the compiler merges it
+//     across phases and keeps it alive through the 244-register attention bodies (two attentions back to back: 104 spilled
+//     VGPRs).  launder() passes the context through an empty asm in front of every phase: each phase recomputes what it needs,
+//     as the stand-alone kernels do.
+#define CF_PHASE static __device__ __forceinline__
 
 struct TrunkCtx {      // what every phase needs, by value (uniform: lives in SGPRs)
     const TrunkResDev* R;
@@ -103,6 +112,17 @@ struct TrunkCtx {      // what every phase needs, by value (uniform: lives in SG
     int g, S, T, F, save;
     float scale, rscale;
 };
+__device__ __forceinline__ void launder(TrunkCtx& c, float*& smem, float*& persist) {
+    asm volatile("" : "+s"(c.R), "+s"(c.feats), "+s"(c.mask), "+s"(c.mstride), "+s"(c.g), "+s"(c.S), "+s"(c.T), "+s"(c.F), "+s"(c.save),
+                 "+s"(c.scale), "+s"(c.rscale));
+    // LDS pointers: through the local address space (32-bit offsets) and back -- a generic pointer truncated to 32 bits and
+    // widened again is NOT an LDS address any more (its aperture bits are gone)
+    typedef __attribute__((address_space(3))) float* lds_ptr;
+    unsigned a = (unsigned)(uintptr_t)(lds_ptr)smem, b = (unsigned)(uintptr_t)(lds_ptr)persist;
+    asm volatile("" : "+s"(a), "+s"(b));
+    smem = (float*)(lds_ptr)(uintptr_t)a;
+    persist = (float*)(lds_ptr)(uintptr_t)b;
+}
 __device__ __forceinline__ void trunk_attc_args(Attc2Args& at, const TrunkCtx& c, const float* wlp, const float* vin, float* p, float* w, float* vout,
                                                 int N) {
     const TrunkResDev* R = c.R;
@@ -260,7 +280,10 @@ CF_PHASE void trunk_post_p(TrunkCtx c, int l, int n_layers, float* smem) {
     post_fwd_body<true, 128, DFF, kAT / 64>(po, 0, row0, NB, xs, as_, ts, reinterpret_cast<float (*)[PostFwdLds<DFF>::HW + 4]>(wide_raw));
 }
 
-template <int DFF_E, int DFF_P>
+// PL: pairwise_interaction.n_layers as a template parameter -- the phases follow each other in STRAIGHT-LINE code.  (As a loop over
+// a phase counter with the bodies in the cases of a switch the compiler hoists what the phases have in common out of the loop
+// and keeps it alive through all of them: 218 spilled VGPRs against 10 for the straight line.)
+template <int DFF_E, int DFF_P, int PL>
 __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NWV = kAT / 64;
@@ -276,28 +299,185 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
     const int r = a.n_res - 1 - (int)blockIdx.y;
     const TrunkResDev* R = a.tab + r;
     constexpr int DFF_MAX = DFF_E > DFF_P ? DFF_E : DFF_P;
+    float* sm = smem;
     float* persist = smem + trunk_scratch_floats(TF(L), DFF_MAX);
     TrunkCtx c{R, a.pfeats[r], a.pmask[r], a.pmstride[r], (int)blockIdx.x, a.S, a.T, a.F, a.save, a.scale, a.rscale};
+#define CF_NEXT_PHASE   \
+    __syncthreads();    \
+    launder(c, sm, persist)
     // ---------------------------------------------------------------- Embedding layer: one row (the promoter's centre bin)
-    trunk_x0_qchain_e(c, smem);
-    __syncthreads();
-    trunk_attc1_e<false>(c, smem);
-    __syncthreads();
-    trunk_post_e<DFF_E>(c, smem);
-    __syncthreads();
+    trunk_x0_qchain_e(c, sm);
+    CF_NEXT_PHASE;
+    trunk_attc1_e<false>(c, sm);
+    CF_NEXT_PHASE;
+    trunk_post_e<DFF_E>(c, sm);
     // ---------------------------------------------------------------- Pairwise stack: S rows (the gene's pairs)
     c.feats = a.cfeats[r];
     c.mask = a.cmask[r];
     c.mstride = a.cmstride[r];
-    trunk_qchain_p0(c, smem);
-    __syncthreads();
-    for (int l = 0; l < a.pair_layers; ++l) {
-        if (l == 0) trunk_attc2_p<false, false>(c, l, smem, persist);
-        else trunk_attc2_p<false, true>(c, l, smem, persist);
-        __syncthreads();
-        trunk_post_p<DFF_P>(c, l, a.pair_layers, smem);
-        __syncthreads();
+    CF_NEXT_PHASE;
+    trunk_qchain_p0(c, sm);
+    CF_NEXT_PHASE;
+    trunk_attc2_p<false, false>(c, 0, sm, persist);      // first layer: stages features, masks, Wlp
+    CF_NEXT_PHASE;
+    trunk_post_p<DFF_P>(c, 0, PL, sm);
+#pragma unroll
+    for (int l = 1; l < PL; ++l) {
+        CF_NEXT_PHASE;
+        trunk_attc2_p<false, true>(c, l, sm, persist);   // later layers: they are in LDS
+        CF_NEXT_PHASE;
+        trunk_post_p<DFF_P>(c, l, PL, sm);
     }
+}
+
+// ---- backward phases
+__device__ __forceinline__ void trunk_post_bwd_args(PostBwdArgs& pb, const CentreLayerDev* P) {
+    pb.xh2[0] = ldc(&P->xh2);
+    pb.rs2[0] = ldc(&P->rs2);
+    pb.g2[0] = ldc(&P->g2);
+    pb.hdn[0] = ldc(&P->hdn);
+    pb.w2[0] = ldc(&P->w2);
+    pb.w1[0] = ldc(&P->w1);
+    pb.xh1[0] = ldc(&P->xh1);
+    pb.rs1[0] = ldc(&P->rs1);
+    pb.g1[0] = ldc(&P->g1);
+    pb.wo[0] = ldc(&P->wo);
+    pb.wv[0] = ldc(&P->wv);
+    pb.dt2[0] = ldc(&P->dt2);
+    pb.dpre1[0] = ldc(&P->dpre1);
+    pb.dt1[0] = ldc(&P->dt1);
+    pb.da[0] = ldc(&P->da);
+    pb.dxbar[0] = ldc(&P->dxbar);
+    pb.partial[0] = ldc(&P->partial);
+}
+#define CF_BWD_TILES(DFF)                                                                                       \
+    constexpr int WW_ = (DFF) > 128 ? (DFF) : 128;                                                              \
+    float (*wide)[WW_ + 4] = reinterpret_cast<float (*)[WW_ + 4]>(wide_raw)
+template <int DFF>
+CF_PHASE void trunk_post_bwd_p(TrunkCtx c, int l, int n_layers, float* smem) {
+    const TrunkResDev* R = c.R;
+    const CentreLayerDev* P = &R->P[l];
+    const bool last = l + 1 == n_layers;
+    const int S = c.S, row0 = c.g * S, NB = row0 + S;
+    CF_CHAIN_TILES(smem);
+    CF_BWD_TILES(DFF);
+    PostBwdArgs pb;
+    trunk_post_bwd_args(pb, P);
+    pb.dout[0] = last ? (const float*)TF(drx0) : (const float*)ldc(&R->P[last ? l : l + 1].dx);
+    pb.dmap = last ? RowMap{S, c.T, 1, 1} : identity_map();
+    pb.N = NB;
+    post_bwd_body<true, 128, DFF, kAT / 64>(pb, 0, row0, NB, c.g, xs, as_, ts, wide);      // one partial row per gene
+}
+CF_PHASE void trunk_qchain_bwd(TrunkCtx c, const CentreLayerDev* P, int row0, int NB, float* smem) {
+    float (*ds)[256 + 4] = reinterpret_cast<float (*)[256 + 4]>(smem);
+    float (*qs)[kD + 4] = reinterpret_cast<float (*)[kD + 4]>(smem + kTile * (256 + 4));
+    QBwdArgs qb;
+    qb.dqt[0] = ldc(&P->dqt);
+    qb.dres[0] = ldc(&P->dt1);
+    qb.wk[0] = ldc(&P->wk_t);      // NT product in the backward: tiled copy
+    qb.wq[0] = ldc(&P->wq);
+    qb.dq[0] = ldc(&P->dq);
+    qb.dx[0] = ldc(&P->dx);
+    qb.N = NB;
+    (void)c;
+    qchain_bwd_body<kAT / 64>(qb, 0, row0, ds, qs);
+}
+// The join of the gradient streams at the promoter embedding and lin_proj_p backward for ONE gene (k_join_dgrad's arithmetic):
+//   dxp0[g] = sum_s dxP0[g S + s]   (slot 0 first);   edout[g] = dxp0[g] . W + (dX0[g, token 0] + dhin[g, r])
+// thread = (column, quarter of K = 128): fmaf chains in the order of the matrix-core version, quarters summed as (0 + 1) + (2 + 3)
+CF_PHASE void trunk_join(TrunkCtx c, const float* dhin, int r, int n_res, float* smem) {
+    const TrunkResDev* R = c.R;
+    const int g = c.g, S = c.S, tid = threadIdx.x;
+    float* xk = smem;                  // [128]  dxp0 of the gene
+    float* red = smem + kD;            // [4][128]
+    if (tid < kD) {
+        const float* dxp = ldc(&R->P[0].dx) + (size_t)g * S * kD + tid;
+        float s = 0.f;
+        for (int i = 0; i < S; ++i) s += ldg(dxp + (size_t)i * kD);
+        xk[tid] = s;
+        stg(TF(dxp0) + (size_t)g * kD + tid, s);
+    }
+    __syncthreads();
+    {
+        const int col = tid & (kD - 1), kw = (tid >> 7) * 32;
+        const float* w = TF(lin_p) + (size_t)kw * kD + col;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = k * 16 + q * 4 + i;
+                    acc = fmaf(xk[kw + kk], ldg(w + (size_t)kk * kD), acc);
+                }
+        red[(tid >> 7) * kD + col] = acc;
+    }
+    __syncthreads();
+    if (tid < kD) {
+        const float v = (red[tid] + red[kD + tid]) + (red[2 * kD + tid] + red[3 * kD + tid]);
+        const float res = ldg(TF(drx0) + (size_t)g * c.T * kD + tid) + ldg(dhin + (size_t)g * (n_res * kD) + r * kD + tid);
+        stg(TF(edout) + (size_t)g * kD + tid, v + res);
+    }
+}
+template <int DFF>
+CF_PHASE void trunk_post_bwd_e(TrunkCtx c, float* smem) {
+    const TrunkResDev* R = c.R;
+    const int g = c.g;
+    CF_CHAIN_TILES(smem);
+    CF_BWD_TILES(DFF);
+    PostBwdArgs pb;
+    trunk_post_bwd_args(pb, &R->E);
+    pb.dout[0] = TF(edout);
+    pb.dmap = identity_map();
+    pb.N = g + 1;
+    post_bwd_body<true, 128, DFF, kAT / 64>(pb, 0, g, g + 1, g, xs, as_, ts, wide);
+}
+CF_PHASE void trunk_lp(const LpJob* jobs, int r, int g, int batch) {
+    const int tid = threadIdx.x;
+    wgrad_lp_body(jobs[2 * r + (tid >> 8)], g, batch, tid & 255);
+}
+
+template <int DFF_E, int DFF_P, int PL>
+__global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = a.n_res - 1 - (int)blockIdx.y;
+    const TrunkResDev* R = a.tab + r;
+    constexpr int DFF_MAX = DFF_E > DFF_P ? DFF_E : DFF_P;
+    float* sm = smem;
+    float* persist = smem + trunk_scratch_floats(TF(L), DFF_MAX);
+    TrunkCtx c{R, a.cfeats[r], a.cmask[r], a.cmstride[r], (int)blockIdx.x, a.S, a.T, a.F, 1, a.scale, a.rscale};
+    // ---------------------------------------------------------------- Pairwise stack, last layer first
+    trunk_post_bwd_p<DFF_P>(c, PL - 1, PL, sm);
+    CF_NEXT_PHASE;
+    trunk_attc2_p<true, false>(c, PL - 1, sm, persist);       // stages features, masks, Wlp
+    CF_NEXT_PHASE;
+    trunk_qchain_bwd(c, &c.R->P[PL - 1], c.g * c.S, c.g * c.S + c.S, sm);
+#pragma unroll
+    for (int l = PL - 2; l >= 0; --l) {
+        CF_NEXT_PHASE;
+        trunk_post_bwd_p<DFF_P>(c, l, PL, sm);
+        CF_NEXT_PHASE;
+        trunk_attc2_p<true, true>(c, l, sm, persist);         // they are in LDS
+        CF_NEXT_PHASE;
+        trunk_qchain_bwd(c, &c.R->P[l], c.g * c.S, c.g * c.S + c.S, sm);
+    }
+    // ---------------------------------------------------------------- join at the promoter embedding, lin_proj_p backward
+    CF_NEXT_PHASE;
+    trunk_join(c, a.dhin, r, a.n_res, sm);
+    // ---------------------------------------------------------------- Embedding layer
+    c.feats = a.pfeats[r];
+    c.mask = a.pmask[r];
+    c.mstride = a.pmstride[r];
+    CF_NEXT_PHASE;
+    trunk_post_bwd_e<DFF_E>(c, sm);
+    CF_NEXT_PHASE;
+    trunk_attc1_e<true>(c, sm);
+    CF_NEXT_PHASE;
+    trunk_qchain_bwd(c, &c.R->E, c.g, c.g + 1, sm);
+    // ---------------------------------------------------------------- 7-mark projection partials of this gene (k_wgrad_lp)
+    CF_NEXT_PHASE;
+    trunk_lp(a.lp_jobs, r, c.g, a.B);
 }
 
 }  // namespace cf

@@ -261,9 +261,10 @@ class ChromoformerBase(nn.Module):
 
     # ----------------------------------------------------------------- forward / backward
     def _run_forward(self, bs, save):
+        """save: False / 0 = inference, True / 1 = keep activations, 2 = as 1 with the head left to the cf_backward that follows."""
         out = torch.empty(bs.B, self.n_out, device=self._device)
         st = torch.cuda.current_stream(self._device).cuda_stream
-        _lib.check(_lib.lib().cf_forward(self._handle, C.byref(bs), out.data_ptr(), 1 if save else 0, st), "cf_forward")
+        _lib.check(_lib.lib().cf_forward(self._handle, C.byref(bs), out.data_ptr(), int(save), st), "cf_forward")
         return out
 
     def forward(self, promoter_feats, promoter_pad_masks, pcre_feats, pcre_pad_masks, interaction_masks, interaction_freq):
@@ -303,7 +304,7 @@ class ChromoformerBase(nn.Module):
     def forward_backward(self, packed, labels, loss_scale=1.0):
         """Fused forward + loss + backward.  Returns (logits, loss tensor on device)."""
         bs, _ = packed
-        logits = self._run_forward(bs, save=True)
+        logits = self._run_forward(bs, save=2)       # filled by cf_backward below (head forward + loss + head backward: one launch)
         labels = labels.to(self._device)
         labels = labels.float().contiguous() if self.n_out == 1 else labels.long().contiguous()
         st = torch.cuda.current_stream(self._device).cuda_stream

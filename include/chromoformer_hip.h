@@ -108,15 +108,17 @@ void cf_destroy(cf_handle* h);
 int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg, float* exp_avg_sq);
 
 /* ---- hot path ------------------------------------------------------------------- */
-/* ChromoformerBase.forward (net.py:332-380).  logits: [B, n_out].  With save_for_backward
- * = 0 the call is inference only. */
+/* ChromoformerBase.forward (net.py:332-380).  logits: [B, n_out].  save_for_backward: 0 = inference only; 1 = keep what
+ * cf_backward needs; 2 = as 1, and the prediction head (net.py:377-380) is LEFT to the cf_backward / cf_backward_part(parts & 1)
+ * call that must follow with labels: head forward, loss and head backward then run as one launch, and `logits` (which has to
+ * stay valid until then) is written by that call -- the training step of a caller that does not need the logits in between. */
 int cf_forward(cf_handle* h, const cf_batch* batch, float* logits, int save_for_backward, void* stream);
 /* criterion(out, label) + loss.backward() (train.py:156, 193-195).  labels: int64 [B]
  * (n_out = 2, CrossEntropyLoss) or float [B] (n_out = 1, MSELoss).  `loss_scale`
  * multiplies the mean-over-B loss gradient (1.0 single GPU; 1/world for an all-reduce SUM).
  * Writes the scalar loss to loss_out (device, 1 float) and every trainable gradient into
  * the bound grads buffer (overwrites; nothing accumulates across calls).  Must follow a
- * cf_forward(..., save_for_backward = 1) on the same batch. */
+ * cf_forward(..., save_for_backward = 1 or 2) on the same batch. */
 int cf_backward(cf_handle* h, const cf_batch* batch, const void* labels, float loss_scale,
                 float* loss_out, void* stream);
 /* The two halves of cf_backward, for callers that replay the first as a hipGraph:

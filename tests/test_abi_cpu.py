@@ -56,6 +56,13 @@ def test_unsupported_configs_are_rejected_loudly():
     lay = _lib.cf_layout()
     assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
     assert b"embed.n_layers" in _lib.lib().cf_last_error()
+    # widths the reference leaves free (net.py:277-278) and this library does not implement: refused by name, with the reference site
+    for field, site in (("d_emb", b"net.py:277"), ("d_head", b"net.py:278")):
+        cfg = _cfg()
+        setattr(cfg, field, 256)
+        assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
+        err = _lib.lib().cf_last_error()
+        assert field.encode() in err and site in err and b"not supported" in err
 
 
 def test_model_state_dict_and_seeded_init_match_golden():
