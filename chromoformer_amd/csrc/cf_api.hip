@@ -1907,6 +1907,34 @@ extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float bet
     h->n_opt = (buckets == (CF_BUCKET_REG | CF_BUCKET_PE)) ? 1 : 2;      // one launch over the whole range, or one per bucket
     return 0;
 }
+// The deferred gradients of `reduce_buckets` and the AdamW update of `adam_buckets` (disjoint from them, gradients already
+// complete) in ONE launch (k_reduce_adamw).
+extern "C" int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                    long long step, int adam_buckets, void* stream) {
+    if (!h || !h->grads) return fail("cf_reduce_adamw_part: no gradient buffer bound");
+    if (B < 1 || B > h->cfg.max_batch) return fail("cf_reduce_adamw_part: bad batch size %d", B);
+    if (reduce_buckets != CF_BUCKET_PE && reduce_buckets != CF_BUCKET_REG) return fail("cf_reduce_adamw_part: exactly one reduction bucket");
+    if (adam_buckets & reduce_buckets) return fail("cf_reduce_adamw_part: the optimiser range overlaps the bucket under reduction");
+    AdamHyper hy;
+    long long lo, n4;
+    int agrid;
+    if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy) || adam_range(h, adam_buckets, lo, n4, agrid)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const long long launches0 = g_launches;
+    if ((reduce_buckets & CF_BUCKET_PE) && !h->trunk) {
+        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
+        LAUNCH_CHECK("k_wgrad_lp");
+    }
+    const bool reg = reduce_buckets == CF_BUCKET_REG;
+    const int w0 = reg ? 0 : h->n_wg_r, wn = reg ? h->n_wg_r : h->n_wg - h->n_wg_r;
+    const int c0 = reg ? 0 : h->n_cs_r, cn = reg ? h->n_cs_r : h->n_cs - h->n_cs_r;
+    AdamArgs o{h->params + lo, h->m + lo, h->v + lo, h->grads + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps};
+    hipLaunchKernelGGL(k_reduce_adamw, dim3(xcd_grid(wn) + cn + agrid), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn,
+                       (const CsTile*)h->cs_tiles + c0, cn, B, h->xcd_reduce, o);
+    LAUNCH_CHECK("k_reduce_adamw");
+    h->n_bwd += (int)(g_launches - launches0);
+    return 0;
+}
 // Split form for callers that replay the optimiser launch from a hipGraph: cf_adamw_set (eager, once per step, before the
 // replay) writes the step's scalars to device memory, cf_adamw_step_dev (capturable) reads them.
 extern "C" int cf_adamw_set(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void* stream) {

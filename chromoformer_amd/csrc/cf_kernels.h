@@ -1850,11 +1850,10 @@ __global__ __launch_bounds__(256) void k_reduce(const WgTile* __restrict__ wg, i
 // AdamW (torch.optim.AdamW defaults as used at train.py:157): decoupled decay, then the
 // moment updates and the bias-corrected step, in the same operation order as torch.
 // =======================================================================================
-__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                               float* __restrict__ v, long long n4, float decay, float one_m_b1, float b2,
-                                               float one_m_b2, float step_size, float bc2_sqrt, float eps) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+__device__ __forceinline__ void adamw_range(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                            long long n4, float decay, float one_m_b1, float b2, float one_m_b2, float step_size, float bc2_sqrt,
+                                            float eps, long long first, long long stride) {
+    for (long long i = first; i < n4; i += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i];
@@ -1874,6 +1873,36 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, long long n4, float decay, float one_m_b1, float b2,
+                                               float one_m_b2, float step_size, float bc2_sqrt, float eps) {
+    adamw_range(p, g, m, v, n4, decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                (long long)gridDim.x * blockDim.x);
+}
+// The gradient reductions of one bucket and the AdamW update of ANOTHER bucket's (already reduced) range in one launch: workgroups
+// [0, n_red) take the weight-gradient / column-sum tiles, the rest stream the optimiser state.  The Embedding + Pairwise bucket's
+// reduction is a launch of ~300 latency-bound tiles (21 us with most of the chip idle), the Regulation + head bucket's AdamW a pure
+// 116 MB stream (19 us): side by side they take about as long as the longer one.
+struct AdamArgs {
+    float *p, *m, *v;
+    const float* g;
+    long long n4;
+    float decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps;
+};
+__global__ __launch_bounds__(256) void k_reduce_adamw(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int n_cs, int batch,
+                                                      int xcd, AdamArgs o) {
+    const int nb = xcd_grid(n_wg), n_red = nb + n_cs;
+    if ((int)blockIdx.x < nb) {
+        const int t = xcd_tile(blockIdx.x, n_wg, xcd);
+        if (t < n_wg) wgrad_tile(wg[t], batch);
+    } else if ((int)blockIdx.x < n_red) {
+        colsum_tile(cs[blockIdx.x - nb], batch);
+    } else {
+        const long long nblk = gridDim.x - n_red;
+        adamw_range(o.p, o.g, o.m, o.v, o.n4, o.decay, o.one_m_b1, o.b2, o.one_m_b2, o.step_size, o.bc2_sqrt, o.eps,
+                    (long long)(blockIdx.x - n_red) * blockDim.x + threadIdx.x, nblk * blockDim.x);
     }
 }
 // The same update with the step-dependent scalars read from device memory, so that the launch can sit inside a

@@ -96,7 +96,7 @@ class Slot:
 class EpochFeed:
     """The batches of an epoch taken from a device-resident GeneStore INSIDE the step graph (cf_gather_batch): the gene
     order of the epoch is uploaded once, a device-side cursor walks it, and every step's logits / labels / loss are
-    appended to per-epoch logs (cf_record_step).  A training step is then two host calls -- graph replay and AdamW --
+    appended to per-epoch logs (cf_record_step).  A training step is then three host calls -- graph replay, reduction + AdamW, AdamW --
     instead of the reference's DataLoader round trip plus per-tensor .cuda() copies (train.py:137-140, 171-177)."""
 
     def __init__(self, model, store, bsz, max_batches=None):
@@ -179,7 +179,7 @@ class Trainer:
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
-                 overlap_allreduce=None):
+                 overlap_allreduce=None, merge_opt=True):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -215,6 +215,10 @@ class Trainer:
         # latency-bound kernels live on.  The default is one eager launch over the whole range behind the graph.
         self.opt_in_graph = opt_in_graph and timed_kernel != "k_adamw"
         self.overlap_opt = overlap_opt and self.opt_in_graph
+        # Single GPU: the Embedding + Pairwise bucket's gradient reduction (~300 latency-bound tiles, 21 us on a mostly idle chip)
+        # and the Regulation + head bucket's AdamW (a 116 MB stream, 19 us) are independent of each other: ONE launch runs them
+        # side by side (cf_reduce_adamw_part), the small bucket's AdamW follows.  Three host calls per step instead of two.
+        self.merge_opt = bool(merge_opt) and not self.dp and not self.opt_in_graph and timed_kernel not in ("k_wgrad", "k_colsum", "k_adamw")
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -249,6 +253,10 @@ class Trainer:
                                         slot.loss.data_ptr(), slot.B, feed.logits_log.data_ptr(), feed.labels_log.data_ptr(),
                                         feed.loss_log.data_ptr(), st), "cf_record_step")
         self._reduce(slot, st, _lib.BUCKET_REG)
+
+    def _seq_main(self, slot, st):      # single GPU, merged optimiser: everything up to the Pairwise + Embedding backward (its bucket is reduced beside AdamW)
+        self._seq_early(slot, st)
+        self._part(slot, st, 4)
 
     def _seq_late(self, slot, st):      # Pairwise + Embedding backward and their gradient bucket
         self._part(slot, st, 4)
@@ -307,7 +315,7 @@ class Trainer:
             if getattr(slot, "feed", None) is not None:
                 slot.feed.rewind()                     # the validation pass consumed a batch: rewind (no parameter was updated)
             torch.cuda.synchronize()
-            first = self._seq_early if self.dp else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph))
+            first = self._seq_early if self.dp else (self._seq_main if self.merge_opt else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph)))
             slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
         if feed is not None:
             feed.taken += 1
@@ -315,7 +323,16 @@ class Trainer:
         if oig:      # this step's AdamW scalars go to device memory before anything is replayed
             m._step += 1
             _lib.check(L.cf_adamw_set(m._handle, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step, st), "cf_adamw_set")
-        if not self.dp:
+        if not self.dp and self.merge_opt:
+            if self.use_graph:
+                self._launch(slot.graph["first"], st)
+            else:
+                self._seq_main(slot, st)
+            m._step += 1
+            hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
+            _lib.check(L.cf_reduce_adamw_part(m._handle, slot.B, _lib.BUCKET_PE, *hp, _lib.BUCKET_REG, st), "cf_reduce_adamw_part")
+            _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_PE, st), "cf_adamw_step_part")
+        elif not self.dp:
             if self.use_graph:
                 self._launch(slot.graph["first"], st)
             else:
@@ -363,7 +380,7 @@ class Trainer:
                 _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_REG, st), "cf_adamw_step_part")
                 self.stream.wait_event(ev_done)                  # late bucket reduced
                 _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_PE, st), "cf_adamw_step_part")
-        if not oig and not self.dp:
+        if not oig and not self.dp and not self.merge_opt:
             m.adamw_step(self.lr, self.betas, self.eps, self.wd)
         self._last = slot
         return slot.logits, slot.loss

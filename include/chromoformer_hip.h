@@ -204,6 +204,12 @@ double cf_kernel_flops(cf_handle* h, const char* kernel, int B);
 int cf_debug_copy(cf_handle* h, const char* name, float* dst, long long* n_floats, void* stream);
 /* Names of all workspace buffers, '\n' separated (host string owned by the handle). */
 const char* cf_debug_names(cf_handle* h);
+/* cf_backward_reduce_part(reduce_buckets) and cf_adamw_step_part(adam_buckets) as ONE launch: the tiles of the bucket under
+ * reduction and the optimiser stream of the OTHER bucket (whose gradients must be complete, and all-reduced under data
+ * parallelism) run side by side.  reduce_buckets: exactly one bucket; adam_buckets: disjoint from it.  Same results as the two
+ * separate calls, bit for bit.  Not capturable (the optimiser's scalars are launch arguments). */
+int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, long long step, int adam_buckets, void* stream);
 /* Number of kernels the LAST forward / backward (chain pieces + bucket reductions) / optimiser step launched, counted at the
  * launch sites (zero before the first call; calls replayed from a graph do not pass the host code and leave the counts
  * of the capture pass). */
