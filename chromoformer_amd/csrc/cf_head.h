@@ -28,52 +28,71 @@ __device__ __forceinline__ void head_fwd_body(const HeadFwdArgs& a) {
     const int row0 = blockIdx.x * kTile, K = a.n_res * kD, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int col0 = w * 16;
-    FragNT<1, 8> f;      // (chunks are requested by hand below: the reduction length n_res * 128 is a run-time value)
-    f.wp = a.w1_t + (size_t)col0 * K + lane * 4;
-    f.tstride = K * 16;
-    const int nch = K / 32;
-    for (int i = tid; i < kTile * (K / 4); i += kHeadThreads) {
-        const int row = i / (K / 4), c4k = i - row * (K / 4), r = c4k >> 5, c4 = c4k & 31, g = row0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < a.B) {
-            const size_t o = (size_t)g * a.T * kD + c4 * 4;
-            const float4 p = ldg4(a.xl[r] + o), q = ldg4(a.x0[r] + o);
-            v = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
-            stg4(a.hin + (size_t)g * K + r * kD + c4 * 4, v);
-        }
-        *reinterpret_cast<float4*>(&xs[row][c4k * 4]) = v;
+    // The whole operand stream of the wave (16 hidden columns x K = n_res * 128: 1 KB per 16-deep k-block) is requested at once:
+    // a 3-chunk ring covers ~800 cycles of MFMA work against ~2 K cycles of L2 latency, i.e. the product used to stall on every
+    // chunk (12 x ~1.3 K cycles); 24 sixteen-byte loads in flight cost 96 registers this kernel has to spare.
+    constexpr int KB = kMaxRes * kD / 16;            // 16-deep k-blocks at most
+    float4 wb[KB];
+    const float* wp = a.w1_t + (size_t)col0 * K + lane * 4;
+    const int nkb = K / 16;
+    // input rows first (loads return in order: the tile's puts wait for these alone), the operand stream behind them
+    constexpr int NTL = kTile * (KMAX / 4) / kHeadThreads;      // float4 pairs per thread: 3
+    float4 tp[NTL], tq[NTL];
+#pragma unroll
+    for (int u = 0; u < NTL; ++u) {
+        const int i = min(tid + u * kHeadThreads, kTile * (K / 4) - 1);
+        const int row = i / (K / 4), c4k = i - row * (K / 4), r = c4k >> 5, c4 = c4k & 31, g = min(row0 + row, a.B - 1);
+        const size_t o = (size_t)g * a.T * kD + c4 * 4;
+        tp[u] = ldg4(a.xl[r] + o);
+        tq[u] = ldg4(a.x0[r] + o);
     }
 #pragma unroll
-    for (int c = 0; c < kRing - 1; ++c) frag_chunk_nt(f, c, min(c, nch - 1));
+    for (int kb = 0; kb < KB; ++kb) wb[kb] = ldg4(wp + (size_t)min(kb, nkb - 1) * 256);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NTL; ++u) {
+        const int i = tid + u * kHeadThreads;
+        if (i < kTile * (K / 4)) {
+            const int row = i / (K / 4), c4k = i - row * (K / 4), r = c4k >> 5, c4 = c4k & 31, g = row0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < a.B) {
+                v = make_float4(tp[u].x + tq[u].x, tp[u].y + tq[u].y, tp[u].z + tq[u].z, tp[u].w + tq[u].w);
+                stg4(a.hin + (size_t)g * K + r * kD + c4 * 4, v);
+            }
+            *reinterpret_cast<float4*>(&xs[row][c4k * 4]) = v;
+        }
+    }
+    // operands of the logits (fc_head.2) and the first bias: requested here, consumed two barriers later
+    const float b1v = ldg(a.b1 + col0 + lr);
+    float w2v[2][kD / 16];
+    {
+        const int sub = tid & 15;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < kD / 16; ++k) w2v[c][k] = ldg(a.w2 + min(c, a.n_out - 1) * kD + sub + 16 * k);
+    }
     __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     {
         const float* ap = &xs[lr][lq * 4];
-        for (int c0 = 0; c0 < nch; c0 += kRing) {
 #pragma unroll
-            for (int u = 0; u < kRing; ++u) {
-                const int c = c0 + u;
-                if (c + kRing - 1 < nch) frag_chunk_nt(f, (u + kRing - 1) % kRing, c + kRing - 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c < nch)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const float4 av = *reinterpret_cast<const float4*>(ap + (c * 2 + k) * 16);
-                        const float4 b = f.ring[u][k][0];
-                        acc = mfma4(av.x, b.x, acc);
-                        acc = mfma4(av.y, b.y, acc);
-                        acc = mfma4(av.z, b.z, acc);
-                        acc = mfma4(av.w, b.w, acc);
-                    }
+        for (int kb = 0; kb < KB; ++kb)
+            if (kb < nkb) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + kb * 16);
+                const float4 b = wb[kb];
+                acc = mfma4(av.x, b.x, acc);
+                acc = mfma4(av.y, b.y, acc);
+                acc = mfma4(av.z, b.z, acc);
+                acc = mfma4(av.w, b.w, acc);
             }
-        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = lq * 4 + i, col = col0 + lr;
-        const float v = fmaxf(acc[i] + a.b1[col], 0.f);
+        const float v = fmaxf(acc[i] + b1v, 0.f);
         hs[row][col] = v;
-        if (row0 + row < a.B) a.h1[(size_t)(row0 + row) * kD + col] = v;
+        if (row0 + row < a.B) stg(a.h1 + (size_t)(row0 + row) * kD + col, v);
     }
     __syncthreads();
     if (tid < 256) {   // logits: 16 lanes per gene
@@ -81,7 +100,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadFwdArgs& a) {
         for (int c = 0; c < a.n_out; ++c) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < kD / 16; ++k) s = fmaf(hs[row][sub + 16 * k], a.w2[c * kD + sub + 16 * k], s);
+            for (int k = 0; k < kD / 16; ++k) s = fmaf(hs[row][sub + 16 * k], w2v[c & 1][k], s);
             s = group16_sum(s);
             if (sub == 0 && g < a.B) {
                 const float v = s + a.b2[c];
@@ -113,6 +132,19 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
     __shared__ float li[kTile];
     const int row0 = blockIdx.x * kTile, K = a.n_res * kD, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    // what the later phases read from global memory is requested up front (every phase used to start with a round trip of its
+    // own): the W1 operand of this wave's first column block of the dhin product, the W2 rows and the ReLU mask of dh1
+    FragNN<4, 8> f0;
+    frag_load_nn(f0, a.w1 + min(w, K / 64 - 1) * 64, K);
+    constexpr int NDH = kTile * kD / kHeadThreads;      // dh1 entries per thread: 4
+    float w2a[NDH], w2b[NDH], h1v[NDH];
+#pragma unroll
+    for (int u = 0; u < NDH; ++u) {
+        const int i = tid + u * kHeadThreads, row = i >> 7, j = i & 127, g = min(row0 + row, a.B - 1);
+        w2a[u] = ldg(a.w2 + j);
+        w2b[u] = ldg(a.w2 + (a.n_out == 2 ? kD : 0) + j);
+        h1v[u] = ldg(a.h1 + (size_t)g * kD + j);
+    }
     if (tid < kTile) {        // loss and d loss / d logits of one gene
         const int g = row0 + tid;
         float l = 0.f, d0 = 0.f, d1 = 0.f;
@@ -143,18 +175,20 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
         li[tid] = l;
     }
     __syncthreads();
-    for (int i = tid; i < kTile * kD; i += kHeadThreads) {      // dh1 = (dlogits W2) * (h1 > 0)
-        const int row = i >> 7, j = i & 127, g = row0 + row;
-        float s = dl[row][0] * a.w2[j];
-        if (a.n_out == 2) s = fmaf(dl[row][1], a.w2[kD + j], s);
-        const float v = (g < a.B && a.h1[(size_t)g * kD + j] > 0.f) ? s : 0.f;
+#pragma unroll
+    for (int u = 0; u < NDH; ++u) {      // dh1 = (dlogits W2) * (h1 > 0)
+        const int i = tid + u * kHeadThreads, row = i >> 7, j = i & 127, g = row0 + row;
+        float s = dl[row][0] * w2a[u];
+        if (a.n_out == 2) s = fmaf(dl[row][1], w2b[u], s);
+        const float v = (g < a.B && h1v[u] > 0.f) ? s : 0.f;
         ds[row][j] = v;
-        if (g < a.B) a.dh1[(size_t)g * kD + j] = v;
+        if (g < a.B) stg(a.dh1 + (size_t)g * kD + j, v);
     }
     __syncthreads();
     for (int jb = w; jb < K / 64; jb += kHeadThreads / 64) {          // dhin[:, 64 jb ..] = dh1 . W1[:, 64 jb ..]
         FragNN<4, 8> f;
-        frag_load_nn(f, a.w1 + jb * 64, K);
+        if (jb == w) f = f0;
+        else frag_load_nn(f, a.w1 + jb * 64, K);
         f32x4 acc[4];
         zero_acc(acc);
         frag_mma_nn(f, &ds[0][0], kD + 4, acc);
