@@ -145,14 +145,18 @@ __device__ __forceinline__ float wave_max(float v) {
 #define CF_APREFETCH 1      // read the A operand of a k-step one step ahead (experiment switch)
 #endif
 constexpr int kRing = 4;      // register ring slots: chunks c+1 .. c+kRing-1 are in flight while chunk c is multiplied
-template <int NT, int KS>
+// RING: slots of this product's ring (default kRing).  A chunk of a narrow product (NT = 1: eight MFMAs, ~256 cycles) covers little
+// of the ~2 K cycles of an L2 round trip; where a wave is alone with its product (the head: 4 workgroups) requesting everything at
+// once paid (cf_head.h: -7 us); in the chain bodies, where the second wave of the SIMD fills the gaps, RING = 8 for the K = 256
+// products changed nothing (k_trunk_fwd 100.0 vs 98.9 us, k_trunk_bwd 138.0 vs 139.0).
+template <int NT, int KS, int RING = kRing>
 struct FragNT {
-    float4 ring[kRing][2][NT];
+    float4 ring[RING][2][NT];
     const float* wp;
     int tstride;      // floats between consecutive 16-row tiles: (ldw / 16) * 256
 };
-template <int NT, int KS>
-__device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS>& f, int slot, int chunk) {
+template <int NT, int KS, int RING>
+__device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS, RING>& f, int slot, int chunk) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -161,25 +165,25 @@ __device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS>& f, int slot, int c
 }
 // Wt: TILED address of the first output row of this wave (row index a multiple of 16), plus
 // (k0 / 16) * 256 for a reduction offset k0; ldw: K of the full tensor.
-template <int NT, int KS>
-__device__ __forceinline__ void frag_load_nt(FragNT<NT, KS>& f, const float* __restrict__ Wt, int ldw) {
+template <int NT, int KS, int RING>
+__device__ __forceinline__ void frag_load_nt(FragNT<NT, KS, RING>& f, const float* __restrict__ Wt, int ldw) {
     static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
     f.wp = Wt + (threadIdx.x & 63) * 4;
     f.tstride = ldw * 16;
 #pragma unroll
-    for (int c = 0; c < kRing - 1; ++c)
+    for (int c = 0; c < RING - 1; ++c)
         if (c < KS / 2) frag_chunk_nt(f, c, c);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int NT, int KS>
-__device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
+template <int NT, int KS, int RING>
+__device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS, RING>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
     constexpr int NC = KS / 2;
     float4 a_nxt = *reinterpret_cast<const float4*>(ap);      // A operand one k-step ahead: its LDS latency hides behind the MFMAs
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (c + kRing - 1 < NC) frag_chunk_nt(f, (c + kRing - 1) % kRing, c + kRing - 1);
+        if (c + RING - 1 < NC) frag_chunk_nt(f, (c + RING - 1) % RING, c + RING - 1);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -187,7 +191,7 @@ __device__ __forceinline__ void frag_mma_nt(FragNT<NT, KS>& f, const float* As, 
             if (CF_APREFETCH && c * 2 + k + 1 < KS) a_nxt = *reinterpret_cast<const float4*>(ap + (c * 2 + k + 1) * 16);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float4 b = f.ring[c % kRing][k][t];
+                const float4 b = f.ring[c % RING][k][t];
                 acc[t] = mfma4(a.x, b.x, acc[t]);
                 acc[t] = mfma4(a.y, b.y, acc[t]);
                 acc[t] = mfma4(a.z, b.z, acc[t]);
@@ -215,40 +219,40 @@ template <>
 struct VecN<4> {
     typedef float4 type;
 };
-template <int NT, int KS>
+template <int NT, int KS, int RING = kRing>
 struct FragNN {
-    typename VecN<NT>::type ring[kRing][2][4];
+    typename VecN<NT>::type ring[RING][2][4];
     const float* bp;
     int ldb;
 };
-template <int NT, int KS>
-__device__ __forceinline__ void frag_chunk_nn(FragNN<NT, KS>& f, int slot, int chunk) {
+template <int NT, int KS, int RING>
+__device__ __forceinline__ void frag_chunk_nn(FragNN<NT, KS, RING>& f, int slot, int chunk) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             f.ring[slot][k][i] = LdgN<NT>::ld(f.bp + (size_t)((chunk * 2 + k) * 16 + i) * f.ldb);
 }
-template <int NT, int KS>
-__device__ __forceinline__ void frag_load_nn(FragNN<NT, KS>& f, const float* __restrict__ Bm, int ldb) {
+template <int NT, int KS, int RING>
+__device__ __forceinline__ void frag_load_nn(FragNN<NT, KS, RING>& f, const float* __restrict__ Bm, int ldb) {
     static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     f.bp = Bm + (size_t)(q * 4) * ldb + NT * r;
     f.ldb = ldb;
 #pragma unroll
-    for (int c = 0; c < kRing - 1; ++c)
+    for (int c = 0; c < RING - 1; ++c)
         if (c < KS / 2) frag_chunk_nn(f, c, c);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int NT, int KS>
-__device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
+template <int NT, int KS, int RING>
+__device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS, RING>& f, const float* As, int lda, f32x4 (&acc)[NT]) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const float* ap = As + r * lda + q * 4;
     constexpr int NC = KS / 2;
     float4 a_nxt = *reinterpret_cast<const float4*>(ap);      // A operand one k-step ahead
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (c + kRing - 1 < NC) frag_chunk_nn(f, (c + kRing - 1) % kRing, c + kRing - 1);
+        if (c + RING - 1 < NC) frag_chunk_nn(f, (c + RING - 1) % RING, c + RING - 1);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -257,7 +261,7 @@ __device__ __forceinline__ void frag_mma_nn(FragNN<NT, KS>& f, const float* As, 
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float* bv = reinterpret_cast<const float*>(&f.ring[c % kRing][k][i]);
+                const float* bv = reinterpret_cast<const float*>(&f.ring[c % RING][k][i]);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = mfma4(av[i], bv[t], acc[t]);
             }
@@ -1043,7 +1047,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
                 if (a.save && row0 + row < N) stg(a.hdn[r] + (size_t)(row0 + row) * DFF + col, v);
             }
     }
-    FragNT<NTC, DFF / 16> f2;
+    FragNT<NTC, DFF / 16> f2;      // (RING = 8 for this K = 256 product, everything in flight at once: measured, no change)
     frag_load_nt(f2, a.w2[r] + (size_t)(w * CW) * DFF, DFF);
     __syncthreads();
     {   // t2 = y1 + hdn W2^T + b2
@@ -1187,7 +1191,7 @@ __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r,
         ln_bwd_tile16(&ds[0][0], &t2[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g2[r] + sub * 8), ldg4(a.g2[r] + sub * 8 + 4), a.rs2[r], row0,
                       min(kTile, N - row0), a.dt2[r]);   // t2 = dt2
     }
-    FragNN<NTC, DFF / 16> fw1;
+    FragNN<NTC, DFF / 16> fw1;      // (RING = 8 for this K = 256 product: measured, no change)
     frag_load_nn(fw1, a.w1[r] + w * CW, kD);
     __syncthreads();
     colsum16q(&t2[0][0], kD + 4, nullptr, 0, kD, part + 256);          // d l2.bias
