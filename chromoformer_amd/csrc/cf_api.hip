@@ -1019,6 +1019,7 @@ static void trunk_args(const cf_handle* h, const cf_batch* bt, TrunkArgs& a, int
     a.B = bt->B, a.S = c.i_max, a.T = c.i_max + 1, a.F = c.n_feats, a.n_res = c.n_res, a.pair_layers = c.pair_layers, a.save = save;
     a.scale = sqrtf(64.f);
     a.rscale = 1.0f / a.scale;
+    a.tdbg = getenv("CF_STAMP_TRUNK") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;      // tools/trunk_stamps.py
 }
 
 static int check_batch(const cf_handle* h, const cf_batch* b) {

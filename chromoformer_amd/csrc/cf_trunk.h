@@ -60,6 +60,7 @@ struct TrunkArgs {
     float* rt_tiledT;
     int rt_n;
     const LpJob* lp_jobs;              // backward: the 7-mark projection jobs, [2 r] = Embedding, [2 r + 1] = Pairwise of resolution r
+    unsigned long long* tdbg;          // optional shader-clock stamps of workgroup (gene 0, longest resolution), one per phase boundary
 };
 
 // a table field through the constant address space: the pointer stays in SGPRs (cf_reg8.h, load_layer)
@@ -87,8 +88,11 @@ __host__ __device__ inline size_t trunk_smem(int L, int F, int S, int dff_max) {
     const size_t two = trunk_scratch_floats(L, dff_max) * sizeof(float) + attc2_persist_bytes(L, F, kAGMax);
     const size_t one = attc1_smem(L, F);
     const size_t rt = (size_t)(kAT / 64) * 16 * 20 * sizeof(float);
+    const size_t lp = (size_t)80 * (kD + 8) * sizeof(float);      // trunk_lp's operand rows (kLpRowsMax)
     (void)S;
-    return (two > one ? two : one) > rt ? (two > one ? two : one) : rt;
+    size_t m = two > one ? two : one;
+    m = m > rt ? m : rt;
+    return m > lp ? m : lp;
 }
 
 // How the phases are put together matters more than anything in them:
@@ -302,8 +306,11 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
     float* sm = smem;
     float* persist = smem + trunk_scratch_floats(TF(L), DFF_MAX);
     TrunkCtx c{R, a.pfeats[r], a.pmask[r], a.pmstride[r], (int)blockIdx.x, a.S, a.T, a.F, a.save, a.scale, a.rscale};
-#define CF_NEXT_PHASE   \
-    __syncthreads();    \
+    int stamp_i = 0;
+    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime();
+#define CF_NEXT_PHASE                                                                                     \
+    __syncthreads();                                                                                      \
+    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime(); \
     launder(c, sm, persist)
     // ---------------------------------------------------------------- Embedding layer: one row (the promoter's centre bin)
     trunk_x0_qchain_e(c, sm);
@@ -328,6 +335,7 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
         CF_NEXT_PHASE;
         trunk_post_p<DFF_P>(c, l, PL, sm);
     }
+    CF_NEXT_PHASE;
 }
 
 // ---- backward phases
@@ -433,9 +441,63 @@ CF_PHASE void trunk_post_bwd_e(TrunkCtx c, float* smem) {
     pb.N = g + 1;
     post_bwd_body<true, 128, DFF, kAT / 64>(pb, 0, g, g + 1, g, xs, as_, ts, wide);
 }
-CF_PHASE void trunk_lp(const LpJob* jobs, int r, int g, int batch) {
+// The 7-mark projection partials of the gene (k_wgrad_lp's arithmetic, same order): dW[e][f] = sum over the job's segments and
+// rows of A[m][e] B[m][f].  The <= 80 operand rows of both jobs (this workgroup wrote them a few phases ago) are staged in LDS
+// in ONE round trip -- thread-private loops over 64 rows of dependent global loads took 8 us here --, then thread (job, e, half
+// of the marks) walks them in the table's order.
+constexpr int kLpRowsMax = 80;
+CF_PHASE void trunk_lp(const LpJob* jobs, int r, int g, int batch, float* smem) {
     const int tid = threadIdx.x;
-    wgrad_lp_body(jobs[2 * r + (tid >> 8)], g, batch, tid & 255);
+    const LpJob* J = jobs + 2 * r;      // [0] Embedding (<= 3 segments), [1] Pairwise (<= kLpMaxSeg)
+    float* As = smem;                   // [rows][128]
+    float* Bs = smem + kLpRowsMax * kD; // [rows][8]
+    (void)batch;
+    constexpr int NSEG = 3 + kLpMaxSeg;
+    const int ns0 = ldc(&J[0].nseg), ns1 = ldc(&J[1].nseg);
+    // every segment holds <= 16 rows of 128 floats = one float4 per thread: all segments are requested before anything is put
+    float4 va[NSEG], vb[NSEG];
+    int rpg[NSEG];
+#pragma unroll
+    for (int u = 0; u < NSEG; ++u) {
+        const int jj = u < 3 ? 0 : 1, s = u < 3 ? u : u - 3;
+        const bool on = s < (jj ? ns1 : ns0);
+        const WgSeg* sp = &J[jj].seg[on ? s : 0];
+        const float* A = ldc(&sp->A);
+        const float* Bp = ldc(&sp->B);
+        const int lda = ldc(&sp->lda), ldb = ldc(&sp->ldb), n = ldc(&sp->rows_per_gene);
+        rpg[u] = on ? n : 0;
+        const size_t m0 = (size_t)g * n;
+        va[u] = ldg4(A + (m0 + min(tid >> 5, n - 1)) * lda + (tid & 31) * 4);
+        vb[u] = ldg4(Bp + (m0 + min(tid >> 1, n - 1)) * ldb + (tid & 1) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int base = 0, n0 = 0;
+#pragma unroll
+    for (int u = 0; u < NSEG; ++u) {
+        if (u == 3) n0 = base;
+        if ((tid >> 5) < rpg[u]) *reinterpret_cast<float4*>(As + (base + (tid >> 5)) * kD + (tid & 31) * 4) = va[u];
+        if ((tid >> 1) < rpg[u]) *reinterpret_cast<float4*>(Bs + (base + (tid >> 1)) * 8 + (tid & 1) * 4) = vb[u];
+        base += rpg[u];
+    }
+    __syncthreads();
+    const int job = tid >> 8, t256 = tid & 255, e = t256 & 127, fh = t256 >> 7;
+    const int lo = job ? n0 : 0, hi = job ? base : n0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int row = lo; row < hi; ++row) {
+        const float av = As[row * kD + e];
+        const float4 bv = *reinterpret_cast<const float4*>(Bs + row * 8 + fh * 4);
+        acc[0] = fmaf(av, bv.x, acc[0]);
+        acc[1] = fmaf(av, bv.y, acc[1]);
+        acc[2] = fmaf(av, bv.z, acc[2]);
+        acc[3] = fmaf(av, bv.w, acc[3]);
+    }
+    const int F = ldc(&J[0].F);
+    float* const p0 = ldc(&J[0].partial);
+    float* const p1 = ldc(&J[1].partial);
+    float* out = (job ? p1 : p0) + (size_t)g * (kD * F) + e * F;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (fh * 4 + k < F) stg(out + fh * 4 + k, acc[k]);
 }
 
 template <int DFF_E, int DFF_P, int PL>
@@ -447,6 +509,8 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     float* sm = smem;
     float* persist = smem + trunk_scratch_floats(TF(L), DFF_MAX);
     TrunkCtx c{R, a.cfeats[r], a.cmask[r], a.cmstride[r], (int)blockIdx.x, a.S, a.T, a.F, 1, a.scale, a.rscale};
+    int stamp_i = 32;
+    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime();
     // ---------------------------------------------------------------- Pairwise stack, last layer first
     trunk_post_bwd_p<DFF_P>(c, PL - 1, PL, sm);
     CF_NEXT_PHASE;
@@ -477,7 +541,8 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     trunk_qchain_bwd(c, &c.R->E, c.g, c.g + 1, sm);
     // ---------------------------------------------------------------- 7-mark projection partials of this gene (k_wgrad_lp)
     CF_NEXT_PHASE;
-    trunk_lp(a.lp_jobs, r, c.g, a.B);
+    trunk_lp(a.lp_jobs, r, c.g, a.B, sm);
+    CF_NEXT_PHASE;
 }
 
 }  // namespace cf
