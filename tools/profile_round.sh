@@ -1,18 +1,20 @@
 #!/bin/bash
 # rocprofv3 evidence of one round: kernel statistics of the benchmark step, HBM traffic (separate FETCH_SIZE / WRITE_SIZE
-# passes, as the gfx950 guide prescribes) and MFMA-pipe occupancy.   tools/profile_round.sh <tag>   (run on the GPU box)
+# passes, as the gfx950 guide prescribes) and MFMA-pipe occupancy, plus the bench lines of the variants DESIGN.md quotes.
+#   tools/profile_round.sh <tag>   (run on the GPU box; every step under its own `timeout`)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dp-path --train-loop-steps 0"
-rocprofv3 --kernel-trace --stats -d /tmp/p_stats --output-format csv -- python3 $B > $OUT/stats_bench.json 2> /dev/null
+R=$GRAFT_REPO_ROOT
+B="$R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dp-path --train-loop-steps 0"
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats --output-format csv -- python3 $B > $OUT/stats_bench.json 2> /dev/null
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch --output-format csv -- python3 $B --no-graph > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write --output-format csv -- python3 $B --no-graph > /dev/null 2>&1
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $(find /tmp/p_fetch -name "*counter_collection.csv" | head -1) $(find /tmp/p_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json $OUT/pmc_hbm_traffic.csv
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p_mfma --output-format csv -- python3 $B --no-graph > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch --output-format csv -- python3 $B --eager > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write --output-format csv -- python3 $B --eager > /dev/null 2>&1
+python3 $R/tools/pmc_summary.py $(find /tmp/p_fetch -name "*counter_collection.csv" | head -1) $(find /tmp/p_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json $OUT/pmc_hbm_traffic.csv
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p_mfma --output-format csv -- python3 $B --eager > /dev/null 2>&1
 python3 - <<PY
 import csv, collections
 f = "$(find /tmp/p_mfma -name '*counter_collection.csv' | head -1)"
@@ -27,4 +29,14 @@ with open("$OUT/mfma_utilisation.csv", "w") as o:
         busy, act = v["SQ_VALU_MFMA_BUSY_CYCLES"] / n[k], v["GRBM_GUI_ACTIVE"] / n[k]
         o.write('"%s",%d,%.0f,%.0f,%.4f\n' % (k, n[k], busy, act, busy / (act / 8 * 1024) if act else 0))
 PY
+cd $R
+# the bench lines DESIGN.md quotes (un-profiled runs)
+timeout 400 python3 bench.py --steps 300 --warmup 30 > $OUT/bench.json 2> /dev/null
+timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --graph > $OUT/bench_graph.json 2> /dev/null
+timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --roofline-kernel k_reg_fwd > $OUT/bench_k_reg_fwd.json 2> /dev/null
+timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --roofline-kernel k_wgrad > $OUT/bench_k_wgrad.json 2> /dev/null
+timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --regime realistic > $OUT/bench_realistic.json 2> /dev/null
+timeout 200 python3 bench.py --config stress --steps 20 --warmup 3 > $OUT/bench_stress.json 2> /dev/null
+CF_TRUNK=0 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 > $OUT/bench_no_trunk.json 2> /dev/null
+timeout 100 python3 tools/trunk_stamps.py > $OUT/trunk_stamps.txt 2> /dev/null
 ls -la $OUT

@@ -1,5 +1,6 @@
-"""Phase timeline of the fused centre-row trunk kernels (workgroup of gene 0 at the longest resolution; cycles of the 100 MHz
-s_memtime clock are scaled to ns):   CF_STAMP_TRUNK=1 python tools/trunk_stamps.py"""
+"""Phase timeline of the fused centre-row trunk kernels (workgroup of gene 0 at the longest resolution), in s_memtime ticks and as a
+share of the workgroup's time (the tick rate is not documented for gfx950; against the kernel durations of rocprofv3 it is ~2.4 GHz
+here):   python tools/trunk_stamps.py"""
 import os, sys
 os.environ["CF_STAMP_TRUNK"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,6 +19,6 @@ bwd = ["post chain P1", "attention P1 (staging)", "q chain P1", "post chain P0",
        "q chain E", "7-mark partials"]
 for name, base, names in (("forward", 0, fwd), ("backward", 32, bwd)):
     d = np.diff(t[base: base + len(names) + 1])
-    print("%s: total %.1f us (s_memtime ticks x 10 ns)" % (name, d.sum() * 0.01))
+    print("%s: total %d ticks" % (name, d.sum()))
     for n, v in zip(names, d):
-        print("   %-32s %6.2f us" % (n, v * 0.01))
+        print("   %-32s %7d ticks  %5.1f %%" % (n, v, 100.0 * v / d.sum()))
