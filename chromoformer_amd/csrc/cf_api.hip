@@ -979,7 +979,7 @@ static int build_trunk_table(cf_handle* h) {
     if (const char* e = getenv("CF_TRUNK"))      // CF_TRUNK=0: the stand-alone kernels (A/B runs, cross-checks in the tests)
         if (atoi(e) == 0) return 0;
     size_t need = 0;
-    for (int r = 0; r < c.n_res; ++r) need = std::max(need, trunk_smem(c.n_bins[r], c.n_feats, c.i_max, std::max(c.embed_dff, c.pair_dff)));
+    for (int r = 0; r < c.n_res; ++r) need = std::max(need, trunk_smem(c.n_bins[r], c.n_feats, std::max(c.embed_dff, c.pair_dff)));
     if (need > 160 * 1024) return 0;
     if (hipFuncSetAttribute(trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
         hipFuncSetAttribute(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)

@@ -84,28 +84,27 @@ __host__ __device__ inline size_t trunk_scratch_floats(int L, int dff_max) {
     const size_t att = attc2_scratch_floats(L);
     return (chain > att ? chain : att) + 4;
 }
-__host__ __device__ inline size_t trunk_smem(int L, int F, int S, int dff_max) {
+__host__ __device__ inline size_t trunk_smem(int L, int F, int dff_max) {
     const size_t two = trunk_scratch_floats(L, dff_max) * sizeof(float) + attc2_persist_bytes(L, F, kAGMax);
     const size_t one = attc1_smem(L, F);
     const size_t rt = (size_t)(kAT / 64) * 16 * 20 * sizeof(float);
     const size_t lp = (size_t)80 * (kD + 8) * sizeof(float);      // trunk_lp's operand rows (kLpRowsMax)
-    (void)S;
     size_t m = two > one ? two : one;
     m = m > rt ? m : rt;
     return m > lp ? m : lp;
 }
 
-// How the phases are put together matters more than anything in them:
-//   * inlined one behind the other, the compiler hoists and merges the table loads of all phases and allocates registers for the
-//     lot: 1.8 KB of scratch per lane, 477 spilled VGPRs;
-//   * as NOINLINE calls each body keeps the allocation it has as a stand-alone kernel -- but the callee saves the 108
-//     callee-saved VGPRs of the calling convention it uses (every body of 256 registers: 108 scratch stores + loads per lane and
-//     call, ~0.4 MB per workgroup and phase): the fused forward kernel took 134 us against 122 us for the eight launches;
-//   * so they ARE inlined, in straight-line code (the number of Pairwise layers is a template parameter) -- 
-//     With one more thing: the phases compute the same address arithmetic from the same uniform inputs, the compiler merges it
-//     across phases and keeps it alive through the 244-register attention bodies (two attentions back to back: 104 spilled
-//     VGPRs).  launder() passes the context through an empty asm in front of every phase: each phase recomputes what it needs,
-//     as the stand-alone kernels do.
+// How the phases are put together matters more than anything in them (all measured / compiled, round 3):
+//   * as NOINLINE calls each body keeps the register allocation it has as a stand-alone kernel -- but the callee saves the 108
+//     callee-saved VGPRs of the calling convention it uses (every 256-register body: 108 scratch stores + loads per lane and call)
+//     and receives its uniform arguments in VGPRs: every table field becomes a vector load, the attention body has 212 flat
+//     accesses and 287 divergent branches.  The fused forward kernel took 134 us against 122 us for the eight launches it replaces;
+//   * inlined one behind the other as they are, the compiler merges the address arithmetic the phases have in common and keeps it
+//     alive through the 244-register attention bodies: 477 spilled VGPRs (two attentions back to back alone: 104);
+//   * inlined into the cases of a switch inside a loop over a phase counter, the common part is hoisted out of the loop: 218 spills.
+// What the kernels below do: every phase forceinline, STRAIGHT-LINE code (the number of Pairwise layers is a template parameter), and
+// launder() in front of every phase -- the context passes through an empty `asm volatile`, so each phase recomputes what it needs
+// from opaque inputs, as the stand-alone kernels do.  21 (forward) / 72 (backward) spilled VGPRs remain, none inside a loop.
 #define CF_PHASE static __device__ __forceinline__
 
 struct TrunkCtx {      // what every phase needs, by value (uniform: lives in SGPRs)

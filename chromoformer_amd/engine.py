@@ -179,7 +179,7 @@ class Trainer:
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
-                 overlap_allreduce=None, merge_opt=True):
+                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -219,6 +219,13 @@ class Trainer:
         # and the Regulation + head bucket's AdamW (a 116 MB stream, 19 us) are independent of each other: ONE launch runs them
         # side by side (cf_reduce_adamw_part), the small bucket's AdamW follows.  Three host calls per step instead of two.
         self.merge_opt = bool(merge_opt) and not self.dp and not self.opt_in_graph and timed_kernel not in ("k_wgrad", "k_colsum", "k_adamw")
+        # Single GPU: the Regulation + head bucket's gradient reduction (55 us) depends on the Regulation backward only, the Pairwise +
+        # Embedding backward (k_trunk_bwd, 135 us on 192 of the 256 CUs) does not depend on it: with overlap_reduce the reduction is
+        # issued on the side stream BEHIND the trunk launch and runs beside it (CF_OVERLAP_REDUCE=1; see DESIGN.md for the numbers).
+        if overlap_reduce is None:
+            import os
+            overlap_reduce = os.environ.get("CF_OVERLAP_REDUCE", "0") != "0"
+        self.overlap_reduce = bool(overlap_reduce) and self.merge_opt
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -239,7 +246,7 @@ class Trainer:
     def _reduce(self, slot, st, buckets):
         _lib.check(self._L.cf_backward_reduce_part(self.model._handle, slot.B, buckets, st), "cf_backward_reduce_part")
 
-    def _seq_early(self, slot, st):     # [batch gather,] forward, loss, head + Regulation backward, [step log,] Regulation + head gradient bucket
+    def _seq_early(self, slot, st, reduce=True):     # [batch gather,] forward, loss, head + Regulation backward, [step log,] Regulation + head gradient bucket
         m, L = self.model, self._L
         feed = getattr(slot, "feed", None)
         if feed is not None:
@@ -252,9 +259,18 @@ class Trainer:
             _lib.check(L.cf_record_step(m._handle, feed.cursor.data_ptr(), slot.logits.data_ptr(), slot.label.data_ptr(),
                                         slot.loss.data_ptr(), slot.B, feed.logits_log.data_ptr(), feed.labels_log.data_ptr(),
                                         feed.loss_log.data_ptr(), st), "cf_record_step")
-        self._reduce(slot, st, _lib.BUCKET_REG)
+        if reduce:
+            self._reduce(slot, st, _lib.BUCKET_REG)
 
     def _seq_main(self, slot, st):      # single GPU, merged optimiser: everything up to the Pairwise + Embedding backward (its bucket is reduced beside AdamW)
+        if self.overlap_reduce:
+            side = self.side.cuda_stream
+            self._seq_early(slot, st, reduce=False)
+            self._wait(side, st)                             # fork behind the Regulation backward
+            self._part(slot, st, 4)                          # the trunk's 192 big workgroups are dispatched first ...
+            self._reduce(slot, side, _lib.BUCKET_REG)        # ... the reduction tiles fill what is left
+            self._wait(st, side)                             # join
+            return
         self._seq_early(slot, st)
         self._part(slot, st, 4)
 
