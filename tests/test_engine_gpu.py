@@ -39,6 +39,33 @@ def test_graph_replay_and_event_timing_are_bit_identical_to_the_eager_step():
             assert torch.equal(ref[k], got[k]), (kw, k)
 
 
+def test_round3_schedules_and_switches_are_bit_identical():
+    """The merged launch (one bucket's reduction beside the other bucket's AdamW), the reduction overlapped with the trunk backward on
+    the side stream, and the library switches that only move work between launches -- all the same arithmetic in the same order."""
+    import os
+    ref, ref_loss = _run(use_graph=False, merge_opt=False)
+    for kw in (dict(use_graph=False, merge_opt=True), dict(use_graph=True, merge_opt=True), dict(use_graph=True, merge_opt=True, overlap_reduce=True),
+               dict(use_graph=False, merge_opt=True, overlap_reduce=True)):
+        got, loss = _run(**kw)
+        assert loss == ref_loss, kw
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (kw, k)
+    for env in ({"CF_DEFER_RETILE": "0"}, {"CF_XCD_REDUCE": "1"}):      # read when the model is constructed
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            got, loss = _run(use_graph=True)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert loss == ref_loss, env
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (env, k)
+
+
 def test_graph_embedded_events_time_every_replay():
     from chromoformer_amd import ChromoformerClassifier
     from chromoformer_amd.engine import Trainer
