@@ -1726,7 +1726,7 @@ extern "C" int cf_backward_part(cf_handle* h, const cf_batch* bt, const void* la
     hipStream_t st = (hipStream_t)stream;
     if ((parts & 1) && !labels) return fail("cf_backward: labels is null");
     const long long launches0 = g_launches;
-    if (parts & 1) h->n_bwd = 0;      // a backward pass starts with the head: its pieces and the bucket reductions add up
+    if (parts & 1) h->n_bwd = h->n_opt = 0;      // a backward pass starts with the head: its pieces, the bucket reductions and the optimiser launches add up
     const int rc = backward_impl(h, bt, st, parts, labels, loss_scale, loss_out);
     h->n_bwd += (int)(g_launches - launches0);
     return rc;
@@ -1905,7 +1905,7 @@ extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float bet
                        h->v + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps);
     h->time_mark("k_adamw", (hipStream_t)stream);
     LAUNCH_CHECK("k_adamw");
-    h->n_opt = (buckets == (CF_BUCKET_REG | CF_BUCKET_PE)) ? 1 : 2;      // one launch over the whole range, or one per bucket
+    h->n_opt += 1;      // (reset when a backward pass starts: the optimiser launches of a step add up)
     return 0;
 }
 // The deferred gradients of `reduce_buckets` and the AdamW update of `adam_buckets` (disjoint from them, gradients already
@@ -1956,6 +1956,7 @@ extern "C" int cf_adamw_step_dev(cf_handle* h, int buckets, void* stream) {
                        h->v + lo, n4, (const AdamHyper*)h->hyper);
     h->time_mark("k_adamw", (hipStream_t)stream);
     LAUNCH_CHECK("k_adamw_dev");
+    h->n_opt += 1;
     return 0;
 }
 // `waiter` waits for everything enqueued on `signaller` so far (fork / join of a side stream; under capture this pulls
