@@ -129,6 +129,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed",
            os.path.join(CSRC, "cf_api.hip"), "-o", LIB_PATH]
+    cmd[6:6] = os.environ.get("CF_HIPCC_FLAGS", "").split()      # experiments (-DCF_...); the shipped library is built without
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -414,7 +414,7 @@ static void plan_workspace(cf_handle* h) {
     h->dhin = h->ws_get("dH.in", MB * 3 * kD);
     h->loss = h->ws_get("H.loss", 4);
     h->loss_part = h->ws_get("H.loss_part", MB / kTile + 1);
-    h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 40);      // shader-clock stamps (uint64) of the fused Regulation kernels
+    h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 64);      // shader-clock stamps (uint64) of the fused Regulation kernels
 }
 
 // ------------------------------------------------------------------------------------

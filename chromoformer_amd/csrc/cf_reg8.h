@@ -13,9 +13,12 @@
 //     operand stream is two such blocks = 8 MFMAs; a product requests all its units (64 registers) one product ahead,
 //     the two long products (K = 128 x 4 chunks forward, K = 1024 backward) run an 8-unit ring 7 units ahead.
 //   * what the backward needs of the attention is saved per (gene, head) in the layouts its operands want: q^T, k^T,
-//     gate^T as [32][16] tiles (= the forward's accumulator registers, one float4 per lane), v as [16][32] rows, p^T
-//     as a [16][16] tile.  Only row quarters that hold a token are written (the arena is zero-filled once): the forward
-//     is sensitive to its store volume -- 37 MB more per launch cost 10 us (measured: 3.7 TB/s at the margin).
+//     gate^T as transposed tiles (= the forward's accumulator registers, one float4 of four tokens per lane), v as
+//     [16][32] rows, p^T as a [16][16] tile.  The tiles are quarter-major -- [token quarter][column][4 tokens], 256
+//     contiguous bytes per quarter -- and only quarters / rows that hold a token are written or read back (T = 9: 6.3 KB
+//     of the 9 KB block, whole 64-byte pieces): the forward is sensitive to its store volume (37 MB more per launch cost
+//     10 us: 3.7 TB/s at the margin) and the backward waits for these reads, which every workgroup of the launch issues
+//     in the same microsecond (tools/reg_stamps.py bwd: the two LayerNorm phases).
 //   * bias / LayerNorm gradients are column sums of arrays the weight-gradient launch needs anyway (dt2, dpre1, dt1,
 //     dy1, d(layer output)): k_colsum takes them from there, nothing is reduced inside this kernel.
 //
@@ -181,7 +184,7 @@ __device__ __forceinline__ void ln_bwd_tile16_r(const float* src, float* dst, in
 
 #define CF_STAMP8(slot)                                                                     \
     do {                                                                                    \
-        if (a.tdbg && g == 0 && r == 0 && tid == 0) a.tdbg[l * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (a.tdbg && g == 0 && r == 0 && l < 6 && lane == 0) a.tdbg[(w * 6 + l) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
 template <int DFF, bool SAVE>
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
     const int oDLH = lq * 4 * LH + w * HW + lr, oALH = lr * LH + lq * 4;
     // global: per-lane BYTE offsets (the wave / gene part of an address is scalar and goes into the base, see sbase())
     const int hq0 = (g * kRH + w) * kHqFloats;                       // (gene, head) block of the saved attention operands
-    const unsigned bT = (lr * 16 + lq * 4) * 4;                      // transposed [32][16] tiles / p^T: one float4 per lane
+    const unsigned bT = (lq * 64 + lr * 4) * 4;                      // transposed tiles / p^T, one float4 per lane, quarter-major (see header)
     const unsigned bV = (lq * 4 * 32 + lr) * 4;                      // v rows
     const unsigned zA = (lq * 4 * kRDm + lr) * 4, zH = (lq * 4 * DFF + lr) * 4;
     const unsigned wl = lane * 16;
@@ -285,6 +288,9 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                 mma_unit(av, av, rq.s[u % 8][0], rq.s[u % 8][1], pacc[0], pacc[1]);
                 if ((u & 7) == 7) {
                     const int c = u >> 3;
+#ifdef CF_STAMP_CHUNKS      // (tools/reg_stamps.py: ends of the q, k, v chunks)
+                    if (c < 3) CF_STAMP8(9 + c);
+#endif
                     if (c < 2) {            // q, k: row-major into the wave's patch (operands of the scores), transposed tiles to global
                         float* dst = (c == 0 ? qs : ks) + oD36;
 #pragma unroll
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
     const int oDLH = lq * 4 * LH + w * HW + lr, oALH = lr * LH + lq * 4;
     const int oDQ = lq * 4 * kQkLd + w * 32 + lr, oAQ = lr * kQkLd + lq * 4;
     const int hq0 = (g * kRH + w) * kHqFloats;
-    const unsigned bT = (lr * 16 + lq * 4) * 4;                      // transposed [32][16] tiles / p^T: one float4 per lane
+    const unsigned bT = (lq * 64 + lr * 4) * 4;                      // transposed tiles / p^T, one float4 per lane, quarter-major
     const unsigned bVr = (lr * 32 + lq * 4) * 4;                     // B-operand rows of v: v[j = lr][4 lq ..]
     const unsigned zA = (lq * 4 * kRDm + lr) * 4, zH = (lq * 4 * DFF + lr) * 4, zD = (lq * 4 * kD + lr) * 4, zQ = (lq * 4 * kRW + lr) * 4;
     const unsigned wl = lane * 16;
@@ -606,13 +612,24 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         if (w < 4) ln_bwd_tile16_r(ds, ds, LD, l1x0, l1x1, l1ga, l1gb, l1rs, llive, lane_at(sbase(P.dt1, row0 * kD), bL));
         float4 gT[2], kT[2], qT[2], vr[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            gT[t] = ldg4(lane_at(sbase(P.hq, hq0 + kHqG + t * 256), bT));
-            kT[t] = ldg4(lane_at(sbase(P.hq, hq0 + kHqK + t * 256), bT));
-            qT[t] = ldg4(lane_at(sbase(P.hq, hq0 + kHqQ + t * 256), bT));
-            vr[t] = ldg4(lane_at(sbase(P.hq, hq0 + kHqV), bVr) + t * 16);
+        for (int t = 0; t < 2; ++t) {      // (only pieces that hold a token: the rest of the block is never written nor read)
+            const float* gp = lane_at(sbase(P.hq, hq0 + kHqG + t * 256), bT);
+            const float* kp = lane_at(sbase(P.hq, hq0 + kHqK + t * 256), bT);
+            const float* qp = lane_at(sbase(P.hq, hq0 + kHqQ + t * 256), bT);
+            const float* vp = lane_at(sbase(P.hq, hq0 + kHqV), bVr) + t * 16;
+            gT[t] = kT[t] = qT[t] = vr[t] = f4z();
+            if (rok[0]) {
+                gT[t] = ldg4(gp);
+                kT[t] = ldg4(kp);
+                qT[t] = ldg4(qp);
+            }
+            if (lr < T) vr[t] = ldg4(vp);
         }
-        const float4 pT = ldg4(lane_at(sbase(P.hq, hq0 + kHqP), bT));      // lane (j = lr, lq): p[4 lq + ii][j]
+        float4 pT = f4z();      // lane (j = lr, lq): p[4 lq + ii][j]
+        {
+            const float* pp = lane_at(sbase(P.hq, hq0 + kHqP), bT);
+            if (rok[0] && lr < T) pT = ldg4(pp);
+        }
         float av[2][4];      // gated attention output of the head (forward); rows >= T read row T - 1
 #pragma unroll
         for (int t = 0; t < 2; ++t)
