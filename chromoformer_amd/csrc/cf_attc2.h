@@ -101,6 +101,53 @@ __host__ __device__ inline size_t attc2_scratch_floats(int L) { return (size_t)k
 __host__ __device__ inline size_t attc2_persist_bytes(int L, int F, int AG) {
     return (size_t)(kD * 8 + AG * L * F + 8) * sizeof(float) + (size_t)AG * attc2_lpad(L);
 }
+// The persistent part filled AHEAD of the first attention over a group of regions (cf_trunk.h: at the start of the launch, under the
+// Embedding layer / the last layer's chain): Wlp and the masks through registers, the feature strips -- the long HBM stream -- by
+// 16-byte loads straight into LDS (global_load_lds_dwordx4: no registers in flight, nothing to wait for here).  The caller waits
+// (`s_waitcnt vmcnt(0)`, then a workgroup barrier) before the first attention, which then runs with STAGED = true.
+template <int AG>
+__device__ __forceinline__ void attc2_stage(const float* feats, const uint8_t* mask, long long mstride, const float* wlp, int L, int Lpad, int F,
+                                            const int n0, const int N, float* persist) {
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* wlp_s = persist;
+    float* feats_s = wlp_s + kD * 8;
+    uint8_t* mk_s = reinterpret_cast<uint8_t*>(feats_s + AG * L * F + 8);
+    const int nreg = min(AG, N - n0);
+    const float* fg = feats + (size_t)n0 * L * F;
+    const int nf = nreg * L * F;
+    constexpr int NFL = AG == 8 ? 12 : AG == 4 ? 6 : AG == 2 ? 3 : 2;
+    const bool f16b = ((L * F) & 3) == 0 && AG * L * F <= NFL * 4 * kAT && (reinterpret_cast<uintptr_t>(fg) & 15) == 0;
+    if (f16b) {
+        const int n4 = (AG * L * F) >> 2, last4 = (nf >> 2) - 1;      // strips of absent regions re-read the last one (never used)
+#pragma unroll
+        for (int u = 0; u < NFL; ++u) {
+            const int i = tid + u * kAT;
+            typedef __attribute__((address_space(3))) void* lds_void;
+            typedef const __attribute__((address_space(1))) void* glb_void;
+            if (i < n4)
+                __builtin_amdgcn_global_load_lds((glb_void)(fg + (size_t)min(i, last4) * 4), (lds_void)(feats_s + (size_t)(w * 64 + u * kAT) * 4), 16, 0, 0);
+        }
+    } else {
+        for (int i = tid; i < AG * L * F; i += kAT) feats_s[i] = i < nf ? ldg(fg + i) : 0.f;
+    }
+    if (tid < 8) feats_s[AG * L * F + tid] = 0.f;
+    static_assert(kD * 8 == 2 * kAT, "wlp staging assumes two entries per thread");
+    wlp_s[tid] = (tid & 7) < F ? ldg(wlp + (tid >> 3) * F + (tid & 7)) : 0.f;
+    wlp_s[tid + kAT] = (tid & 7) < F ? ldg(wlp + ((tid + kAT) >> 3) * F + (tid & 7)) : 0.f;
+    const uint8_t* mg = mask + (size_t)n0 * mstride;
+    const bool words = ((L | (int)mstride | (int)(reinterpret_cast<uintptr_t>(mask))) & 3) == 0;
+    if (words) {
+        const int LW = Lpad >> 2, lw = L >> 2;
+        uint32_t* mk_w = reinterpret_cast<uint32_t*>(mk_s);
+        for (int idx = tid; idx < AG * LW; idx += kAT) {
+            const int sreg = idx / LW, jw = idx - sreg * LW;
+            mk_w[idx] = (sreg < nreg && jw < lw) ? *(const CF_GLOBAL uint32_t*)(mg + (size_t)sreg * mstride + 4 * jw) : 0x01010101u;
+        }
+    } else {
+        for (int s = 0; s < AG; ++s)
+            for (int j = tid; j < Lpad; j += kAT) mk_s[s * Lpad + j] = (s < nreg && j < L) ? *(const CF_GLOBAL uint8_t*)(mg + (size_t)s * mstride + j) : (uint8_t)1;
+    }
+}
 template <bool BWD, int AG, bool STAGED = false>
 __device__ __forceinline__ void attc2_body(const Attc2Args& a, const int r, const int n0, const int N, float* scratch, float* persist,
                                            const int stamp_wg = -1) {

@@ -259,6 +259,13 @@ CF_PHASE void trunk_attc2_p(TrunkCtx c, int l, float* scratch, float* persist) {
     else trunk_attc_args(at, c, TF(wlp_p), ldc(&P->dxbar), ldc(&P->p), ldc(&P->du), ldc(&P->dqt), NB);
     attc2_body<BWD, kAGMax, STAGED>(at, 0, row0, NB, scratch, persist);
 }
+// features, masks and Wlp of the gene's S regions into the persistent LDS part, requested at the START of a launch: the feature
+// strips (90 KB per L = 400 workgroup, straight out of HBM) land under the phases in front of the first Pairwise attention, which
+// used to wait for them (tools/trunk_stamps.py: that attention took 54.6 K ticks against 44.1 K for the second layer's)
+CF_PHASE void trunk_stage_p(TrunkCtx c, float* persist) {
+    const TrunkResDev* R = c.R;
+    attc2_stage<kAGMax>(c.feats, c.mask, c.mstride, TF(wlp_p), TF(L), TF(Lpad), c.F, c.g * c.S, c.g * c.S + c.S, persist);
+}
 template <int DFF>
 CF_PHASE void trunk_post_p(TrunkCtx c, int l, int n_layers, float* smem) {
     const TrunkResDev* R = c.R;
@@ -311,6 +318,11 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
     __syncthreads();                                                                                      \
     if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime(); \
     launder(c, sm, persist)
+    {
+        TrunkCtx cs{R, a.cfeats[r], a.cmask[r], a.cmstride[r], (int)blockIdx.x, a.S, a.T, a.F, a.save, a.scale, a.rscale};
+        trunk_stage_p(cs, persist);
+        launder(c, sm, persist);
+    }
     // ---------------------------------------------------------------- Embedding layer: one row (the promoter's centre bin)
     trunk_x0_qchain_e(c, sm);
     CF_NEXT_PHASE;
@@ -323,8 +335,9 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
     c.mstride = a.cmstride[r];
     CF_NEXT_PHASE;
     trunk_qchain_p0(c, sm);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the feature strips of trunk_stage_p: every wave's share, then the barrier
     CF_NEXT_PHASE;
-    trunk_attc2_p<false, false>(c, 0, sm, persist);      // first layer: stages features, masks, Wlp
+    trunk_attc2_p<false, true>(c, 0, sm, persist);       // features, masks, Wlp are in LDS (trunk_stage_p)
     CF_NEXT_PHASE;
     trunk_post_p<DFF_P>(c, 0, PL, sm);
 #pragma unroll
@@ -510,10 +523,13 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     TrunkCtx c{R, a.cfeats[r], a.cmask[r], a.cmstride[r], (int)blockIdx.x, a.S, a.T, a.F, 1, a.scale, a.rscale};
     int stamp_i = 32;
     if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime();
+    trunk_stage_p(c, persist);
+    launder(c, sm, persist);
     // ---------------------------------------------------------------- Pairwise stack, last layer first
     trunk_post_bwd_p<DFF_P>(c, PL - 1, PL, sm);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the feature strips of trunk_stage_p
     CF_NEXT_PHASE;
-    trunk_attc2_p<true, false>(c, PL - 1, sm, persist);       // stages features, masks, Wlp
+    trunk_attc2_p<true, true>(c, PL - 1, sm, persist);        // features, masks, Wlp are in LDS (trunk_stage_p)
     CF_NEXT_PHASE;
     trunk_qchain_bwd(c, &c.R->P[PL - 1], c.g * c.S, c.g * c.S + c.S, sm);
 #pragma unroll

@@ -14,8 +14,8 @@ for _ in range(3):
     m.forward_backward(packed, torch.zeros(B, dtype=torch.long))
 torch.cuda.synchronize()
 t = m.debug_buffer("reg_tdbg").cpu().numpy().view(np.uint64).astype(np.int64)
-fwd = ["x0 + q chain E", "attention E", "post chain E (+lin_proj_p)", "q chain P0", "attention P0 (staging)", "post chain P0 (+q chain P1)", "attention P1", "post chain P1"]
-bwd = ["post chain P1", "attention P1 (staging)", "q chain P1", "post chain P0", "attention P0", "q chain P0", "join + lin_proj_p", "post chain E", "attention E",
+fwd = ["x0 + q chain E", "attention E", "post chain E (+lin_proj_p)", "q chain P0", "attention P0", "post chain P0 (+q chain P1)", "attention P1", "post chain P1"]
+bwd = ["post chain P1", "attention P1", "q chain P1", "post chain P0", "attention P0", "q chain P0", "join + lin_proj_p", "post chain E", "attention E",
        "q chain E", "7-mark partials"]
 for name, base, names in (("forward", 0, fwd), ("backward", 32, bwd)):
     d = np.diff(t[base: base + len(names) + 1])
