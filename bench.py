@@ -101,7 +101,7 @@ def train_loop_rate(model, lr, steps, store_genes, regime, dev):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return {"value": round(BSZ * done / el, 1), "unit": "genes/s", "ms_per_step": round(1e3 * el / done, 4), "steps": done,
-            "store_genes": store_genes, "host_calls_per_step": 3,
+            "store_genes": store_genes, "host_calls_per_step": 4 if trainer.fuse_opt else 3,
             "what": "chromoformer_amd.train.train_epoch over a resident synthetic split: cf_gather_batch + cf_record_step inside "
                     "the step graph, running metrics (train.py:205-232) on every 10-step window"}
 
@@ -305,7 +305,8 @@ def main():
             "config": {"workload": "default config (d_emb 128, i_max 8, binsizes 2000/500/100 -> L 20/80/400), bsz 64 genes per GPU, "
                                    "%s synthetic 7-mark signals, fwd+loss+bwd+allreduce+AdamW" % args.regime,
                        "parallelism": "dp%d" % world, "global_batch": BSZ * world, "hip_graph": bool(args.graph),
-                       "launches_per_step": sum(model.launch_counts())},
+                       "launches_per_step": sum(model.launch_counts()),
+                       "adamw": "in the epilogue of the gradient reductions (cf_reduce_opt_part)" if trainer.fuse_opt else "own launches"},
             "roofline": roof,
             "loss": round(float(trainer.last_loss()), 6),
         }

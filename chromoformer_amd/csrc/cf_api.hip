@@ -1936,6 +1936,32 @@ extern "C" int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, flo
     h->n_bwd += (int)(g_launches - launches0);
     return 0;
 }
+// The deferred gradients of ONE bucket and the AdamW update of the same bucket in the epilogues of the reduction tiles
+// (k_reduce_opt): single-GPU training, where nothing stands between a gradient element and its update.
+extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  long long step, int keep_grads, void* stream) {
+    if (!h || !h->grads || !h->params || !h->m || !h->v) return fail("cf_reduce_opt_part: params / grads / moments not bound");
+    if (B < 1 || B > h->cfg.max_batch) return fail("cf_reduce_opt_part: bad batch size %d", B);
+    if (bucket != CF_BUCKET_PE && bucket != CF_BUCKET_REG) return fail("cf_reduce_opt_part: exactly one bucket");
+    if (h->embed_dense) return fail("cf_reduce_opt_part: the all-rows Embedding path (embed n_layers > 1) writes its gradients outside the reduction tables; use cf_backward_reduce_part + cf_adamw_step_part");
+    AdamHyper hy;
+    if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const long long launches0 = g_launches;
+    if ((bucket & CF_BUCKET_PE) && !h->trunk) {
+        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
+        LAUNCH_CHECK("k_wgrad_lp");
+    }
+    const bool reg = bucket == CF_BUCKET_REG;
+    const int w0 = reg ? 0 : h->n_wg_r, wn = reg ? h->n_wg_r : h->n_wg - h->n_wg_r;
+    const int c0 = reg ? 0 : h->n_cs_r, cn = reg ? h->n_cs_r : h->n_cs - h->n_cs_r;
+    AdamFuse o{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0};
+    hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
+                       h->xcd_reduce, o);
+    LAUNCH_CHECK("k_reduce_opt");
+    h->n_bwd += (int)(g_launches - launches0);
+    return 0;
+}
 // Split form for callers that replay the optimiser launch from a hipGraph: cf_adamw_set (eager, once per step, before the
 // replay) writes the step's scalars to device memory, cf_adamw_step_dev (capturable) reads them.
 extern "C" int cf_adamw_set(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void* stream) {

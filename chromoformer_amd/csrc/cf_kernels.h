@@ -1640,6 +1640,25 @@ __global__ __launch_bounds__(256) void k_join_dgrad(JoinDgradArgs a) {
 // Deferred weight gradients: one launch, a table of 64x64 output tiles.
 //   C[n][k] = sum over segments, sum_m A[m][n] * Bm[m][k]      (dW = dY^T X)
 // =======================================================================================
+// AdamW folded into the epilogue of the gradient reductions (single GPU: nothing stands between a finished gradient element and
+// its update): every element of a bucket's gradients is produced exactly once, by one weight-gradient or column-sum tile, so the
+// tile that holds it in registers applies torch.optim.AdamW's update (adamw_range below, same operation order) to the
+// parameter / moment elements at the same offset of the flat buffers.  The 21 MB of gradients, the 116 + 32 MB optimiser
+// streams of two launches and their launch boundaries become part of the two reductions.
+struct AdamFuse {
+    float *p, *m, *v;        // flat parameter / moment buffers
+    const float* gbase;      // flat gradient buffer: a tile's output pointer minus this is the element's offset in all four
+    float decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps;
+    int keep_grads;          // also store the gradient (callers that read it back)
+};
+__device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, const AdamFuse& o) {
+#pragma clang fp contract(off)      // every product and sum rounded on its own, wherever this is inlined: the stand-alone and the fused form agree bit for bit
+    p = p * o.decay;
+    m = m + o.one_m_b1 * (g - m);
+    v = v * o.b2 + o.one_m_b2 * g * g;
+    const float denom = sqrtf(v) / o.bc2_sqrt + o.eps;
+    p = p - o.step_size * (m / denom);
+}
 struct WgSeg {
     const float* A;
     const float* B;
@@ -1670,7 +1689,8 @@ constexpr int kWgM = 32;            // reduction rows per LDS stage
 constexpr int kWgTk = CF_WG_TK;     // tile width along K (columns of dW): 64 or 128; tiles are 64 (n) x kWgTk (k)
 constexpr int kWgLdA = 64 + 16;     // A stage row stride: a half-wave's scalar reads (two rows x 16 columns) hit 32 distinct banks
 constexpr int kWgLdB = kWgTk + 4;
-__device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch) {
+template <bool OPT = false>
+__device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const AdamFuse* o = nullptr) {
     // 64 x kWgTk output tile; wave w owns rows n0+16w..+15 and all the tile's columns.  Both operands are staged through LDS
     // (every element of dY is used by one wave but every element of X by all four: reading X straight from L2 in each wave
     // made the kernel L1-bound at 37 % of the MFMA peak), one stage of 32 reduction rows (single-buffered: several workgroups
@@ -1743,8 +1763,24 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = t.n0 + w * 16 + lq * 4 + i;
-            if (row < t.Nn)
-                stg4(t.C + (size_t)row * t.ldc + kc + 64 * h, make_float4(acc[4 * h + 0][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i]));
+            if (row < t.Nn) {
+                float* cp = t.C + (size_t)row * t.ldc + kc + 64 * h;
+                const float4 g4 = make_float4(acc[4 * h + 0][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i]);
+                if (OPT) {
+                    const size_t off = (size_t)(cp - o->gbase);
+                    float4 pp = ldg4(o->p + off), mm = ldg4(o->m + off), vv = ldg4(o->v + off);
+                    adamw_elem(pp.x, g4.x, mm.x, vv.x, *o);
+                    adamw_elem(pp.y, g4.y, mm.y, vv.y, *o);
+                    adamw_elem(pp.z, g4.z, mm.z, vv.z, *o);
+                    adamw_elem(pp.w, g4.w, mm.w, vv.w, *o);
+                    stg4(o->p + off, pp);
+                    stg4(o->m + off, mm);
+                    stg4(o->v + off, vv);
+                    if (o->keep_grads) stg4(cp, g4);
+                } else {
+                    stg4(cp, g4);
+                }
+            }
         }
     }
 }
@@ -1816,7 +1852,8 @@ struct CsTile {
     int rows_per_gene, div;      // M = ceil(rows_per_gene * batch / div)
     const float* src2;           // optional elementwise factor (same leading dimension): LayerNorm weight gradients
 };
-__device__ __forceinline__ void colsum_tile(const CsTile& t, int batch) {
+template <bool OPT = false>
+__device__ __forceinline__ void colsum_tile(const CsTile& t, int batch, const AdamFuse* o = nullptr) {
     __shared__ float red[4][64];
     const int M = (t.rows_per_gene * batch + t.div - 1) / t.div;
     const int c = t.c0 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
@@ -1834,7 +1871,20 @@ __device__ __forceinline__ void colsum_tile(const CsTile& t, int batch) {
     }
     red[ph][threadIdx.x & 63] = s;
     __syncthreads();
-    if (ph == 0 && c < t.ncols) stg(t.out + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (ph == 0 && c < t.ncols) {
+        const float g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (OPT) {
+            const size_t off = (size_t)(t.out + c - o->gbase);
+            float pp = ldg(o->p + off), mm = ldg(o->m + off), vv = ldg(o->v + off);
+            adamw_elem(pp, g, mm, vv, *o);
+            stg(o->p + off, pp);
+            stg(o->m + off, mm);
+            stg(o->v + off, vv);
+            if (o->keep_grads) stg(t.out + c, g);
+        } else {
+            stg(t.out + c, g);
+        }
+    }
 }
 __global__ __launch_bounds__(256) void k_colsum(const CsTile* __restrict__ tiles, int batch) { colsum_tile(tiles[blockIdx.x], batch); }
 // Both reductions of a gradient bucket in ONE launch: workgroups [0, n_wg) take weight-gradient tiles, the rest column-sum
@@ -1847,6 +1897,17 @@ __global__ __launch_bounds__(256) void k_reduce(const WgTile* __restrict__ wg, i
         if (t < n_wg) wgrad_tile(wg[t], batch);
     } else {
         colsum_tile(cs[blockIdx.x - nb], batch);
+    }
+}
+
+// The reductions of a bucket with the AdamW update of the same bucket in their epilogues (AdamFuse above)
+__global__ __launch_bounds__(256) void k_reduce_opt(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int batch, int xcd, AdamFuse o) {
+    const int nb = xcd_grid(n_wg);
+    if ((int)blockIdx.x < nb) {
+        const int t = xcd_tile(blockIdx.x, n_wg, xcd);
+        if (t < n_wg) wgrad_tile<true>(wg[t], batch, &o);
+    } else {
+        colsum_tile<true>(cs[blockIdx.x - nb], batch, &o);
     }
 }
 
@@ -1866,14 +1927,9 @@ __device__ __forceinline__ void adamw_range(float* __restrict__ p, const float* 
         const float* ga = reinterpret_cast<const float*>(&gg);
         float* ma = reinterpret_cast<float*>(&mm);
         float* va = reinterpret_cast<float*>(&vv);
+        const AdamFuse o{nullptr, nullptr, nullptr, nullptr, decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps, 0};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            pa[k] = pa[k] * decay;
-            ma[k] = ma[k] + one_m_b1 * (ga[k] - ma[k]);
-            va[k] = va[k] * b2 + one_m_b2 * ga[k] * ga[k];
-            const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
-            pa[k] = pa[k] - step_size * (ma[k] / denom);
-        }
+        for (int k = 0; k < 4; ++k) adamw_elem(pa[k], ga[k], ma[k], va[k], o);      // (one definition of the update for both forms)
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
@@ -1918,30 +1974,8 @@ __global__ void k_adamw_set(AdamHyper* dst, AdamHyper v) { *dst = v; }
 __global__ __launch_bounds__(256) void k_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n4, const AdamHyper* __restrict__ hp) {
     const AdamHyper h = *hp;
-    const float decay = h.decay, one_m_b1 = h.one_m_b1, b2 = h.b2, one_m_b2 = h.one_m_b2, step_size = h.step_size, bc2_sqrt = h.bc2_sqrt,
-                eps = h.eps;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
-        float* pa = reinterpret_cast<float*>(&pp);
-        const float* ga = reinterpret_cast<const float*>(&gg);
-        float* ma = reinterpret_cast<float*>(&mm);
-        float* va = reinterpret_cast<float*>(&vv);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            pa[k] = pa[k] * decay;
-            ma[k] = ma[k] + one_m_b1 * (ga[k] - ma[k]);
-            va[k] = va[k] * b2 + one_m_b2 * ga[k] * ga[k];
-            const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
-            pa[k] = pa[k] - step_size * (ma[k] / denom);
-        }
-        reinterpret_cast<float4*>(p)[i] = pp;
-        reinterpret_cast<float4*>(m)[i] = mm;
-        reinterpret_cast<float4*>(v)[i] = vv;
-    }
+    adamw_range(p, g, m, v, n4, h.decay, h.one_m_b1, h.b2, h.one_m_b2, h.step_size, h.bc2_sqrt, h.eps, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                (long long)gridDim.x * blockDim.x);
 }
 
 // =======================================================================================

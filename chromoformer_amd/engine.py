@@ -179,7 +179,7 @@ class Trainer:
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
-                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None):
+                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -226,6 +226,16 @@ class Trainer:
             import os
             overlap_reduce = os.environ.get("CF_OVERLAP_REDUCE", "0") != "0"
         self.overlap_reduce = bool(overlap_reduce) and self.merge_opt
+        # Single GPU: AdamW in the EPILOGUE of the two gradient reductions (cf_reduce_opt_part): the tile that finishes a gradient
+        # element updates the parameter and its moments -- no optimiser launches, no second pass over gradients and state.  The step
+        # is then [graph: gather, forward, head, Regulation backward] -> reduction + AdamW of the Regulation + head bucket -> Pairwise +
+        # Embedding backward -> reduction + AdamW of their bucket.  The flat gradient buffer is only written with keep_grads=True.
+        # Bit-identical parameters and moments (tests/test_engine_gpu.py); CF_FUSE_OPT=0 restores the merged schedule above.
+        if fuse_opt is None:
+            import os
+            fuse_opt = os.environ.get("CF_FUSE_OPT", "1") != "0"
+        self.fuse_opt = (bool(fuse_opt) and self.merge_opt and not self.overlap_reduce and model._kws[0].get("n_layers", 1) == 1)
+        self.keep_grads = bool(keep_grads)
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -332,6 +342,8 @@ class Trainer:
                 slot.feed.rewind()                     # the validation pass consumed a batch: rewind (no parameter was updated)
             torch.cuda.synchronize()
             first = self._seq_early if self.dp else (self._seq_main if self.merge_opt else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph)))
+            if self.fuse_opt:
+                first = lambda s_, t_: self._seq_early(s_, t_, reduce=False)
             slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
         if feed is not None:
             feed.taken += 1
@@ -339,7 +351,18 @@ class Trainer:
         if oig:      # this step's AdamW scalars go to device memory before anything is replayed
             m._step += 1
             _lib.check(L.cf_adamw_set(m._handle, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step, st), "cf_adamw_set")
-        if not self.dp and self.merge_opt:
+        if self.fuse_opt:
+            if self.use_graph:
+                self._launch(slot.graph["first"], st)
+            else:
+                self._seq_early(slot, st, reduce=False)
+            m._step += 1
+            hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
+            kg = 1 if self.keep_grads else 0
+            _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG, *hp, kg, st), "cf_reduce_opt_part")
+            self._part(slot, st, 4)
+            _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")
+        elif not self.dp and self.merge_opt:
             if self.use_graph:
                 self._launch(slot.graph["first"], st)
             else:

@@ -210,6 +210,14 @@ const char* cf_debug_names(cf_handle* h);
  * separate calls, bit for bit.  Not capturable (the optimiser's scalars are launch arguments). */
 int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, float lr, float beta1, float beta2, float eps,
                          float weight_decay, long long step, int adam_buckets, void* stream);
+/* cf_backward_reduce_part(bucket) with cf_adamw_step_part(bucket) folded into it: the tile that finishes a gradient element applies
+ * torch.optim.AdamW's update (train.py:157, 194) to the parameter and moment elements at the same offset -- one launch, no second
+ * pass over gradients and optimiser state.  For single-GPU training (under data parallelism the all-reduce stands between the two).
+ * bucket: exactly one; keep_grads != 0 also stores the gradients (otherwise the flat gradient buffer keeps what it held).  Same
+ * parameters / moments as the two separate calls, bit for bit.  Fails when the all-rows Embedding path is active (embed n_layers > 1:
+ * its gradients are written outside the reduction tables).  Not capturable (the optimiser's scalars are launch arguments). */
+int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       long long step, int keep_grads, void* stream);
 /* Number of kernels the LAST forward / backward (chain pieces + bucket reductions) / optimiser step launched, counted at the
  * launch sites (zero before the first call; calls replayed from a graph do not pass the host code and leave the counts
  * of the capture pass). */

@@ -25,6 +25,9 @@ def _run(steps=3, **kw):
             losses.append(loss.clone())
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    sd["<exp_avg>"], sd["<exp_avg_sq>"] = model._mflat.cpu().clone(), model._vflat.cpu().clone()      # the optimiser state as well
+    if kw.get("keep_grads") or not trainer.fuse_opt:
+        sd["<grads>"] = model._gflat.cpu().clone()
     return sd, [float(x) for x in losses]
 
 
@@ -44,11 +47,13 @@ def test_round3_schedules_and_switches_are_bit_identical():
     the side stream, and the library switches that only move work between launches -- all the same arithmetic in the same order."""
     import os
     ref, ref_loss = _run(use_graph=False, merge_opt=False)
-    for kw in (dict(use_graph=False, merge_opt=True), dict(use_graph=True, merge_opt=True), dict(use_graph=True, merge_opt=True, overlap_reduce=True),
-               dict(use_graph=False, merge_opt=True, overlap_reduce=True)):
+    for kw in (dict(use_graph=False, merge_opt=True, fuse_opt=False), dict(use_graph=True, merge_opt=True, fuse_opt=False),
+               dict(use_graph=True, merge_opt=True, overlap_reduce=True), dict(use_graph=False, merge_opt=True, overlap_reduce=True),
+               # AdamW in the epilogue of the gradient reductions (the default single-GPU step), with and without the gradient stores
+               dict(use_graph=False, fuse_opt=True), dict(use_graph=True, fuse_opt=True), dict(use_graph=True, fuse_opt=True, keep_grads=True)):
         got, loss = _run(**kw)
         assert loss == ref_loss, kw
-        for k in ref:
+        for k in got:
             assert torch.equal(ref[k], got[k]), (kw, k)
     for env in ({"CF_DEFER_RETILE": "0"}, {"CF_XCD_REDUCE": "1"}):      # read when the model is constructed
         old = {k: os.environ.get(k) for k in env}
@@ -62,7 +67,7 @@ def test_round3_schedules_and_switches_are_bit_identical():
                 else:
                     os.environ[k] = v
         assert loss == ref_loss, env
-        for k in ref:
+        for k in got:
             assert torch.equal(ref[k], got[k]), (env, k)
 
 
