@@ -1942,7 +1942,7 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
                                   long long step, int keep_grads, void* stream) {
     if (!h || !h->grads || !h->params || !h->m || !h->v) return fail("cf_reduce_opt_part: params / grads / moments not bound");
     if (B < 1 || B > h->cfg.max_batch) return fail("cf_reduce_opt_part: bad batch size %d", B);
-    if (bucket != CF_BUCKET_PE && bucket != CF_BUCKET_REG) return fail("cf_reduce_opt_part: exactly one bucket");
+    if (!bucket || (bucket & ~(CF_BUCKET_REG | CF_BUCKET_PE))) return fail("cf_reduce_opt_part: bad bucket mask %d", bucket);
     if (h->embed_dense) return fail("cf_reduce_opt_part: the all-rows Embedding path (embed n_layers > 1) writes its gradients outside the reduction tables; use cf_backward_reduce_part + cf_adamw_step_part");
     AdamHyper hy;
     if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy)) return -1;
@@ -1952,9 +1952,10 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
         hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
         LAUNCH_CHECK("k_wgrad_lp");
     }
-    const bool reg = bucket == CF_BUCKET_REG;
-    const int w0 = reg ? 0 : h->n_wg_r, wn = reg ? h->n_wg_r : h->n_wg - h->n_wg_r;
-    const int c0 = reg ? 0 : h->n_cs_r, cn = reg ? h->n_cs_r : h->n_cs - h->n_cs_r;
+    // the tables hold the Regulation + head bucket's tiles first: one bucket is a prefix / suffix, both are everything
+    const bool reg = (bucket & CF_BUCKET_REG) != 0, pe = (bucket & CF_BUCKET_PE) != 0;
+    const int w0 = reg ? 0 : h->n_wg_r, wn = (reg ? h->n_wg_r : 0) + (pe ? h->n_wg - h->n_wg_r : 0);
+    const int c0 = reg ? 0 : h->n_cs_r, cn = (reg ? h->n_cs_r : 0) + (pe ? h->n_cs - h->n_cs_r : 0);
     AdamFuse o{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0};
     hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
                        h->xcd_reduce, o);

@@ -1685,7 +1685,10 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col,
 #ifndef CF_WG_TK
 #define CF_WG_TK 64      // 128 measured: 91.6 vs 78.1 us per step (half as many workgroups: the barriers of a stage are no longer hidden)
 #endif
-constexpr int kWgM = 32;            // reduction rows per LDS stage
+#ifndef CF_WG_M
+#define CF_WG_M 32
+#endif
+constexpr int kWgM = CF_WG_M;       // reduction rows per LDS stage
 constexpr int kWgTk = CF_WG_TK;     // tile width along K (columns of dW): 64 or 128; tiles are 64 (n) x kWgTk (k)
 constexpr int kWgLdA = 64 + 16;     // A stage row stride: a half-wave's scalar reads (two rows x 16 columns) hit 32 distinct banks
 constexpr int kWgLdB = kWgTk + 4;

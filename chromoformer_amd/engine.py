@@ -179,7 +179,7 @@ class Trainer:
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
-                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False):
+                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -236,6 +236,13 @@ class Trainer:
             fuse_opt = os.environ.get("CF_FUSE_OPT", "1") != "0"
         self.fuse_opt = (bool(fuse_opt) and self.merge_opt and not self.overlap_reduce and model._kws[0].get("n_layers", 1) == 1)
         self.keep_grads = bool(keep_grads)
+        # ... and both buckets' tiles in ONE launch behind the whole backward pass (the Embedding + Pairwise bucket's ~300 latency-bound
+        # tiles fill the gaps of the Regulation bucket's 1,008): [graph: gather, forward, head, both backward launches] -> reduction +
+        # AdamW.  7 launches, 2 host calls per step; 0.600 -> 0.590 ms.  fuse_one=False / CF_FUSE_ONE=0: one launch per bucket.
+        if fuse_one is None:
+            import os
+            fuse_one = os.environ.get("CF_FUSE_ONE", "1") != "0"
+        self.fuse_one = bool(fuse_one)
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -342,7 +349,9 @@ class Trainer:
                 slot.feed.rewind()                     # the validation pass consumed a batch: rewind (no parameter was updated)
             torch.cuda.synchronize()
             first = self._seq_early if self.dp else (self._seq_main if self.merge_opt else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph)))
-            if self.fuse_opt:
+            if self.fuse_opt and self.fuse_one:
+                first = lambda s_, t_: (self._seq_early(s_, t_, reduce=False), self._part(s_, t_, 4))
+            elif self.fuse_opt:
                 first = lambda s_, t_: self._seq_early(s_, t_, reduce=False)
             slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
         if feed is not None:
@@ -359,9 +368,14 @@ class Trainer:
             m._step += 1
             hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
             kg = 1 if self.keep_grads else 0
-            _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG, *hp, kg, st), "cf_reduce_opt_part")
-            self._part(slot, st, 4)
-            _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")
+            if self.fuse_one:       # both buckets' tiles in ONE launch behind the whole backward pass
+                if not self.use_graph:
+                    self._part(slot, st, 4)
+                _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG | _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")
+            else:
+                _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG, *hp, kg, st), "cf_reduce_opt_part")
+                self._part(slot, st, 4)
+                _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")
         elif not self.dp and self.merge_opt:
             if self.use_graph:
                 self._launch(slot.graph["first"], st)

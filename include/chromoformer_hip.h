@@ -213,7 +213,8 @@ int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, float lr, floa
 /* cf_backward_reduce_part(bucket) with cf_adamw_step_part(bucket) folded into it: the tile that finishes a gradient element applies
  * torch.optim.AdamW's update (train.py:157, 194) to the parameter and moment elements at the same offset -- one launch, no second
  * pass over gradients and optimiser state.  For single-GPU training (under data parallelism the all-reduce stands between the two).
- * bucket: exactly one; keep_grads != 0 also stores the gradients (otherwise the flat gradient buffer keeps what it held).  Same
+ * bucket: one bucket or both (CF_BUCKET_REG | CF_BUCKET_PE: every tile of the step in one launch, behind the whole backward pass);
+ * keep_grads != 0 also stores the gradients (otherwise the flat gradient buffer keeps what it held).  Same
  * parameters / moments as the two separate calls, bit for bit.  Fails when the all-rows Embedding path is active (embed n_layers > 1:
  * its gradients are written outside the reduction tables).  Not capturable (the optimiser's scalars are launch arguments). */
 int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -50,7 +50,8 @@ def test_round3_schedules_and_switches_are_bit_identical():
     for kw in (dict(use_graph=False, merge_opt=True, fuse_opt=False), dict(use_graph=True, merge_opt=True, fuse_opt=False),
                dict(use_graph=True, merge_opt=True, overlap_reduce=True), dict(use_graph=False, merge_opt=True, overlap_reduce=True),
                # AdamW in the epilogue of the gradient reductions (the default single-GPU step), with and without the gradient stores
-               dict(use_graph=False, fuse_opt=True), dict(use_graph=True, fuse_opt=True), dict(use_graph=True, fuse_opt=True, keep_grads=True)):
+               dict(use_graph=False, fuse_opt=True), dict(use_graph=True, fuse_opt=True), dict(use_graph=True, fuse_opt=True, keep_grads=True),
+               dict(use_graph=True, fuse_opt=True, fuse_one=False), dict(use_graph=False, fuse_opt=True, fuse_one=False, keep_grads=True)):
         got, loss = _run(**kw)
         assert loss == ref_loss, kw
         for k in got:
