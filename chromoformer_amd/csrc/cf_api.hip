@@ -229,6 +229,14 @@ struct cf_handle {
     size_t trunk_smem_bytes = 0;
     bool head_deferred = false;                // cf_forward(save = 2) left the head to cf_backward_part (k_head_train)
     float* deferred_logits_user = nullptr;
+    // riders of the next k_trunk_bwd launch (cf_rider_arm): leading Regulation weight-gradient tiles with AdamW in their epilogues
+    struct Rider {
+        bool armed = false;
+        int max_tiles = 0, done = 0;           // done: tiles the last trunk launch took (the reduction call that follows skips them)
+        long long step = -1;
+        AdamFuse o;
+    } rider;
+    int n_wg_uniform = 0;                      // leading tiles of the table that are one segment of the same length (the Regulation layers')
     int xcd_reduce = 0;                        // XCD-aware order of the weight-gradient tiles (measured slower: cf_kernels.h, xcd_tile)
     int defer_retile = 1;                      // Regulation + head units ride in the Embedding layer's chain launch (CF_DEFER_RETILE=0: all in the prologue)
     // workspace
@@ -662,6 +670,10 @@ static int build_tables(cf_handle* h) {
     HIP_TRY(hipMemcpy(h->lp_jobs, lpj.data(), lpj.size() * sizeof(LpJob), hipMemcpyHostToDevice));
     h->n_wg_r = (int)wgR.size();
     h->n_cs_r = (int)csR.size();
+    h->n_wg_uniform = 0;
+    while (h->n_wg_uniform < (int)wgR.size() && wgR[h->n_wg_uniform].nseg == 1 &&
+           wgR[h->n_wg_uniform].seg[0].rows_per_gene == wgR[0].seg[0].rows_per_gene)
+        ++h->n_wg_uniform;
     wg.insert(wg.begin(), wgR.begin(), wgR.end());      // table layout: [Regulation + head | Embedding + Pairwise]
     cs.insert(cs.begin(), csR.begin(), csR.end());
     h->wg_flops_per_gene = 0.0;
@@ -1532,8 +1544,22 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         TrunkArgs ta;
         trunk_args(h, bt, ta, 1);
         ta.lp_jobs = h->lp_jobs;
+        ta.rd_tiles = nullptr;
+        ta.rd_n = 0;
+        ta.rd_batch = B;
+        memset(&ta.rd_opt, 0, sizeof ta.rd_opt);
+        if (h->rider.armed) {      // (cf_rider_arm) a multiple of the team count, all of the same length
+            if (h->capturing) return fail("cf_backward_part: armed riders carry this step's AdamW scalars as launch arguments and cannot be captured");
+            h->rider.armed = false;
+            const int teams = 2 * B;
+            ta.rd_n = std::min(h->rider.max_tiles, h->n_wg_uniform) / teams * teams;
+            ta.rd_tiles = h->wg_tiles;
+            ta.rd_opt = h->rider.o;
+            h->rider.done = ta.rd_n;
+        }
         void* kargs[] = {&ta};
-        HIP_TRY(hipLaunchKernel(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres), dim3(kAT), kargs, h->trunk_smem_bytes, st));
+        HIP_TRY(hipLaunchKernel(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + (ta.rd_n > 0 ? 1 : 0)), dim3(kAT), kargs,
+                                h->trunk_smem_bytes, st));
         LAUNCH_CHECK("k_trunk_bwd");
         return 0;
     }
@@ -1688,6 +1714,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
 constexpr bool kMergeReduce = CF_MERGE_REDUCE;
 // deferred weight / bias gradients: one launch per bucket over the two tile tables
 static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUCKET_REG | CF_BUCKET_PE) {
+    if (h->rider.done) return fail("gradient reduction: the riders of step %lld have updated part of the Regulation + head bucket; finish the step with cf_reduce_opt_part", h->rider.step);
     if ((buckets & CF_BUCKET_PE) && !h->trunk) {      // (the fused trunk backward writes these partials itself)
         hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
         LAUNCH_CHECK("k_wgrad_lp");
@@ -1954,13 +1981,36 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
     }
     // the tables hold the Regulation + head bucket's tiles first: one bucket is a prefix / suffix, both are everything
     const bool reg = (bucket & CF_BUCKET_REG) != 0, pe = (bucket & CF_BUCKET_PE) != 0;
-    const int w0 = reg ? 0 : h->n_wg_r, wn = (reg ? h->n_wg_r : 0) + (pe ? h->n_wg - h->n_wg_r : 0);
+    int w0 = reg ? 0 : h->n_wg_r, wn = (reg ? h->n_wg_r : 0) + (pe ? h->n_wg - h->n_wg_r : 0);
     const int c0 = reg ? 0 : h->n_cs_r, cn = (reg ? h->n_cs_r : 0) + (pe ? h->n_cs - h->n_cs_r : 0);
+    if (h->rider.done) {       // tiles the riders of the last k_trunk_bwd launch have reduced and stepped already
+        if (!reg || h->rider.step != step) return fail("cf_reduce_opt_part: riders were armed for step %lld of the Regulation + head bucket; this call must finish that step", h->rider.step);
+        w0 += h->rider.done;
+        wn -= h->rider.done;
+        h->rider.done = 0;
+    }
     AdamFuse o{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0};
     hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
                        h->xcd_reduce, o);
     LAUNCH_CHECK("k_reduce_opt");
     h->n_bwd += (int)(g_launches - launches0);
+    return 0;
+}
+// Arms the riders of the NEXT cf_backward_part(parts & 4) call (k_trunk_bwd; cf_trunk.h): up to max_tiles leading weight-gradient
+// tiles of the Regulation + head bucket are reduced, with this step's AdamW update in their epilogues, on the CUs the trunk leaves
+// idle.  The cf_reduce_opt_part call of the same step (a mask that contains CF_BUCKET_REG) then skips them.
+extern "C" int cf_rider_arm(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, int keep_grads,
+                            int max_tiles) {
+    if (!h || !h->grads || !h->params || !h->m || !h->v) return fail("cf_rider_arm: params / grads / moments not bound");
+    if (!h->trunk) return fail("cf_rider_arm: the fused trunk kernels are not in use for this configuration");
+    if (h->embed_dense) return fail("cf_rider_arm: not with the all-rows Embedding path");
+    if (h->rider.done) return fail("cf_rider_arm: the riders of step %lld have not been followed by cf_reduce_opt_part", h->rider.step);
+    AdamHyper hy;
+    if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy)) return -1;
+    h->rider.o = AdamFuse{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0};
+    h->rider.max_tiles = std::max(0, max_tiles);
+    h->rider.step = step;
+    h->rider.armed = max_tiles > 0;      // (max_tiles <= 0: disarms; the checks above tell a caller whether riders are available at all)
     return 0;
 }
 // Split form for callers that replay the optimiser launch from a hipGraph: cf_adamw_set (eager, once per step, before the

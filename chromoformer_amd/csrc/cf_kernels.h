@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cf {
 
@@ -1640,6 +1641,13 @@ __global__ __launch_bounds__(256) void k_join_dgrad(JoinDgradArgs a) {
 // Deferred weight gradients: one launch, a table of 64x64 output tiles.
 //   C[n][k] = sum over segments, sum_m A[m][n] * Bm[m][k]      (dW = dY^T X)
 // =======================================================================================
+template <int N, class F>
+__device__ __forceinline__ void static_for(F f) {      // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 // AdamW folded into the epilogue of the gradient reductions (single GPU: nothing stands between a finished gradient element and
 // its update): every element of a bucket's gradients is produced exactly once, by one weight-gradient or column-sum tile, so the
 // tile that holds it in registers applies torch.optim.AdamW's update (adamw_range below, same operation order) to the
@@ -1692,8 +1700,15 @@ constexpr int kWgM = CF_WG_M;       // reduction rows per LDS stage
 constexpr int kWgTk = CF_WG_TK;     // tile width along K (columns of dW): 64 or 128; tiles are 64 (n) x kWgTk (k)
 constexpr int kWgLdA = 64 + 16;     // A stage row stride: a half-wave's scalar reads (two rows x 16 columns) hit 32 distinct banks
 constexpr int kWgLdB = kWgTk + 4;
-template <bool OPT = false>
-__device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const AdamFuse* o = nullptr) {
+// As / Bs: the LDS stage of the 256 threads that work on this tile, tid: their index (the tile of a 256-thread workgroup, or one of
+// the two teams of a 512-thread rider workgroup of k_trunk_bwd, which walk equally long tiles in lock step: the barriers are the
+// workgroup's)
+// D: stages whose global loads are in flight (a register ring).  1 where several workgroups share a CU and hide each other's round
+// trips; the riders of k_trunk_bwd are alone on their CU (two teams, cold operands: a stage took 6 K cycles for 1 K of MFMA issue
+// with D = 1) and run with D = 4.
+template <bool OPT, int D = 1>
+__device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, const AdamFuse* o, float (*As)[kWgM * kWgLdA], float (*Bs)[kWgM * kWgLdB],
+                                                const int tid) {
     // 64 x kWgTk output tile; wave w owns rows n0+16w..+15 and all the tile's columns.  Both operands are staged through LDS
     // (every element of dY is used by one wave but every element of X by all four: reading X straight from L2 in each wave
     // made the kernel L1-bound at 37 % of the MFMA peak), one stage of 32 reduction rows (single-buffered: several workgroups
@@ -1702,9 +1717,7 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const Ada
     // k0 + 64 h + 4 r + c.  A 64 x 128 tile moves (64 + 128) x 32 floats per 2 x 64 x 128 x 32 flops: 21 flop per byte out of
     // L2 against 16 for a 64 x 64 tile.
     constexpr int NH = kWgTk / 64;
-    __shared__ __attribute__((aligned(16))) float As[1][kWgM * kWgLdA];
-    __shared__ __attribute__((aligned(16))) float Bs[1][kWgM * kWgLdB];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int kc = t.k0 + 4 * lr;
     f32x4 acc[4 * NH];
     zero_acc(acc);
@@ -1714,36 +1727,42 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const Ada
         const int M = sg.rows_per_gene * batch, nst = (M + kWgM - 1) / kWgM;
         const bool va = ((sg.lda | t.n0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.A) & 15) == 0;
         const bool vb = ((sg.ldb | t.k0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.B) & 15) == 0;
-        float4 ra[kWgM / 16], rb[kWgM / 16][NH];
-        auto fetch = [&](int st) {
+        float4 ra[D][kWgM / 16], rb[D][kWgM / 16][NH];
+        auto fetch = [&](int st, auto slot_c) {
+            constexpr int sl = decltype(slot_c)::value;
 #pragma unroll
             for (int p = 0; p < kWgM / 16; ++p) {
                 const int m = st * kWgM + sm + 16 * p;
                 if (m < M) {
-                    ra[p] = wg_load4(sg.A + (size_t)m * sg.lda, t.n0 + sc, t.Nn, va);
+                    ra[sl][p] = wg_load4(sg.A + (size_t)m * sg.lda, t.n0 + sc, t.Nn, va);
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) rb[p][h] = wg_load4(sg.B + (size_t)m * sg.ldb, t.k0 + 64 * h + sc, t.Kk, vb);
+                    for (int h = 0; h < NH; ++h) rb[sl][p][h] = wg_load4(sg.B + (size_t)m * sg.ldb, t.k0 + 64 * h + sc, t.Kk, vb);
                 } else {
-                    ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ra[sl][p] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) rb[p][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int h = 0; h < NH; ++h) rb[sl][p][h] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         };
-        auto put = [&](int buf) {
+        auto put = [&](auto slot_c) {
+            constexpr int sl = decltype(slot_c)::value;
 #pragma unroll
             for (int p = 0; p < kWgM / 16; ++p) {
-                *reinterpret_cast<float4*>(&As[buf][(sm + 16 * p) * kWgLdA + sc]) = ra[p];
+                *reinterpret_cast<float4*>(&As[0][(sm + 16 * p) * kWgLdA + sc]) = ra[sl][p];
 #pragma unroll
-                for (int h = 0; h < NH; ++h) *reinterpret_cast<float4*>(&Bs[buf][(sm + 16 * p) * kWgLdB + 64 * h + sc]) = rb[p][h];
+                for (int h = 0; h < NH; ++h) *reinterpret_cast<float4*>(&Bs[0][(sm + 16 * p) * kWgLdB + 64 * h + sc]) = rb[sl][p][h];
             }
         };
-        fetch(0);
-        for (int st = 0; st < nst; ++st) {
+        static_for<D>([&](auto u) {
+            if (decltype(u)::value < nst) fetch(decltype(u)::value, u);
+        });
+        for (int st0 = 0; st0 < nst; st0 += D) static_for<D>([&](auto u) {
+            const int st = st0 + decltype(u)::value;
+            if (st >= nst) return;
             __syncthreads();                                   // the previous stage has been consumed
-            put(0);
+            put(u);
             __syncthreads();
-            if (st + 1 < nst) fetch(st + 1);                   // in flight during this stage's multiply
+            if (st + D < nst) fetch(st + D, u);                // in flight during the next D stages' multiplies
             const float* ap = &As[0][lq * kWgLdA + 16 * w + lr];
             const float* bp = &Bs[0][lq * kWgLdB + 4 * lr];
 #pragma unroll
@@ -1758,7 +1777,7 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const Ada
                     acc[4 * h + 3] = mfma4(av, bv.w, acc[4 * h + 3]);
                 }
             }
-        }
+        });
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -1786,6 +1805,12 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const Ada
             }
         }
     }
+}
+template <bool OPT = false>
+__device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const AdamFuse* o = nullptr) {
+    __shared__ __attribute__((aligned(16))) float As[1][kWgM * kWgLdA];
+    __shared__ __attribute__((aligned(16))) float Bs[1][kWgM * kWgLdB];
+    wgrad_tile_impl<OPT>(t, batch, o, As, Bs, threadIdx.x);
 }
 
 // XCD-aware tile order.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with a private L2), and the tiles of one

@@ -60,6 +60,11 @@ struct TrunkArgs {
     float* rt_tiledT;
     int rt_n;
     const LpJob* lp_jobs;              // backward: the 7-mark projection jobs, [2 r] = Embedding, [2 r + 1] = Pairwise of resolution r
+    // backward, single-GPU training: the first rd_n weight-gradient tiles of the Regulation bucket (all equally long), with AdamW in
+    // their epilogues, walked by an extra row of workgroups on the CUs the trunk leaves idle (k_trunk_bwd; cf_rider_arm)
+    const WgTile* rd_tiles;
+    int rd_n, rd_batch;
+    AdamFuse rd_opt;
     unsigned long long* tdbg;          // optional shader-clock stamps of workgroup (gene 0, longest resolution), one per phase boundary
 };
 
@@ -515,6 +520,19 @@ CF_PHASE void trunk_lp(const LpJob* jobs, int r, int g, int batch, float* smem) 
 template <int DFF_E, int DFF_P, int PL>
 __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.y >= a.n_res) {
+        // Riders: the trunk's 192 workgroups fill one CU each (141 KB of LDS, 2 x 256 registers per SIMD lane) for ~130 us of
+        // latency chains; the other 64 CUs take Regulation weight-gradient tiles meanwhile -- those depend on the Regulation
+        // backward only, and neither the trunk nor anything before the next step's Regulation forward reads what their epilogues
+        // update.  Two 256-thread teams per workgroup, each with its own LDS stage, tile t to team t mod (2 gridDim.x): the host
+        // hands over a multiple of the team count of EQUALLY long tiles, so the teams of a workgroup meet at the same barriers.
+        float (*As)[kWgM * kWgLdA] = reinterpret_cast<float (*)[kWgM * kWgLdA]>(smem + (threadIdx.x >> 8) * (kWgM * kWgLdA + kWgM * kWgLdB));
+        float (*Bs)[kWgM * kWgLdB] = reinterpret_cast<float (*)[kWgM * kWgLdB]>(&As[0][0] + kWgM * kWgLdA);
+        const int n_teams = 2 * gridDim.x;
+        for (int t = 2 * blockIdx.x + (threadIdx.x >> 8); t < a.rd_n; t += n_teams)
+            wgrad_tile_impl<true, 4>(a.rd_tiles[t], a.rd_batch, &a.rd_opt, As, Bs, threadIdx.x & 255);
+        return;
+    }
     const int r = a.n_res - 1 - (int)blockIdx.y;
     const TrunkResDev* R = a.tab + r;
     constexpr int DFF_MAX = DFF_E > DFF_P ? DFF_E : DFF_P;

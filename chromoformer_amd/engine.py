@@ -179,7 +179,7 @@ class Trainer:
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
-                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None):
+                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None, rider_tiles=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -243,6 +243,13 @@ class Trainer:
             import os
             fuse_one = os.environ.get("CF_FUSE_ONE", "1") != "0"
         self.fuse_one = bool(fuse_one)
+        # ... and part of the Regulation bucket's tiles as riders of the trunk's backward launch (cf_rider_arm): rider_tiles of the 1,008
+        if rider_tiles is None:
+            import os
+            rider_tiles = int(os.environ.get("CF_RIDER_TILES", "256"))
+        self.rider_tiles = int(rider_tiles) if self.fuse_opt and self.fuse_one else 0
+        if self.rider_tiles > 0 and self._L.cf_rider_arm(model._handle, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, 0, 0) != 0:
+            self.rider_tiles = 0          # (configurations without the fused trunk kernels)
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -349,7 +356,7 @@ class Trainer:
                 slot.feed.rewind()                     # the validation pass consumed a batch: rewind (no parameter was updated)
             torch.cuda.synchronize()
             first = self._seq_early if self.dp else (self._seq_main if self.merge_opt else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph)))
-            if self.fuse_opt and self.fuse_one:
+            if self.fuse_opt and self.fuse_one and self.rider_tiles == 0:
                 first = lambda s_, t_: (self._seq_early(s_, t_, reduce=False), self._part(s_, t_, 4))
             elif self.fuse_opt:
                 first = lambda s_, t_: self._seq_early(s_, t_, reduce=False)
@@ -368,7 +375,12 @@ class Trainer:
             m._step += 1
             hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
             kg = 1 if self.keep_grads else 0
-            if self.fuse_one:       # both buckets' tiles in ONE launch behind the whole backward pass
+            if self.fuse_one and self.rider_tiles > 0:
+                # riders: part of the Regulation bucket's tiles (with their AdamW) inside the trunk's backward launch, on the CUs it leaves idle
+                _lib.check(L.cf_rider_arm(m._handle, *hp, kg, self.rider_tiles), "cf_rider_arm")
+                self._part(slot, st, 4)
+                _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG | _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")
+            elif self.fuse_one:       # both buckets' tiles in ONE launch behind the whole backward pass
                 if not self.use_graph:
                     self._part(slot, st, 4)
                 _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG | _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")

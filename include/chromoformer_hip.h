@@ -219,6 +219,14 @@ int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, float lr, floa
  * its gradients are written outside the reduction tables).  Not capturable (the optimiser's scalars are launch arguments). */
 int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, float beta1, float beta2, float eps, float weight_decay,
                        long long step, int keep_grads, void* stream);
+/* Arms "riders" for the NEXT cf_backward_part(parts & 4) call: while the Pairwise + Embedding backward occupies 192 of the 256 CUs
+ * with latency chains, an extra row of workgroups of the same launch reduces up to max_tiles leading weight-gradient tiles of the
+ * Regulation + head bucket (they depend on the Regulation backward only) and applies this step's AdamW update in their epilogues,
+ * as cf_reduce_opt_part does.  The cf_reduce_opt_part call that follows (same `step`, a mask with CF_BUCKET_REG) skips those tiles;
+ * it must follow, and nothing else may read or reduce that bucket in between.  Requires the fused trunk kernels (default
+ * configuration); not capturable.  Same parameters and moments as without riders, bit for bit. */
+int cf_rider_arm(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, int keep_grads,
+                 int max_tiles);
 /* Number of kernels the LAST forward / backward (chain pieces + bucket reductions) / optimiser step launched, counted at the
  * launch sites (zero before the first call; calls replayed from a graph do not pass the host code and leave the counts
  * of the capture pass). */

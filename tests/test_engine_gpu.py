@@ -51,7 +51,10 @@ def test_round3_schedules_and_switches_are_bit_identical():
                dict(use_graph=True, merge_opt=True, overlap_reduce=True), dict(use_graph=False, merge_opt=True, overlap_reduce=True),
                # AdamW in the epilogue of the gradient reductions (the default single-GPU step), with and without the gradient stores
                dict(use_graph=False, fuse_opt=True), dict(use_graph=True, fuse_opt=True), dict(use_graph=True, fuse_opt=True, keep_grads=True),
-               dict(use_graph=True, fuse_opt=True, fuse_one=False), dict(use_graph=False, fuse_opt=True, fuse_one=False, keep_grads=True)):
+               dict(use_graph=True, fuse_opt=True, fuse_one=False), dict(use_graph=False, fuse_opt=True, fuse_one=False, keep_grads=True),
+               # without / with riders in the trunk's backward launch (B = 8: 16 teams; 1,008 uniform tiles)
+               dict(use_graph=True, fuse_opt=True, rider_tiles=0), dict(use_graph=True, fuse_opt=True, rider_tiles=100, keep_grads=True),
+               dict(use_graph=False, fuse_opt=True, rider_tiles=5000)):
         got, loss = _run(**kw)
         assert loss == ref_loss, kw
         for k in got:
