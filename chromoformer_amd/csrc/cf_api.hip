@@ -993,8 +993,10 @@ static int build_trunk_table(cf_handle* h) {
     size_t need = 0;
     for (int r = 0; r < c.n_res; ++r) need = std::max(need, trunk_smem(c.n_bins[r], c.n_feats, std::max(c.embed_dff, c.pair_dff)));
     if (need > 160 * 1024) return 0;
+    const size_t need_bwd = std::max(need, (size_t)(kAT / 64) * kWgWaveLds * sizeof(float));      // (riders of the backward launch: cf_rider_arm)
+    if (need_bwd > 160 * 1024) return 0;
     if (hipFuncSetAttribute(trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
-        hipFuncSetAttribute(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
+        hipFuncSetAttribute(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_bwd) != hipSuccess)
         return 0;
     std::vector<TrunkResDev> tab(c.n_res);
     for (int r = 0; r < c.n_res; ++r) {
@@ -1551,15 +1553,18 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         if (h->rider.armed) {      // (cf_rider_arm) a multiple of the team count, all of the same length
             if (h->capturing) return fail("cf_backward_part: armed riders carry this step's AdamW scalars as launch arguments and cannot be captured");
             h->rider.armed = false;
-            const int teams = 2 * B;
-            ta.rd_n = std::min(h->rider.max_tiles, h->n_wg_uniform) / teams * teams;
+            ta.rd_n = std::min(h->rider.max_tiles, h->n_wg_r);      // (one tile per wave at a time: any leading part of the bucket's table)
             ta.rd_tiles = h->wg_tiles;
             ta.rd_opt = h->rider.o;
             h->rider.done = ta.rd_n;
         }
         void* kargs[] = {&ta};
-        HIP_TRY(hipLaunchKernel(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + (ta.rd_n > 0 ? 1 : 0)), dim3(kAT), kargs,
-                                h->trunk_smem_bytes, st));
+        const size_t rider_lds = (size_t)(kAT / 64) * kWgWaveLds * sizeof(float);      // eight wave-private stages
+        // one tile per rider wave: rows of B workgroups x 8 waves until every tile has a wave.  The first 256 - 3 B workgroups start at once on
+        // the idle CUs, the others as the short-resolution workgroups of the trunk (dispatched last, done first) leave theirs
+        const int rider_rows = ta.rd_n > 0 ? (ta.rd_n + B * (kAT / 64) - 1) / (B * (kAT / 64)) : 0;
+        HIP_TRY(hipLaunchKernel(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + rider_rows), dim3(kAT), kargs,
+                                ta.rd_n > 0 ? std::max(h->trunk_smem_bytes, rider_lds) : h->trunk_smem_bytes, st));
         LAUNCH_CHECK("k_trunk_bwd");
         return 0;
     }

@@ -1700,6 +1700,23 @@ constexpr int kWgM = CF_WG_M;       // reduction rows per LDS stage
 constexpr int kWgTk = CF_WG_TK;     // tile width along K (columns of dW): 64 or 128; tiles are 64 (n) x kWgTk (k)
 constexpr int kWgLdA = 64 + 16;     // A stage row stride: a half-wave's scalar reads (two rows x 16 columns) hit 32 distinct banks
 constexpr int kWgLdB = kWgTk + 4;
+// (component-wise: a select between two float4 OBJECTS is compiled to a select between their addresses -- both spilled to scratch)
+__device__ __forceinline__ float4 f4_keep_if(bool keep, const float4& v) {
+    return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+}
+// A tile whose 64 x kWgTk block lies inside the matrix and whose operands allow 16-byte loads (every tile of the default
+// configuration but the head's last layer) fetches its stages WITHOUT branches: wg_load4's edge handling puts every load into a
+// conditional of its own, and the compiler then waits for each one before it issues the next -- a stage of four loads per thread
+// was four round trips, 6 K cycles around 1 K cycles of MFMA issue (tools/reg_stamps-style stamps of the riders; the instruction
+// mix of a stage: 27 branches, 24 scalar and 4 vector loads).
+__device__ __forceinline__ bool wg_tile_interior(const WgTile& t) {
+    bool ok = t.n0 + 64 <= t.Nn && t.k0 + kWgTk <= t.Kk;
+    for (int s = 0; s < t.nseg; ++s) {
+        const WgSeg& sg = t.seg[s];
+        ok = ok && ((sg.lda | sg.ldb | t.n0 | t.k0) & 3) == 0 && ((reinterpret_cast<uintptr_t>(sg.A) | reinterpret_cast<uintptr_t>(sg.B)) & 15) == 0;
+    }
+    return ok;
+}
 // As / Bs: the LDS stage of the 256 threads that work on this tile, tid: their index (the tile of a 256-thread workgroup, or one of
 // the two teams of a 512-thread rider workgroup of k_trunk_bwd, which walk equally long tiles in lock step: the barriers are the
 // workgroup's)
@@ -1722,6 +1739,9 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
     f32x4 acc[4 * NH];
     zero_acc(acc);
     const int sm = tid >> 4, sc = (tid & 15) * 4;          // staging: rows sm, sm + 16; columns sc .. sc + 3 (+ 64 h)
+    const bool interior = wg_tile_interior(t);
+    auto run = [&](auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
     for (int s = 0; s < t.nseg; ++s) {
         const WgSeg sg = t.seg[s];
         const int M = sg.rows_per_gene * batch, nst = (M + kWgM - 1) / kWgM;
@@ -1733,7 +1753,12 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
 #pragma unroll
             for (int p = 0; p < kWgM / 16; ++p) {
                 const int m = st * kWgM + sm + 16 * p;
-                if (m < M) {
+                if (FAST) {      // no branch around a load (see wg_tile_interior): rows past the end re-read the last one and are zeroed by a select
+                    const int mc = min(m, M - 1);      // (the select sits in put(): nothing here needs a loaded value)
+                    ra[sl][p] = ldg4(sg.A + (size_t)mc * sg.lda + t.n0 + sc);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) rb[sl][p][h] = ldg4(sg.B + (size_t)mc * sg.ldb + t.k0 + 64 * h + sc);
+                } else if (m < M) {
                     ra[sl][p] = wg_load4(sg.A + (size_t)m * sg.lda, t.n0 + sc, t.Nn, va);
 #pragma unroll
                     for (int h = 0; h < NH; ++h) rb[sl][p][h] = wg_load4(sg.B + (size_t)m * sg.ldb, t.k0 + 64 * h + sc, t.Kk, vb);
@@ -1744,13 +1769,14 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
                 }
             }
         };
-        auto put = [&](auto slot_c) {
+        auto put = [&](int st, auto slot_c) {
             constexpr int sl = decltype(slot_c)::value;
 #pragma unroll
             for (int p = 0; p < kWgM / 16; ++p) {
-                *reinterpret_cast<float4*>(&As[0][(sm + 16 * p) * kWgLdA + sc]) = ra[sl][p];
+                const bool live = !FAST || st * kWgM + sm + 16 * p < M;
+                *reinterpret_cast<float4*>(&As[0][(sm + 16 * p) * kWgLdA + sc]) = f4_keep_if(live, ra[sl][p]);
 #pragma unroll
-                for (int h = 0; h < NH; ++h) *reinterpret_cast<float4*>(&Bs[0][(sm + 16 * p) * kWgLdB + 64 * h + sc]) = rb[sl][p][h];
+                for (int h = 0; h < NH; ++h) *reinterpret_cast<float4*>(&Bs[0][(sm + 16 * p) * kWgLdB + 64 * h + sc]) = f4_keep_if(live, rb[sl][p][h]);
             }
         };
         static_for<D>([&](auto u) {
@@ -1760,7 +1786,7 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
             const int st = st0 + decltype(u)::value;
             if (st >= nst) return;
             __syncthreads();                                   // the previous stage has been consumed
-            put(u);
+            put(st, u);
             __syncthreads();
             if (st + D < nst) fetch(st + D, u);                // in flight during the next D stages' multiplies
             const float* ap = &As[0][lq * kWgLdA + 16 * w + lr];
@@ -1779,6 +1805,9 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
             }
         });
     }
+    };
+    if (interior) run(std::true_type{});
+    else run(std::false_type{});
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         if (kc + 64 * h >= t.Kk) continue;
@@ -1805,6 +1834,111 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
             }
         }
     }
+}
+// The same tile by ONE wave (the riders of k_trunk_bwd, cf_trunk.h): all four 16-row blocks of the tile in sixteen accumulators, a
+// wave-private LDS stage (kWgWaveLds floats), no workgroup barrier -- eight waves of a workgroup walk eight tiles at their own pace
+// instead of two four-wave teams in lock step (a team's stage is ~6 K cycles of round trips and barriers around 1 K cycles of MFMA
+// issue; only other tiles on the same CU fill that, and a rider workgroup is alone on its CU).  Every element sums its products in
+// the order of the four-wave routine: bit-identical results.  A float4 of B feeds 16 MFMAs instead of 4.
+constexpr int kWgWaveLds = kWgM * kWgLdA + kWgM * kWgLdB;
+template <bool OPT>
+__device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, const AdamFuse* o, float* lds) {
+    static_assert(kWgTk == 64, "one 64 x 64 tile per wave");
+    const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    float* As = lds;
+    float* Bs = lds + kWgM * kWgLdA;
+    const int kc = t.k0 + 4 * lr;
+    f32x4 acc[4][4];      // [16-row block][column quarter c: columns k0 + 4 lr + c]
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) zero_acc(acc[rt]);
+    const int sm = lane >> 4, sc = (lane & 15) * 4;          // staging: rows sm + 4 p; columns sc .. sc + 3
+    constexpr int NP = kWgM / 4;
+    const bool interior = wg_tile_interior(t);
+    auto run = [&](auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        for (int s = 0; s < t.nseg; ++s) {
+            const WgSeg sg = t.seg[s];
+            const int M = sg.rows_per_gene * batch, nst = (M + kWgM - 1) / kWgM;
+            const bool va = ((sg.lda | t.n0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.A) & 15) == 0;
+            const bool vb = ((sg.ldb | t.k0) & 3) == 0 && (reinterpret_cast<uintptr_t>(sg.B) & 15) == 0;
+            float4 ra[NP], rb[NP];
+            auto fetch = [&](int st) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int m = st * kWgM + sm + 4 * p;
+                    if (FAST) {      // (see wg_tile_interior; rows past the end re-read the last one and are zeroed on their way into LDS)
+                        const int mc = min(m, M - 1);
+                        ra[p] = ldg4(sg.A + (size_t)mc * sg.lda + t.n0 + sc);
+                        rb[p] = ldg4(sg.B + (size_t)mc * sg.ldb + t.k0 + sc);
+                    } else {
+                        ra[p] = rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (m < M) {
+                            ra[p] = wg_load4(sg.A + (size_t)m * sg.lda, t.n0 + sc, t.Nn, va);
+                            rb[p] = wg_load4(sg.B + (size_t)m * sg.ldb, t.k0 + sc, t.Kk, vb);
+                        }
+                    }
+                }
+            };
+            fetch(0);
+            for (int st = 0; st < nst; ++st) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (LDS operations of a wave execute in order; these keep the compiler from reordering them)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const bool live = !FAST || st * kWgM + sm + 4 * p < M;
+                    *reinterpret_cast<float4*>(&As[(sm + 4 * p) * kWgLdA + sc]) = f4_keep_if(live, ra[p]);
+                    *reinterpret_cast<float4*>(&Bs[(sm + 4 * p) * kWgLdB + sc]) = f4_keep_if(live, rb[p]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_sched_barrier(0);      // (the next stage's loads stay BEHIND the LDS writes: hoisted above them, the writes' wait would cover one of the new loads)
+                if (st + 1 < nst) fetch(st + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const float* ap = &As[lq * kWgLdA + lr];
+                const float* bp = &Bs[lq * kWgLdB + 4 * lr];
+#pragma unroll
+                for (int i = 0; i < kWgM / 4; ++i) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bp + 4 * i * kWgLdB);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        const float av = ap[4 * i * kWgLdA + 16 * rt];
+                        acc[rt][0] = mfma4(av, bv.x, acc[rt][0]);
+                        acc[rt][1] = mfma4(av, bv.y, acc[rt][1]);
+                        acc[rt][2] = mfma4(av, bv.z, acc[rt][2]);
+                        acc[rt][3] = mfma4(av, bv.w, acc[rt][3]);
+                    }
+                }
+            }
+        }
+    };
+    if (interior) run(std::true_type{});
+    else run(std::false_type{});
+    if (kc >= t.Kk) return;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = t.n0 + rt * 16 + lq * 4 + i;
+            if (row < t.Nn) {
+                float* cp = t.C + (size_t)row * t.ldc + kc;
+                const float4 g4 = make_float4(acc[rt][0][i], acc[rt][1][i], acc[rt][2][i], acc[rt][3][i]);
+                if (OPT) {
+                    const size_t off = (size_t)(cp - o->gbase);
+                    float4 pp = ldg4(o->p + off), mm = ldg4(o->m + off), vv = ldg4(o->v + off);
+                    adamw_elem(pp.x, g4.x, mm.x, vv.x, *o);
+                    adamw_elem(pp.y, g4.y, mm.y, vv.y, *o);
+                    adamw_elem(pp.z, g4.z, mm.z, vv.z, *o);
+                    adamw_elem(pp.w, g4.w, mm.w, vv.w, *o);
+                    stg4(o->p + off, pp);
+                    stg4(o->m + off, mm);
+                    stg4(o->v + off, vv);
+                    if (o->keep_grads) stg4(cp, g4);
+                } else {
+                    stg4(cp, g4);
+                }
+            }
+        }
 }
 template <bool OPT = false>
 __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const AdamFuse* o = nullptr) {

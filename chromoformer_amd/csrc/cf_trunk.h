@@ -524,13 +524,10 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
         // Riders: the trunk's 192 workgroups fill one CU each (141 KB of LDS, 2 x 256 registers per SIMD lane) for ~130 us of
         // latency chains; the other 64 CUs take Regulation weight-gradient tiles meanwhile -- those depend on the Regulation
         // backward only, and neither the trunk nor anything before the next step's Regulation forward reads what their epilogues
-        // update.  Two 256-thread teams per workgroup, each with its own LDS stage, tile t to team t mod (2 gridDim.x): the host
-        // hands over a multiple of the team count of EQUALLY long tiles, so the teams of a workgroup meet at the same barriers.
-        float (*As)[kWgM * kWgLdA] = reinterpret_cast<float (*)[kWgM * kWgLdA]>(smem + (threadIdx.x >> 8) * (kWgM * kWgLdA + kWgM * kWgLdB));
-        float (*Bs)[kWgM * kWgLdB] = reinterpret_cast<float (*)[kWgM * kWgLdB]>(&As[0][0] + kWgM * kWgLdA);
-        const int n_teams = 2 * gridDim.x;
-        for (int t = 2 * blockIdx.x + (threadIdx.x >> 8); t < a.rd_n; t += n_teams)
-            wgrad_tile_impl<true, 4>(a.rd_tiles[t], a.rd_batch, &a.rd_opt, As, Bs, threadIdx.x & 255);
+        // update.  One tile per WAVE at a time (wgrad_tile_wave: no workgroup barrier, eight tiles in flight per CU).
+        const int w = threadIdx.x >> 6;
+        const int t = (((int)blockIdx.y - a.n_res) * gridDim.x + blockIdx.x) * (kAT / 64) + w;      // (rows of riders: one tile per wave)
+        if (t < a.rd_n) wgrad_tile_wave<true>(a.rd_tiles[t], a.rd_batch, &a.rd_opt, smem + w * kWgWaveLds);
         return;
     }
     const int r = a.n_res - 1 - (int)blockIdx.y;

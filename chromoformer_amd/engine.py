@@ -243,10 +243,13 @@ class Trainer:
             import os
             fuse_one = os.environ.get("CF_FUSE_ONE", "1") != "0"
         self.fuse_one = bool(fuse_one)
-        # ... and part of the Regulation bucket's tiles as riders of the trunk's backward launch (cf_rider_arm): rider_tiles of the 1,008
+        # ... and part of the Regulation bucket's tiles as RIDERS of the trunk's backward launch (cf_rider_arm): the trunk's 192 workgroups
+        # occupy one CU each for ~130 us of latency chains, the other 64 CUs reduce (and step) rider_tiles of that bucket's 1,008
+        # weight-gradient tiles meanwhile, one tile per wave.  0.590 -> 0.564 ms; more than one tile per rider wave outlasts the trunk
+        # (768: 0.650 ms).  rider_tiles=0 / CF_RIDER_TILES=0: everything in the reduction launch.
         if rider_tiles is None:
             import os
-            rider_tiles = int(os.environ.get("CF_RIDER_TILES", "256"))
+            rider_tiles = int(os.environ.get("CF_RIDER_TILES", "512"))
         self.rider_tiles = int(rider_tiles) if self.fuse_opt and self.fuse_one else 0
         if self.rider_tiles > 0 and self._L.cf_rider_arm(model._handle, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, 0, 0) != 0:
             self.rider_tiles = 0          # (configurations without the fused trunk kernels)
@@ -377,7 +380,9 @@ class Trainer:
             kg = 1 if self.keep_grads else 0
             if self.fuse_one and self.rider_tiles > 0:
                 # riders: part of the Regulation bucket's tiles (with their AdamW) inside the trunk's backward launch, on the CUs it leaves idle
-                _lib.check(L.cf_rider_arm(m._handle, *hp, kg, self.rider_tiles), "cf_rider_arm")
+                # (one tile per rider wave, eight waves per idle CU: 256 CUs minus the trunk's n_res x B workgroups)
+                n_rd = min(self.rider_tiles, 8 * max(0, 256 - len(m.binsizes) * slot.B))
+                _lib.check(L.cf_rider_arm(m._handle, *hp, kg, n_rd), "cf_rider_arm")
                 self._part(slot, st, 4)
                 _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG | _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")
             elif self.fuse_one:       # both buckets' tiles in ONE launch behind the whole backward pass
