@@ -1811,6 +1811,20 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         if (kc + 64 * h >= t.Kk) continue;
+        // OPT: the optimiser state of all four rows is requested at once (one round trip, not four: a load inside the row loop is
+        // waited for before the next row's is issued); rows past the end re-read the last one and are not stored
+        float4 pp[4], mm[4], vv[4];
+        if (OPT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = min(t.n0 + w * 16 + lq * 4 + i, t.Nn - 1);
+                const size_t off = (size_t)(t.C + (size_t)row * t.ldc + kc + 64 * h - o->gbase);
+                pp[i] = ldg4(o->p + off);
+                mm[i] = ldg4(o->m + off);
+                vv[i] = ldg4(o->v + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = t.n0 + w * 16 + lq * 4 + i;
@@ -1819,14 +1833,13 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
                 const float4 g4 = make_float4(acc[4 * h + 0][i], acc[4 * h + 1][i], acc[4 * h + 2][i], acc[4 * h + 3][i]);
                 if (OPT) {
                     const size_t off = (size_t)(cp - o->gbase);
-                    float4 pp = ldg4(o->p + off), mm = ldg4(o->m + off), vv = ldg4(o->v + off);
-                    adamw_elem(pp.x, g4.x, mm.x, vv.x, *o);
-                    adamw_elem(pp.y, g4.y, mm.y, vv.y, *o);
-                    adamw_elem(pp.z, g4.z, mm.z, vv.z, *o);
-                    adamw_elem(pp.w, g4.w, mm.w, vv.w, *o);
-                    stg4(o->p + off, pp);
-                    stg4(o->m + off, mm);
-                    stg4(o->v + off, vv);
+                    adamw_elem(pp[i].x, g4.x, mm[i].x, vv[i].x, *o);
+                    adamw_elem(pp[i].y, g4.y, mm[i].y, vv[i].y, *o);
+                    adamw_elem(pp[i].z, g4.z, mm[i].z, vv[i].z, *o);
+                    adamw_elem(pp[i].w, g4.w, mm[i].w, vv[i].w, *o);
+                    stg4(o->p + off, pp[i]);
+                    stg4(o->m + off, mm[i]);
+                    stg4(o->v + off, vv[i]);
                     if (o->keep_grads) stg4(cp, g4);
                 } else {
                     stg4(cp, g4);
@@ -1842,7 +1855,7 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
 // the order of the four-wave routine: bit-identical results.  A float4 of B feeds 16 MFMAs instead of 4.
 constexpr int kWgWaveLds = kWgM * kWgLdA + kWgM * kWgLdB;
 template <bool OPT>
-__device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, const AdamFuse* o, float* lds) {
+__device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, const AdamFuse* o, float* lds, unsigned long long* stamp = nullptr) {
     static_assert(kWgTk == 64, "one 64 x 64 tile per wave");
     const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     float* As = lds;
@@ -1912,11 +1925,25 @@ __device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, cons
             }
         }
     };
+    if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
     if (interior) run(std::true_type{});
     else run(std::false_type{});
+    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
     if (kc >= t.Kk) return;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < 4; ++rt) {
+        float4 pp[4], mm[4], vv[4];      // (the optimiser state of a 16-row block at once: four round trips per tile instead of sixteen)
+        if (OPT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = min(t.n0 + rt * 16 + lq * 4 + i, t.Nn - 1);
+                const size_t off = (size_t)(t.C + (size_t)row * t.ldc + kc - o->gbase);
+                pp[i] = ldg4(o->p + off);
+                mm[i] = ldg4(o->m + off);
+                vv[i] = ldg4(o->v + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = t.n0 + rt * 16 + lq * 4 + i;
@@ -1925,20 +1952,20 @@ __device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, cons
                 const float4 g4 = make_float4(acc[rt][0][i], acc[rt][1][i], acc[rt][2][i], acc[rt][3][i]);
                 if (OPT) {
                     const size_t off = (size_t)(cp - o->gbase);
-                    float4 pp = ldg4(o->p + off), mm = ldg4(o->m + off), vv = ldg4(o->v + off);
-                    adamw_elem(pp.x, g4.x, mm.x, vv.x, *o);
-                    adamw_elem(pp.y, g4.y, mm.y, vv.y, *o);
-                    adamw_elem(pp.z, g4.z, mm.z, vv.z, *o);
-                    adamw_elem(pp.w, g4.w, mm.w, vv.w, *o);
-                    stg4(o->p + off, pp);
-                    stg4(o->m + off, mm);
-                    stg4(o->v + off, vv);
+                    adamw_elem(pp[i].x, g4.x, mm[i].x, vv[i].x, *o);
+                    adamw_elem(pp[i].y, g4.y, mm[i].y, vv[i].y, *o);
+                    adamw_elem(pp[i].z, g4.z, mm[i].z, vv[i].z, *o);
+                    adamw_elem(pp[i].w, g4.w, mm[i].w, vv[i].w, *o);
+                    stg4(o->p + off, pp[i]);
+                    stg4(o->m + off, mm[i]);
+                    stg4(o->v + off, vv[i]);
                     if (o->keep_grads) stg4(cp, g4);
                 } else {
                     stg4(cp, g4);
                 }
             }
         }
+    }
 }
 template <bool OPT = false>
 __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const AdamFuse* o = nullptr) {

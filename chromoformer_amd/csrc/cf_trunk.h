@@ -527,7 +527,13 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
         // update.  One tile per WAVE at a time (wgrad_tile_wave: no workgroup barrier, eight tiles in flight per CU).
         const int w = threadIdx.x >> 6;
         const int t = (((int)blockIdx.y - a.n_res) * gridDim.x + blockIdx.x) * (kAT / 64) + w;      // (rows of riders: one tile per wave)
-        if (t < a.rd_n) wgrad_tile_wave<true>(a.rd_tiles[t], a.rd_batch, &a.rd_opt, smem + w * kWgWaveLds);
+        unsigned long long* stamp = a.tdbg && blockIdx.x == 0 && (int)blockIdx.y == a.n_res && (threadIdx.x & 63) == 0 ? a.tdbg + 64 + 4 * w : nullptr;
+        if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+        if (t < a.rd_n) wgrad_tile_wave<true>(a.rd_tiles[t], a.rd_batch, &a.rd_opt, smem + w * kWgWaveLds, stamp);
+        if (stamp) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp[2] = __builtin_amdgcn_s_memtime();
+        }
         return;
     }
     const int r = a.n_res - 1 - (int)blockIdx.y;

@@ -126,3 +126,29 @@ def test_one_rank_rccl_all_reduce_in_the_step():
     for k in ref:
         assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], got2[k]) and torch.equal(ref[k], got3[k]), k
         assert torch.equal(ref[k], got4[k]) and torch.equal(ref[k], got5[k]), k
+
+
+def test_riders_must_be_followed_by_the_fused_reduction_of_the_same_step():
+    """cf_rider_arm hands part of a bucket to the next trunk launch, AdamW included: a plain reduction, or a fused one for another step,
+    must be refused afterwards (the bucket would be reduced twice / stepped with two sets of scalars)."""
+    import ctypes as C
+    from chromoformer_amd import ChromoformerClassifier, _lib
+    from chromoformer_amd.engine import Trainer
+    model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+    tr = Trainer(model, use_graph=False, rider_tiles=64)
+    slot = tr.stage(orc.synthetic_batch(B, seed=3, regime="dense"))
+    tr.step(slot)                                   # a regular step with riders
+    L, h, st = _lib.lib(), model._handle, tr.stream.cuda_stream
+    hp = (3e-5, 0.9, 0.999, 1e-8, 0.01)
+    with torch.cuda.stream(tr.stream):
+        tr._seq_early(slot, st, reduce=False)
+        assert L.cf_rider_arm(h, *hp, 2, 0, 64) == 0
+        tr._part(slot, st, 4)                       # the trunk launch takes 64 tiles (and steps them with the scalars of step 2)
+        assert L.cf_backward_reduce_part(h, slot.B, _lib.BUCKET_REG, st) != 0
+        assert b"riders" in L.cf_last_error()
+        assert L.cf_reduce_opt_part(h, slot.B, _lib.BUCKET_REG | _lib.BUCKET_PE, *hp, 3, 0, st) != 0      # another step's scalars
+        assert L.cf_rider_arm(h, *hp, 3, 0, 64) != 0                                                      # nor a second arming
+        assert L.cf_reduce_opt_part(h, slot.B, _lib.BUCKET_REG | _lib.BUCKET_PE, *hp, 2, 0, st) == 0      # the call that belongs there
+    torch.cuda.synchronize()
+    sd = model.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values())
