@@ -56,3 +56,38 @@ def test_forward_and_gradients_match_oracle(name, reg):
             continue
         err = (named[k].grad.cpu() - v.grad).abs().max().item()
         assert err <= GRAD_TOL * v.grad.abs().max().item() + 1e-9, (k, err, v.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths"])
+def test_fused_optimiser_and_riders_equal_the_separate_launches(name):
+    """Away from the default shapes: AdamW in the reduction epilogues, both buckets in one launch, part of the tiles riding in the trunk's
+    backward launch where the fused trunk kernels exist (elsewhere the trainer falls back) -- same parameters and moments, bit for bit,
+    as reduction and AdamW launches of their own (tiles at the edge of a matrix take the riders' general fetch path here)."""
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    cfg = orc._cfg(VARIANTS[name])
+    B = 5
+    batches = [orc.synthetic_batch(B, cfg=cfg, seed=21 + i, regime="realistic") for i in range(2)]
+
+    def run(**kw):
+        model = ChromoformerClassifier(cfg["n_feats"], cfg["d_emb"], cfg["d_head"], cfg["embed"], cfg["pairwise_interaction"], cfg["regulation"],
+                                       binsizes=cfg["binsizes"], seed=3, i_max=cfg["i_max"], w_max=cfg["w_max"], max_batch=B).cuda(0)
+        tr = Trainer(model, lr=1e-3, **kw)
+        slots = [tr.stage(b) for b in batches]
+        losses = []
+        for i in range(3):
+            _, loss = tr.step(slots[i % 2])
+            with torch.cuda.stream(tr.stream):
+                losses.append(loss.clone())
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        sd["<exp_avg>"], sd["<exp_avg_sq>"] = model._mflat.cpu().clone(), model._vflat.cpu().clone()
+        return sd, [float(x) for x in losses], tr
+
+    ref, ref_loss, _ = run(use_graph=False, merge_opt=False)
+    for kw in (dict(use_graph=True), dict(use_graph=False, rider_tiles=37), dict(use_graph=True, rider_tiles=100000), dict(use_graph=True, rider_tiles=0)):
+        got, loss, tr = run(**kw)
+        assert tr.fuse_opt, kw
+        assert loss == ref_loss, (name, kw)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (name, kw, k)
