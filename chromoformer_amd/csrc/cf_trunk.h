@@ -110,6 +110,9 @@ __host__ __device__ inline size_t trunk_smem(int L, int F, int dff_max) {
 // What the kernels below do: every phase forceinline, STRAIGHT-LINE code (the number of Pairwise layers is a template parameter), and
 // launder() in front of every phase -- the context passes through an empty `asm volatile`, so each phase recomputes what it needs
 // from opaque inputs, as the stand-alone kernels do.  21 (forward) / 72 (backward) spilled VGPRs remain, none inside a loop.
+#ifndef CF_STAMP_Y      // which row of workgroups writes the phase stamps (0: the longest resolution; tools/trunk_stamps.py)
+#define CF_STAMP_Y 0
+#endif
 #define CF_PHASE static __device__ __forceinline__
 
 struct TrunkCtx {      // what every phase needs, by value (uniform: lives in SGPRs)
@@ -318,10 +321,10 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
     float* persist = smem + trunk_scratch_floats(TF(L), DFF_MAX);
     TrunkCtx c{R, a.pfeats[r], a.pmask[r], a.pmstride[r], (int)blockIdx.x, a.S, a.T, a.F, a.save, a.scale, a.rscale};
     int stamp_i = 0;
-    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime();
+    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == CF_STAMP_Y && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime();
 #define CF_NEXT_PHASE                                                                                     \
     __syncthreads();                                                                                      \
-    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime(); \
+    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == CF_STAMP_Y && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime(); \
     launder(c, sm, persist)
     {
         TrunkCtx cs{R, a.cfeats[r], a.cmask[r], a.cmstride[r], (int)blockIdx.x, a.S, a.T, a.F, a.save, a.scale, a.rscale};
@@ -543,7 +546,8 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     float* persist = smem + trunk_scratch_floats(TF(L), DFF_MAX);
     TrunkCtx c{R, a.cfeats[r], a.cmask[r], a.cmstride[r], (int)blockIdx.x, a.S, a.T, a.F, 1, a.scale, a.rscale};
     int stamp_i = 32;
-    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime();
+    if (a.tdbg && blockIdx.x == 0 && blockIdx.y == CF_STAMP_Y && threadIdx.x == 0) a.tdbg[stamp_i++] = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_wg0 = __builtin_amdgcn_s_memtime();      // (tools/rider_stamps.py: how long a workgroup of each resolution lasts)
     trunk_stage_p(c, persist);
     launder(c, sm, persist);
     // ---------------------------------------------------------------- Pairwise stack, last layer first
@@ -579,6 +583,7 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     CF_NEXT_PHASE;
     trunk_lp(a.lp_jobs, r, c.g, a.B, sm);
     CF_NEXT_PHASE;
+    if (a.tdbg && blockIdx.x == 0 && threadIdx.x == 0) a.tdbg[100 + blockIdx.y] = __builtin_amdgcn_s_memtime() - t_wg0;
 }
 
 }  // namespace cf

@@ -17,6 +17,7 @@ torch.cuda.synchronize()
 t = m.debug_buffer("reg_tdbg").cpu().numpy().view(np.uint64).astype(np.int64)
 t0 = t[32]
 print("trunk workgroup (gene 0, longest resolution): %d ticks" % (t[32 + 11] - t0))
+print("trunk workgroups of gene 0, longest resolution first: " + "  ".join("%d ticks" % v for v in t[100:103]))
 for w in range(8):
     s = t[64 + 4 * w: 64 + 4 * w + 4]
     print("rider wave %d: starts %6d   stage loop %6d .. %6d (%6d)   optimiser epilogue done %6d (%6d)" % (w, s[3] - t0, s[0] - t0, s[1] - t0, s[1] - s[0], s[2] - t0, s[2] - s[1]))
