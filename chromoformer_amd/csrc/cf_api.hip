@@ -238,6 +238,7 @@ struct cf_handle {
     } rider;
     int n_wg_uniform = 0;                      // leading tiles of the table that are one segment of the same length (the Regulation layers')
     int xcd_reduce = 0;                        // XCD-aware order of the weight-gradient tiles (measured slower: cf_kernels.h, xcd_tile)
+    int xcd_reduce_opt = 1;                    // ... in the fused reduction + AdamW launch, which moves 5.5 TB/s: there it pays (0.568 -> 0.563 ms)
     int defer_retile = 1;                      // Regulation + head units ride in the Embedding layer's chain launch (CF_DEFER_RETILE=0: all in the prologue)
     // workspace
     float* arena = nullptr;
@@ -843,7 +844,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     if (const char* e = getenv("CF_ATTC_CAP")) h->attc_cap = atoi(e);
     if (const char* e = getenv("CF_ATTC1")) h->attc1 = atoi(e) != 0;
     if (const char* e = getenv("CF_DEFER_RETILE")) h->defer_retile = atoi(e) != 0;
-    if (const char* e = getenv("CF_XCD_REDUCE")) h->xcd_reduce = atoi(e) != 0;
+    if (const char* e = getenv("CF_XCD_REDUCE")) h->xcd_reduce = h->xcd_reduce_opt = atoi(e) != 0;
     h->n_fwd = h->n_bwd = h->n_opt = 0;      // counted at the launch sites by the first calls (cf_launch_counts)
     *out = h;
     return 0;
@@ -1996,7 +1997,7 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
     }
     AdamFuse o{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0};
     hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
-                       h->xcd_reduce, o);
+                       h->xcd_reduce_opt, o);
     LAUNCH_CHECK("k_reduce_opt");
     h->n_bwd += (int)(g_launches - launches0);
     return 0;

@@ -1983,7 +1983,9 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const Ada
 // MEASURED (round 3): slower -- k_reduce 38.4 -> 40.6 us per launch on a box whose other kernels ran 2.7 % faster: with a job's
 // tiles in one XCD all of them walk the same rows of the same arrays in lock step and queue on the same L2 channels, and the
 // re-reads the table order causes are served by the 256 MB Infinity Cache anyway (the arrays were written by the kernel in
-// front).  Off by default (`on` = 0: table order), CF_XCD_REDUCE=1 turns it on.
+// front).  Off by default there (`on` = 0: table order).  In the fused reduction + AdamW launch of the single-GPU step
+// (k_reduce_opt behind the riders: 796 tiles + the optimiser state, 312 MB HBM-side in 56 us = 5.5 TB/s) bytes are what binds, and the
+// same order PAYS: 0.5683 -> 0.5633 ms over two A/B rounds; on by default for that launch.  CF_XCD_REDUCE=0 / 1 forces both.
 __device__ __forceinline__ int xcd_tile(int b, int n, int on) {
     const int per = (n + 7) >> 3;
     return on ? (b & 7) * per + (b >> 3) : b;
