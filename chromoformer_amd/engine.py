@@ -96,7 +96,7 @@ class Slot:
 class EpochFeed:
     """The batches of an epoch taken from a device-resident GeneStore INSIDE the step graph (cf_gather_batch): the gene
     order of the epoch is uploaded once, a device-side cursor walks it, and every step's logits / labels / loss are
-    appended to per-epoch logs (cf_record_step).  A training step is then three host calls -- graph replay, reduction + AdamW, AdamW --
+    appended to per-epoch logs (cf_record_step).  A training step is then four host calls -- graph replay, cf_rider_arm, the trunk's backward launch, reduction + AdamW --
     instead of the reference's DataLoader round trip plus per-tensor .cuda() copies (train.py:137-140, 171-177)."""
 
     def __init__(self, model, store, bsz, max_batches=None):

@@ -252,7 +252,7 @@ def main(argv=None):
 
 
 def train_epoch(trainer, feed, batches, report=None, every=10):
-    """The optimisation steps of one epoch (train.py:171-232): per step three host calls (graph replay, two optimiser launches) and no
+    """The optimisation steps of one epoch (train.py:171-232): per step four host calls (graph replay, cf_rider_arm, the trunk's backward launch with its riders, reduction + AdamW) and no
     host synchronisation.  Every `every` steps an event is recorded; `report(logits, labels, losses)` receives each window
     of `every` steps as soon as its event has completed (polled, never waited for inside the epoch), read from the feed's
     pinned-host logs: the host-side metrics never leave the GPU idle, the printed lines are the reference's, a little late."""
