@@ -351,7 +351,7 @@ __device__ __forceinline__ void attc2_body(const Attc2Args& a, const int r, cons
                 pv[bi][ii] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((m >> 1) < nreg && (m >> 1) < kAG) {
                     const float* pg = a.p[r] + ((size_t)n0 * 2 + m) * L;
-                    if (j0 + 3 < L && (L & 3) == 0) pv[bi][ii] = ldg4(pg + j0);
+                    if (j0 + 3 < L && (L & 3) == 0) pv[bi][ii] = (CF_TRUNK_NT & 2) ? ldg4_nt(pg + j0) : ldg4(pg + j0);
                     else {
                         if (j0 < L) pv[bi][ii].x = ldg(pg + j0);
                         if (j0 + 1 < L) pv[bi][ii].y = ldg(pg + j0 + 1);
@@ -464,7 +464,10 @@ __device__ __forceinline__ void attc2_body(const Attc2Args& a, const int r, cons
                 o = make_float4(xs[bi][ii][0] * fac[bi], xs[bi][ii][1] * fac[bi], xs[bi][ii][2] * fac[bi], xs[bi][ii][3] * fac[bi]);
                 if (present) {
                     float* pg = a.p[r] + ((size_t)n0 * 2 + m) * L;
-                    if (j0 + 3 < L && (L & 3) == 0) stg4(pg + j0, o);
+                    if (j0 + 3 < L && (L & 3) == 0) {
+                        if (CF_TRUNK_NT & 1) stg4_nt(pg + j0, o);
+                        else stg4(pg + j0, o);
+                    }
                     else {
                         if (j0 < L) stg(pg + j0, o.x);
                         if (j0 + 1 < L) stg(pg + j0 + 1, o.y);

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#ifndef CF_TRUNK_NT      // streaming hints for what the centre-row kernels only save for the backward pass (1: stores, 2: loads)
+#define CF_TRUNK_NT 0
+#endif
 
 namespace cf {
 
@@ -58,6 +61,15 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
     const v4f v = *(const CF_GLOBAL v4f*)(p);
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// streaming forms (nt): data that is touched once -- the optimiser state under the riders -- should not push the tables of the kernel
+// that runs beside them out of the L2
+__device__ __forceinline__ float4 ldg4_nt(const float* p) {
+    const v4f v = __builtin_nontemporal_load((const CF_GLOBAL v4f*)(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ldg_nt(const float* p) { return __builtin_nontemporal_load((const CF_GLOBAL float*)(p)); }
+__device__ __forceinline__ void stg_nt(float* p, float v) { __builtin_nontemporal_store(v, (CF_GLOBAL float*)(p)); }
+__device__ __forceinline__ void stg4_nt(float* p, float4 v) { __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, (CF_GLOBAL v4f*)(p)); }
 __device__ __forceinline__ void stg(float* p, float v) { *(CF_GLOBAL float*)(p) = v; }
 __device__ __forceinline__ void stg2(float* p, float2 v) { *(CF_GLOBAL v2f*)(p) = v2f{v.x, v.y}; }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *(CF_GLOBAL v4f*)(p) = v4f{v.x, v.y, v.z, v.w}; }
@@ -437,6 +449,7 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
     return make_float4(a.x * b.x + c.x, a.y * b.y + c.y, a.z * b.z + c.z, a.w * b.w + c.w);
 }
 // forward: ts (LDS tile, in place -> y); xhat / rstd / y to global rows row0 + row when row < nvalid
+template <bool NT = false>      // NT: streaming stores (rows nobody reads before they have left the L2 anyway: the Regulation kernels' saves)
 __device__ __forceinline__ void ln_fwd_tile16(float* ts, int ld, const LnParams& P, int row0, int nvalid, float* xhat_g, float* rstd_g,
                                               float* y_g, const RowMap ymap = RowMap{1, 1, 0, 0}) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, row = w * 4 + (lane >> 4), sub = lane & 15;
@@ -453,14 +466,24 @@ __device__ __forceinline__ void ln_fwd_tile16(float* ts, int ld, const LnParams&
     if (row < nvalid) {
         const size_t o = (size_t)(row0 + row) * kD + sub * 8;
         if (xhat_g) {
-            stg4(xhat_g + o, x0);
-            stg4(xhat_g + o + 4, x1);
+            if (NT) {
+                stg4_nt(xhat_g + o, x0);
+                stg4_nt(xhat_g + o + 4, x1);
+            } else {
+                stg4(xhat_g + o, x0);
+                stg4(xhat_g + o + 4, x1);
+            }
             if (sub == 0) stg(rstd_g + row0 + row, rstd);
         }
         if (y_g) {
             const size_t oy = (size_t)map_row(ymap, row0 + row) * kD + sub * 8;
-            stg4(y_g + oy, y0);
-            stg4(y_g + oy + 4, y1);
+            if (NT) {
+                stg4_nt(y_g + oy, y0);
+                stg4_nt(y_g + oy + 4, y1);
+            } else {
+                stg4(y_g + oy, y0);
+                stg4(y_g + oy + 4, y1);
+            }
         }
     }
 }
@@ -1010,7 +1033,10 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
             for (int i = 0; i < 4; ++i) {
                 const int row = lq * 4 + i, col = w * CW + col_nt(t, lr);
                 as_[row][col] = acc[t][i];
-                if (a.save && row0 + row < N) stg(a.a_out[r] + (size_t)(row0 + row) * DM + col, acc[t][i]);
+                if (a.save && row0 + row < N) {
+                    if (CF_TRUNK_NT & 1) stg_nt(a.a_out[r] + (size_t)(row0 + row) * DM + col, acc[t][i]);
+                    else stg(a.a_out[r] + (size_t)(row0 + row) * DM + col, acc[t][i]);
+                }
             }
     } else {
         load_tile(&as_[0][0], DM + 4, a.ain[r], DM, DM, row0, N, identity_map());
@@ -1032,7 +1058,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
     frag_load_nt(f1, a.w1[r] + (size_t)(w * CH) * kD, kD);
     __syncthreads();
     if (w < 4)
-        ln_fwd_tile16(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
+        ln_fwd_tile16<(CF_TRUNK_NT & 1) != 0>(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
     __syncthreads();
     {   // hdn = relu(y1 W1^T + b1)
         f32x4 acc[NT1];
@@ -1045,7 +1071,10 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
                 const int row = lq * 4 + i, col = w * CH + col_nt(t, lr);
                 const float v = fmaxf(acc[t][i] + ldg(a.b1[r] + col), 0.f);
                 hs[row][col] = v;
-                if (a.save && row0 + row < N) stg(a.hdn[r] + (size_t)(row0 + row) * DFF + col, v);
+                if (a.save && row0 + row < N) {
+                    if (CF_TRUNK_NT & 1) stg_nt(a.hdn[r] + (size_t)(row0 + row) * DFF + col, v);
+                    else stg(a.hdn[r] + (size_t)(row0 + row) * DFF + col, v);
+                }
             }
     }
     FragNT<NTC, DFF / 16> f2;      // (RING = 8 for this K = 256 product, everything in flight at once: measured, no change)
@@ -1693,6 +1722,15 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col,
 #ifndef CF_WG_TK
 #define CF_WG_TK 64      // 128 measured: 91.6 vs 78.1 us per step (half as many workgroups: the barriers of a stage are no longer hidden)
 #endif
+// Streaming (nt) loads and stores for the optimiser state in the tile epilogues: every element is touched once per step, and as plain
+// accesses the 128 MB of them sweep the L2s that the operand rows of the other tiles -- and, under the riders, the tables of the trunk --
+// live in.  A/B on one box: riders only 0.568 -> 0.565 ms, all epilogues 0.567 -> 0.558.
+#ifndef CF_OPT_NT
+#define CF_OPT_NT 1
+#endif
+#ifndef CF_RIDER_NT
+#define CF_RIDER_NT 1
+#endif
 #ifndef CF_WG_M
 #define CF_WG_M 32
 #endif
@@ -1819,9 +1857,9 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
             for (int i = 0; i < 4; ++i) {
                 const int row = min(t.n0 + w * 16 + lq * 4 + i, t.Nn - 1);
                 const size_t off = (size_t)(t.C + (size_t)row * t.ldc + kc + 64 * h - o->gbase);
-                pp[i] = ldg4(o->p + off);
-                mm[i] = ldg4(o->m + off);
-                vv[i] = ldg4(o->v + off);
+                pp[i] = CF_OPT_NT ? ldg4_nt(o->p + off) : ldg4(o->p + off);
+                mm[i] = CF_OPT_NT ? ldg4_nt(o->m + off) : ldg4(o->m + off);
+                vv[i] = CF_OPT_NT ? ldg4_nt(o->v + off) : ldg4(o->v + off);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1837,9 +1875,9 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
                     adamw_elem(pp[i].y, g4.y, mm[i].y, vv[i].y, *o);
                     adamw_elem(pp[i].z, g4.z, mm[i].z, vv[i].z, *o);
                     adamw_elem(pp[i].w, g4.w, mm[i].w, vv[i].w, *o);
-                    stg4(o->p + off, pp[i]);
-                    stg4(o->m + off, mm[i]);
-                    stg4(o->v + off, vv[i]);
+                    if (CF_OPT_NT) stg4_nt(o->p + off, pp[i]); else stg4(o->p + off, pp[i]);
+                    if (CF_OPT_NT) stg4_nt(o->m + off, mm[i]); else stg4(o->m + off, mm[i]);
+                    if (CF_OPT_NT) stg4_nt(o->v + off, vv[i]); else stg4(o->v + off, vv[i]);
                     if (o->keep_grads) stg4(cp, g4);
                 } else {
                     stg4(cp, g4);
@@ -1938,9 +1976,9 @@ __device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, cons
             for (int i = 0; i < 4; ++i) {
                 const int row = min(t.n0 + rt * 16 + lq * 4 + i, t.Nn - 1);
                 const size_t off = (size_t)(t.C + (size_t)row * t.ldc + kc - o->gbase);
-                pp[i] = ldg4(o->p + off);
-                mm[i] = ldg4(o->m + off);
-                vv[i] = ldg4(o->v + off);
+                pp[i] = CF_RIDER_NT ? ldg4_nt(o->p + off) : ldg4(o->p + off);
+                mm[i] = CF_RIDER_NT ? ldg4_nt(o->m + off) : ldg4(o->m + off);
+                vv[i] = CF_RIDER_NT ? ldg4_nt(o->v + off) : ldg4(o->v + off);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1956,9 +1994,9 @@ __device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, cons
                     adamw_elem(pp[i].y, g4.y, mm[i].y, vv[i].y, *o);
                     adamw_elem(pp[i].z, g4.z, mm[i].z, vv[i].z, *o);
                     adamw_elem(pp[i].w, g4.w, mm[i].w, vv[i].w, *o);
-                    stg4(o->p + off, pp[i]);
-                    stg4(o->m + off, mm[i]);
-                    stg4(o->v + off, vv[i]);
+                    if (CF_RIDER_NT) stg4_nt(o->p + off, pp[i]); else stg4(o->p + off, pp[i]);
+                    if (CF_RIDER_NT) stg4_nt(o->m + off, mm[i]); else stg4(o->m + off, mm[i]);
+                    if (CF_RIDER_NT) stg4_nt(o->v + off, vv[i]); else stg4(o->v + off, vv[i]);
                     if (o->keep_grads) stg4(cp, g4);
                 } else {
                     stg4(cp, g4);

@@ -28,6 +28,38 @@
 #ifndef CF_STAGGER      // 1: waves 4..7 run the attention BEFORE the gate chunk (opposite to their SIMD partner).  Measured: no change
 #define CF_STAGGER 0    // (116.8 vs 117.0 us, three interleaved rounds) -- the two waves of a SIMD drift apart on their own.
 #endif
+// The activations saved for the backward pass are written once and read once, 100+ us later: as plain accesses they sweep the L2 that
+// the weight tiles of the layer stream through (every workgroup of an XCD reads the same 0.9 MB per layer); as streaming (nt) stores /
+// loads they do not.  CF_SAVE_NT=0: plain.
+#ifndef CF_SAVE_NT      // bits: 1 forward saves of the attention operands / a / hdn, 2 their loads in the backward, 4 the LayerNorm saves,
+#define CF_SAVE_NT 11   //       8 the backward's row-level outputs, 16 the backward's LayerNorm operand loads.  Measured (ms per step, two A/B
+#endif                  //       rounds): 0 0.561, 1 0.553, 2 0.550, 3 0.545 / 0.543, 7 0.545, 11 0.5405, 19 0.544, 31 0.542
+#if CF_SAVE_NT & 1
+#define SAVE_ST stg_nt
+#define SAVE_ST4 stg4_nt
+#else
+#define SAVE_ST stg
+#define SAVE_ST4 stg4
+#endif
+#if CF_SAVE_NT & 2
+#define SAVE_LD ldg_nt
+#define SAVE_LD4 ldg4_nt
+#else
+#define SAVE_LD ldg
+#define SAVE_LD4 ldg4
+#endif
+#if CF_SAVE_NT & 8
+#define BWD_ST stg_nt
+#define BWD_ST4 stg4_nt
+#else
+#define BWD_ST stg
+#define BWD_ST4 stg4
+#endif
+#if CF_SAVE_NT & 16
+#define BWD_LD4 ldg4_nt
+#else
+#define BWD_LD4 ldg4
+#endif
 #ifndef CF_QPRE
 #define CF_QPRE 7
 #endif
@@ -177,8 +209,8 @@ __device__ __forceinline__ void ln_bwd_tile16_r(const float* src, float* dst, in
     *reinterpret_cast<float4*>(dp) = o0;
     *reinterpret_cast<float4*>(dp + 4) = o1;
     if (live) {
-        stg4(dx_lane, o0);
-        stg4(dx_lane + 4, o1);
+        BWD_ST4(dx_lane, o0);
+        BWD_ST4(dx_lane + 4, o1);
     }
 }
 
@@ -298,7 +330,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
 #pragma unroll
                             for (int ii = 0; ii < 4; ++ii) dst[ii * 36 + t * 16] = pacc[t][ii];
                             float* tp_ = lane_at(sbase(hq, (c == 0 ? kHqQ : kHqK) + t * 256), bT);      // (scalar bases are formed outside the conditionals)
-                            if (SAVE && rok[0]) stg4(tp_, acc4(pacc[t]));
+                            if (SAVE && rok[0]) SAVE_ST4(tp_, acc4(pacc[t]));
                         }
                     } else if (c == 2) {    // v: stays in registers (B operand of p v); rows to global for the backward
 #pragma unroll
@@ -308,7 +340,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                                 float* vp_ = lane_at(sbase(hq, kHqV), bV);
 #pragma unroll
                                 for (int ii = 0; ii < 4; ++ii)
-                                    if (rok[ii]) stg(vp_ + ii * 32 + t * 16, pacc[t][ii]);
+                                    if (rok[ii]) SAVE_ST(vp_ + ii * 32 + t * 16, pacc[t][ii]);
                             }
                         }
                     } else {                // gate
@@ -316,7 +348,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                         for (int t = 0; t < 2; ++t) {
                             gacc[t] = pacc[t];
                             float* tp_ = lane_at(sbase(hq, kHqG + t * 256), bT);
-                            if (SAVE && rok[0]) stg4(tp_, acc4(pacc[t]));
+                            if (SAVE && rok[0]) SAVE_ST4(tp_, acc4(pacc[t]));
                         }
                     }
                 }
@@ -340,7 +372,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                 ps[oD20 + ii * 20] = p[ii];
             }
             float* pp_ = lane_at(sbase(hq, kHqP), bT);
-            if (SAVE && rok[0] && lr < T) stg4(pp_, make_float4(p[0], p[1], p[2], p[3]));      // p^T tile
+            if (SAVE && rok[0] && lr < T) SAVE_ST4(pp_, make_float4(p[0], p[1], p[2], p[3]));      // p^T tile
             wave_lds_sync();
             const float4 pa = lds4(ps + oA20);      // A[i = lr][j = 4 lq + m]; B[j = 4 lq + m][d] = the v accumulators
             zero_acc(o);
@@ -364,7 +396,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                     const float val = o[t][ii] * fast_sigmoid(gacc[t][ii]);
                     if (rok[ii]) {
                         as_[oDLW + ii * LW + t * 16] = val;
-                        if (SAVE) stg(ap_ + ii * kRDm + t * 16, val);
+                        if (SAVE) SAVE_ST(ap_ + ii * kRDm + t * 16, val);
                     }
                 }
         }
@@ -391,7 +423,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         }
         CF_STAMP8(4);
         __syncthreads();
-        if (w < 4) ln_fwd_tile16(ts, LD, ln1, row0, T, SAVE ? P.xh1 : nullptr, P.rs1, SAVE ? P.y1 : nullptr);
+        if (w < 4) ln_fwd_tile16<(CF_SAVE_NT & 4) != 0>(ts, LD, ln1, row0, T, SAVE ? P.xh1 : nullptr, P.rs1, SAVE ? P.y1 : nullptr);
         CF_STAMP8(5);
         __syncthreads();
         // ---- FFN (modules.py:100-101)
@@ -412,7 +444,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                     for (int ii = 0; ii < 4; ++ii) {
                         hv[ii] = fmaxf(acc[t][ii] + b1v[t], 0.f);
                         hs[oDLH + ii * LH + t * 16] = hv[ii];
-                        if (SAVE && rok[ii]) stg(hp + ii * DFF + t * 16, hv[ii]);
+                        if (SAVE && rok[ii]) SAVE_ST(hp + ii * DFF + t * 16, hv[ii]);
                     }
                 }
             } else {
@@ -424,7 +456,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                 for (int ii = 0; ii < 4; ++ii) {
                     hv[ii] = fmaxf((acc[0][ii] + acc[1][ii]) + b1v[0], 0.f);
                     hs[oDLH + ii * LH] = hv[ii];
-                    if (SAVE && rok[ii]) stg(hp + ii * DFF, hv[ii]);
+                    if (SAVE && rok[ii]) SAVE_ST(hp + ii * DFF, hv[ii]);
                 }
             }
         }
@@ -445,7 +477,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         }
         CF_STAMP8(7);
         __syncthreads();
-        if (w < 4) ln_fwd_tile16(xs, LD, ln2, row0, T, SAVE ? P.xh2 : nullptr, P.rs2, P.xout);
+        if (w < 4) ln_fwd_tile16<(CF_SAVE_NT & 4) != 0>(xs, LD, ln2, row0, T, SAVE ? P.xh2 : nullptr, P.rs2, P.xout);
         CF_STAMP8(8);
         __syncthreads();
     }
@@ -528,8 +560,8 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             const float* xp = lane_at(sbase(Q.xh2, row0 * kD), bL);
             const float* rp = lane_at(sbase(Q.rs2, row0), bR);
             if (llive) {
-                l2x0 = ldg4(xp);
-                l2x1 = ldg4(xp + 4);
+                l2x0 = BWD_LD4(xp);
+                l2x1 = BWD_LD4(xp + 4);
                 l2rs = ldg(rp);
             }
         }
@@ -546,7 +578,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
 #pragma unroll
         for (int t = 0; t < (DFF == 256 ? 2 : 1); ++t)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) hm[t][ii] = ldg(lane_at(sbase(P.hdn, row0 * DFF + w * HW), zHc[ii]) + t * 16);
+            for (int ii = 0; ii < 4; ++ii) hm[t][ii] = SAVE_LD(lane_at(sbase(P.hdn, row0 * DFF + w * HW), zHc[ii]) + t * 16);
         CF_STAMP8(1);
         __syncthreads();
         // ---- dpre1 = (dt2 W2) . relu'
@@ -566,7 +598,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
                     for (int ii = 0; ii < 4; ++ii) {
                         const float vv = hm[t][ii] > 0.f ? acc[t][ii] : 0.f;
                         wide[oDLH + ii * LH + t * 16] = vv;
-                        if (rok[ii]) stg(dpp + ii * DFF + t * 16, vv);
+                        if (rok[ii]) BWD_ST(dpp + ii * DFF + t * 16, vv);
                     }
                 }
             } else {
@@ -575,7 +607,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
                 for (int ii = 0; ii < 4; ++ii) {
                     const float vv = hm[0][ii] > 0.f ? acc[0][ii] + acc[1][ii] : 0.f;
                     wide[oDLH + ii * LH] = vv;
-                    if (rok[ii]) stg(dpp + ii * DFF, vv);
+                    if (rok[ii]) BWD_ST(dpp + ii * DFF, vv);
                 }
             }
         }
@@ -589,8 +621,8 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             l1ga = ldg4(lane_at(P.g1, lr * 32));
             l1gb = ldg4(lane_at(P.g1, lr * 32) + 4);
             if (llive) {
-                l1x0 = ldg4(lane_at(sbase(P.xh1, row0 * kD), bL));
-                l1x1 = ldg4(lane_at(sbase(P.xh1, row0 * kD), bL) + 4);
+                l1x0 = BWD_LD4(lane_at(sbase(P.xh1, row0 * kD), bL));
+                l1x1 = BWD_LD4(lane_at(sbase(P.xh1, row0 * kD), bL) + 4);
                 l1rs = ldg(lane_at(sbase(P.rs1, row0), bR));
             }
         }
@@ -603,7 +635,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             for (int ii = 0; ii < 4; ++ii) {
                 const float vv = (acc[0][ii] + acc[1][ii]) + t2[oDLD + ii * LD];
                 ds[oDLD + ii * LD] = vv;
-                if (rok[ii]) stg(lane_at(sbase(P.dy1, row0 * kD + w * 16), zD) + ii * kD, vv);
+                if (rok[ii]) BWD_ST(lane_at(sbase(P.dy1, row0 * kD + w * 16), zD) + ii * kD, vv);
             }
         }
         CF_STAMP8(3);
@@ -619,22 +651,22 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             const float* vp = lane_at(sbase(P.hq, hq0 + kHqV), bVr) + t * 16;
             gT[t] = kT[t] = qT[t] = vr[t] = f4z();
             if (rok[0]) {
-                gT[t] = ldg4(gp);
-                kT[t] = ldg4(kp);
-                qT[t] = ldg4(qp);
+                gT[t] = SAVE_LD4(gp);
+                kT[t] = SAVE_LD4(kp);
+                qT[t] = SAVE_LD4(qp);
             }
-            if (lr < T) vr[t] = ldg4(vp);
+            if (lr < T) vr[t] = SAVE_LD4(vp);
         }
         float4 pT = f4z();      // lane (j = lr, lq): p[4 lq + ii][j]
         {
             const float* pp = lane_at(sbase(P.hq, hq0 + kHqP), bT);
-            if (rok[0] && lr < T) pT = ldg4(pp);
+            if (rok[0] && lr < T) pT = SAVE_LD4(pp);
         }
         float av[2][4];      // gated attention output of the head (forward); rows >= T read row T - 1
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) av[t][ii] = ldg(lane_at(sbase(P.a, row0 * kRDm + w * 32), zAc[ii]) + t * 16);
+            for (int ii = 0; ii < 4; ++ii) av[t][ii] = SAVE_LD(lane_at(sbase(P.a, row0 * kRDm + w * 32), zAc[ii]) + t * 16);
         CF_STAMP8(4);
         __syncthreads();
         // ---- da = dt1 Wo (the 32 columns of head w), then the attention backward of the head, wave-local
@@ -658,7 +690,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
                     dos[oD36 + ii * 36 + t * 16] = dov[t][ii];
                     if (rok[ii]) {
                         dqk[oDQ + ii * kQkLd + 3 * kRDm + t * 16] = dgate;
-                        stg(lane_at(sbase(dg, ii * kRW + 3 * kRDm), zQ) + t * 16, dgate);
+                        BWD_ST(lane_at(sbase(dg, ii * kRW + 3 * kRDm), zQ) + t * 16, dgate);
                     }
                 }
             }
@@ -700,9 +732,9 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
                         dqk[o + kRDm] = dk[t][ii];
                         dqk[o + 2 * kRDm] = dv[t][ii];
                         float* dgi = lane_at(sbase(dg, ii * kRW), zQ) + t * 16;
-                        stg(dgi, dq[t][ii]);
-                        stg(dgi + kRDm, dk[t][ii]);
-                        stg(dgi + 2 * kRDm, dv[t][ii]);
+                        BWD_ST(dgi, dq[t][ii]);
+                        BWD_ST(dgi + kRDm, dk[t][ii]);
+                        BWD_ST(dgi + 2 * kRDm, dv[t][ii]);
                     }
         }
         CF_STAMP8(5);
@@ -718,7 +750,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             for (int ii = 0; ii < 4; ++ii) {
                 const float vv = ((acc[0][ii] + acc[1][ii]) + (acc[2][ii] + acc[3][ii])) + ds[oDLD + ii * LD];
                 ds[oDLD + ii * LD] = vv;
-                if (rok[ii]) stg(lane_at(sbase(P.dxin, row0 * kD + w * 16), zD) + ii * kD, vv);
+                if (rok[ii]) BWD_ST(lane_at(sbase(P.dxin, row0 * kD + w * 16), zD) + ii * kD, vv);
             }
         }
         CF_STAMP8(6);
