@@ -1725,6 +1725,9 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col,
 // Streaming (nt) loads and stores for the optimiser state in the tile epilogues: every element is touched once per step, and as plain
 // accesses the 128 MB of them sweep the L2s that the operand rows of the other tiles -- and, under the riders, the tables of the trunk --
 // live in.  A/B on one box: riders only 0.568 -> 0.565 ms, all epilogues 0.567 -> 0.558.
+#ifndef CF_ADAM_NT      // the stand-alone AdamW stream (data-parallel path) likewise
+#define CF_ADAM_NT 1
+#endif
 #ifndef CF_OPT_NT
 #define CF_OPT_NT 1
 #endif
@@ -2148,10 +2151,10 @@ __device__ __forceinline__ void adamw_range(float* __restrict__ p, const float* 
                                             long long n4, float decay, float one_m_b1, float b2, float one_m_b2, float step_size, float bc2_sqrt,
                                             float eps, long long first, long long stride) {
     for (long long i = first; i < n4; i += stride) {
-        float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float4 pp = CF_ADAM_NT ? ldg4_nt(p + 4 * i) : reinterpret_cast<float4*>(p)[i];
+        const float4 gg = CF_ADAM_NT ? ldg4_nt(g + 4 * i) : reinterpret_cast<const float4*>(g)[i];
+        float4 mm = CF_ADAM_NT ? ldg4_nt(m + 4 * i) : reinterpret_cast<float4*>(m)[i];
+        float4 vv = CF_ADAM_NT ? ldg4_nt(v + 4 * i) : reinterpret_cast<float4*>(v)[i];
         float* pa = reinterpret_cast<float*>(&pp);
         const float* ga = reinterpret_cast<const float*>(&gg);
         float* ma = reinterpret_cast<float*>(&mm);
@@ -2159,9 +2162,15 @@ __device__ __forceinline__ void adamw_range(float* __restrict__ p, const float* 
         const AdamFuse o{nullptr, nullptr, nullptr, nullptr, decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps, 0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) adamw_elem(pa[k], ga[k], ma[k], va[k], o);      // (one definition of the update for both forms)
-        reinterpret_cast<float4*>(p)[i] = pp;
-        reinterpret_cast<float4*>(m)[i] = mm;
-        reinterpret_cast<float4*>(v)[i] = vv;
+        if (CF_ADAM_NT) {
+            stg4_nt(p + 4 * i, pp);
+            stg4_nt(m + 4 * i, mm);
+            stg4_nt(v + 4 * i, vv);
+        } else {
+            reinterpret_cast<float4*>(p)[i] = pp;
+            reinterpret_cast<float4*>(m)[i] = mm;
+            reinterpret_cast<float4*>(v)[i] = vv;
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
