@@ -1725,6 +1725,9 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col,
 // Streaming (nt) loads and stores for the optimiser state in the tile epilogues: every element is touched once per step, and as plain
 // accesses the 128 MB of them sweep the L2s that the operand rows of the other tiles -- and, under the riders, the tables of the trunk --
 // live in.  A/B on one box: riders only 0.568 -> 0.565 ms, all epilogues 0.567 -> 0.558.
+#ifndef CF_RIDER_OPND_NT      // the riders' operand rows as well (151 MB streamed through the L2s the trunk works in: 0.5415 -> 0.5388 ms)
+#define CF_RIDER_OPND_NT 1
+#endif
 #ifndef CF_ADAM_NT      // the stand-alone AdamW stream (data-parallel path) likewise
 #define CF_ADAM_NT 1
 #endif
@@ -1922,8 +1925,8 @@ __device__ __forceinline__ void wgrad_tile_wave(const WgTile& t, int batch, cons
                     const int m = st * kWgM + sm + 4 * p;
                     if (FAST) {      // (see wg_tile_interior; rows past the end re-read the last one and are zeroed on their way into LDS)
                         const int mc = min(m, M - 1);
-                        ra[p] = ldg4(sg.A + (size_t)mc * sg.lda + t.n0 + sc);
-                        rb[p] = ldg4(sg.B + (size_t)mc * sg.ldb + t.k0 + sc);
+                        ra[p] = CF_RIDER_OPND_NT ? ldg4_nt(sg.A + (size_t)mc * sg.lda + t.n0 + sc) : ldg4(sg.A + (size_t)mc * sg.lda + t.n0 + sc);
+                        rb[p] = CF_RIDER_OPND_NT ? ldg4_nt(sg.B + (size_t)mc * sg.ldb + t.k0 + sc) : ldg4(sg.B + (size_t)mc * sg.ldb + t.k0 + sc);
                     } else {
                         ra[p] = rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (m < M) {
