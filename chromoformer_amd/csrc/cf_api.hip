@@ -1094,6 +1094,7 @@ static void head_fwd_args(const cf_handle* h, int B, float* logits_user, HeadFwd
     a.T = c.i_max + 1;
     a.n_res = c.n_res;
     a.n_out = c.n_out;
+    a.tdbg = getenv("CF_STAMP_HEAD") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 128 : nullptr;      // tools/head_stamps.py
 }
 
 // ------------------------------------------------------------------------------------
@@ -1458,6 +1459,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         a.T = T;
         a.n_res = nres;
         a.n_out = c.n_out;
+        a.tdbg = getenv("CF_STAMP_HEAD") ? reinterpret_cast<unsigned long long*>(h->tdbg) + 128 : nullptr;
         if (h->head_deferred) {      // the forward pass left the head to this call: forward, loss, backward in one launch
             if (!labels) return fail("cf_backward: cf_forward(save_for_backward = 2) needs the fused loss (labels)");
             HeadFwdArgs f;

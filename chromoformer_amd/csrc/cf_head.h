@@ -17,8 +17,13 @@ struct HeadFwdArgs {
     float *hin, *h1, *logits;    // saved for the backward pass: [B, n_res*128], [B, 128], [B, n_out]
     float* logits_user;          // caller's copy (may be null)
     int B, T, n_res, n_out;
+    unsigned long long* tdbg;    // optional shader-clock stamps of workgroup 0 (tools/head_stamps.py)
 };
 constexpr int kHeadThreads = 512;      // eight waves: wave w owns 16 of the 128 hidden columns
+#define CF_HSTAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (a.tdbg && blockIdx.x == 0 && threadIdx.x == 0) a.tdbg[slot] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 __device__ __forceinline__ void head_fwd_body(const HeadFwdArgs& a) {
     // all n_res resolution chunks of the concatenated input are fetched at once into one [16][n_res*128] tile (one barrier), then
     // every wave runs ONE product over the whole reduction range with a continuous operand ring
@@ -28,6 +33,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadFwdArgs& a) {
     const int row0 = blockIdx.x * kTile, K = a.n_res * kD, tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
     const int col0 = w * 16;
+    CF_HSTAMP(0);
     // The whole operand stream of the wave (16 hidden columns x K = n_res * 128: 1 KB per 16-deep k-block) is requested at once:
     // a 3-chunk ring covers ~800 cycles of MFMA work against ~2 K cycles of L2 latency, i.e. the product used to stall on every
     // chunk (12 x ~1.3 K cycles); 24 sixteen-byte loads in flight cost 96 registers this kernel has to spare.
@@ -73,6 +79,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadFwdArgs& a) {
             for (int k = 0; k < kD / 16; ++k) w2v[c][k] = ldg(a.w2 + min(c, a.n_out - 1) * kD + sub + 16 * k);
     }
     __syncthreads();
+    CF_HSTAMP(1);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     {
         const float* ap = &xs[lr][lq * 4];
@@ -94,6 +101,7 @@ __device__ __forceinline__ void head_fwd_body(const HeadFwdArgs& a) {
         hs[row][col] = v;
         if (row0 + row < a.B) stg(a.h1 + (size_t)(row0 + row) * kD + col, v);
     }
+    CF_HSTAMP(2);
     __syncthreads();
     if (tid < 256) {   // logits: 16 lanes per gene
         const int row = tid >> 4, sub = tid & 15, g = row0 + row;
@@ -125,6 +133,7 @@ struct HeadBwdArgs {
     float* loss_user;            // may be null
     float gscale;
     int B, T, n_res, n_out;
+    unsigned long long* tdbg;
 };
 __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
     __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];
@@ -145,6 +154,7 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
         w2b[u] = ldg(a.w2 + (a.n_out == 2 ? kD : 0) + j);
         h1v[u] = ldg(a.h1 + (size_t)g * kD + j);
     }
+    CF_HSTAMP(3);
     if (tid < kTile) {        // loss and d loss / d logits of one gene
         const int g = row0 + tid;
         float l = 0.f, d0 = 0.f, d1 = 0.f;
@@ -174,6 +184,7 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
         dl[tid][1] = d1;
         li[tid] = l;
     }
+    CF_HSTAMP(4);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NDH; ++u) {      // dh1 = (dlogits W2) * (h1 > 0)
@@ -184,6 +195,7 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
         ds[row][j] = v;
         if (g < a.B) stg(a.dh1 + (size_t)g * kD + j, v);
     }
+    CF_HSTAMP(5);
     __syncthreads();
     for (int jb = w; jb < K / 64; jb += kHeadThreads / 64) {          // dhin[:, 64 jb ..] = dh1 . W1[:, 64 jb ..]
         FragNN<4, 8> f;
@@ -203,6 +215,7 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
             }
         }
     }
+    CF_HSTAMP(6);
     // (last: the fences of this block cost a few thousand cycles, and nothing in the kernel waits for the loss)
     if (a.labels && tid == 0) {       // mean loss: per-workgroup partials, summed in workgroup order by the last to arrive
         float s = 0.f;
@@ -220,6 +233,7 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwdArgs& a) {
             *counter = 0u;
         }
     }
+    CF_HSTAMP(7);
 }
 
 __global__ __launch_bounds__(kHeadThreads) void k_head_bwd(HeadBwdArgs a) { head_bwd_body(a); }
