@@ -100,8 +100,9 @@ static int check_config(const cf_config& c) {
     if (c.d_emb != kD)
         return fail("d_emb = %d is not supported: the HIP path implements d_emb = 128 only (the reference's default, net.py:277; "
                     "configs/default.yaml embed.d_model); use the reference implementation for other widths", c.d_emb);
-    if (c.d_head != kD)
-        return fail("d_head = %d is not supported: the HIP path implements d_head = 128 only (the reference's default, net.py:278)", c.d_head);
+    if (c.d_head < 4 || c.d_head > kHeadGenMaxDH || (c.d_head & 3))
+        return fail("d_head = %d is not supported (net.py:278): multiples of 4 in 4..%d (128, the reference's default, runs the matrix-core head "
+                    "kernels, other widths a vector-ALU head)", c.d_head, kHeadGenMaxDH);
     if (c.n_feats < 1 || c.n_feats > 8) return fail("n_feats must be in 1..8 (got %d)", c.n_feats);
     if (c.n_out != 1 && c.n_out != 2) return fail("n_out must be 1 or 2");
     if (c.n_res != 3) return fail("exactly 3 resolutions are supported (fc_head is Linear(3*d_emb, .), net.py:327)");
@@ -416,13 +417,13 @@ static void plan_workspace(cf_handle* h) {
         }
     }
     h->hin = h->ws_get("H.in", MB * 3 * kD);
-    h->h1 = h->ws_get("H.h1", MB * kD);
+    h->h1 = h->ws_get("H.h1", MB * c.d_head);
     h->logits = h->ws_get("H.logits", MB * c.n_out);
     h->dlogits = h->ws_get("dH.logits", MB * c.n_out);
-    h->dh1 = h->ws_get("dH.h1", MB * kD);
+    h->dh1 = h->ws_get("dH.h1", MB * c.d_head);
     h->dhin = h->ws_get("dH.in", MB * 3 * kD);
     h->loss = h->ws_get("H.loss", 4);
-    h->loss_part = h->ws_get("H.loss_part", MB / kTile + 1);
+    h->loss_part = h->ws_get("H.loss_part", MB + 1);      // (per 16-gene tile; per gene in the generic-width head)
     h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 64);      // shader-clock stamps (uint64) of the fused Regulation kernels
 }
 
@@ -660,9 +661,9 @@ static int build_tables(cf_handle* h) {
             push_cs(csR, b.dgam, kRH, kRH, 1, 1, h->G_(lp + "self_att.gamma_f"));
         }
     }
-    push_wg(wgR, wg1(h->dh1, kD, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, kD, 3 * kD));
-    push_wg(wgR, wg1(h->dlogits, c.n_out, h->h1, kD, 1, h->G_("fc_head.2.weight"), kD, c.n_out, kD));
-    push_cs(csR, h->dh1, kD, kD, 1, 1, h->G_("fc_head.0.bias"));
+    push_wg(wgR, wg1(h->dh1, c.d_head, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, c.d_head, 3 * kD));
+    push_wg(wgR, wg1(h->dlogits, c.n_out, h->h1, c.d_head, 1, h->G_("fc_head.2.weight"), c.d_head, c.n_out, c.d_head));
+    push_cs(csR, h->dh1, c.d_head, c.d_head, 1, 1, h->G_("fc_head.0.bias"));
     push_cs(csR, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
 
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
@@ -1076,6 +1077,23 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
     return 0;
 }
 
+static void head_gen_args(const cf_handle* h, int B, float* logits_user, HeadGenArgs& a) {      // d_head != 128: the vector-ALU head (cf_head.h)
+    const cf_config& c = h->cfg;
+    memset(&a, 0, sizeof a);
+    for (int r = 0; r < c.n_res; ++r) {
+        a.xl[r] = h->Rx[r][c.reg_layers];
+        a.x0[r] = h->Rx[r][0];
+        a.dxl[r] = h->dRx[r][c.reg_layers];
+    }
+    a.w1 = h->P_("fc_head.0.weight");
+    a.b1 = h->P_("fc_head.0.bias");
+    a.w2 = h->P_("fc_head.2.weight");
+    a.b2 = h->P_("fc_head.2.bias");
+    a.hin = h->hin, a.h1 = h->h1, a.logits = h->logits, a.logits_user = logits_user;
+    a.dlogits = h->dlogits, a.dh1 = h->dh1, a.dhin = h->dhin;
+    a.loss = h->loss, a.loss_part = h->loss_part;
+    a.B = B, a.T = c.i_max + 1, a.n_res = c.n_res, a.n_out = c.n_out, a.DH = c.d_head;
+}
 static void head_fwd_args(const cf_handle* h, int B, float* logits_user, HeadFwdArgs& a) {
     const cf_config& c = h->cfg;
     for (int r = 0; r < c.n_res; ++r) {
@@ -1419,7 +1437,12 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
     }
     h->head_deferred = save == 2;
     h->deferred_logits_user = logits;
-    if (save != 2) {   // head (save = 2: together with the loss and its backward in cf_backward_part, one launch)
+    if (save != 2 && c.d_head != kD) {
+        HeadGenArgs a;
+        head_gen_args(h, B, logits, a);
+        hipLaunchKernelGGL(k_head_gen_fwd, dim3(B), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_head_gen_fwd");
+    } else if (save != 2) {   // head (save = 2: together with the loss and its backward in cf_backward_part, one launch)
         HeadFwdArgs a;
         head_fwd_args(h, B, logits, a);
         hipLaunchKernelGGL(k_head_fwd, dim3(tiles_of(B)), dim3(kHeadThreads), 0, st, a);
@@ -1440,7 +1463,21 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
     const float scale_c = sqrtf(64.f);
-    if (parts & 1) {   // loss + head
+    if ((parts & 1) && c.d_head != kD) {      // loss + head, any hidden width
+        if (h->head_deferred && !labels) return fail("cf_backward: cf_forward(save_for_backward = 2) needs the fused loss (labels)");
+        HeadGenArgs a;
+        head_gen_args(h, B, h->head_deferred ? h->deferred_logits_user : nullptr, a);
+        a.labels = labels;
+        a.loss_user = loss_out;
+        a.gscale = loss_scale;
+        if (h->head_deferred) {
+            hipLaunchKernelGGL(k_head_gen_fwd, dim3(B), dim3(256), 0, st, a);
+            LAUNCH_CHECK("k_head_gen_fwd");
+            h->head_deferred = false;
+        }
+        hipLaunchKernelGGL(k_head_gen_bwd, dim3(B), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_head_gen_bwd");
+    } else if (parts & 1) {   // loss + head
         HeadBwdArgs a;
         a.logits = h->logits;
         a.labels = labels;

@@ -246,4 +246,120 @@ __global__ __launch_bounds__(kHeadThreads) void k_head_train(HeadFwdArgs f, Head
     head_bwd_body(b);
 }
 
+// ---- any other hidden width (net.py:278 leaves d_head free): one 256-thread workgroup per gene, vector ALUs, two launches.  The
+//      default width runs the matrix-core kernels above; this path costs ~25 us more per step and exists so that such a model runs at all.
+struct HeadGenArgs {
+    const float* xl[kMaxRes];    // Regulation output [B*T, 128]
+    const float* x0[kMaxRes];    // Regulation input  [B*T, 128]
+    const float *w1, *b1, *w2, *b2;      // fc_head.0.weight [DH, n_res*128] (row-major), .bias, fc_head.2.weight [n_out, DH], .bias
+    float *hin, *h1, *logits, *logits_user;
+    const void* labels;
+    float *dlogits, *dh1, *dhin;
+    float* dxl[kMaxRes];
+    float *loss, *loss_part, *loss_user;
+    float gscale;
+    int B, T, n_res, n_out, DH;
+};
+constexpr int kHeadGenMaxDH = 1024;
+__global__ __launch_bounds__(256) void k_head_gen_fwd(HeadGenArgs a) {
+    __shared__ float xs[kMaxRes * kD];
+    __shared__ float hs[kHeadGenMaxDH];
+    const int g = blockIdx.x, tid = threadIdx.x, K = a.n_res * kD, DH = a.DH;
+    for (int k = tid; k < K; k += 256) {
+        const int r = k >> 7, c = k & 127;
+        const size_t o = (size_t)g * a.T * kD + c;
+        const float v = ldg(a.xl[r] + o) + ldg(a.x0[r] + o);
+        xs[k] = v;
+        stg(a.hin + (size_t)g * K + k, v);
+    }
+    __syncthreads();
+    const int part = tid & 3, kq = K >> 2;      // four lanes per hidden unit, a quarter of the reduction each
+    for (int j0 = 0; j0 < DH; j0 += 64) {
+        const int j = j0 + (tid >> 2);
+        float s = 0.f;
+        if (j < DH) {
+            const float* wr = a.w1 + (size_t)j * K + part * kq;
+            const float* xp = xs + part * kq;
+            for (int k = 0; k < kq; ++k) s = fmaf(ldg(wr + k), xp[k], s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (j < DH && part == 0) {
+            const float h = fmaxf(s + ldg(a.b1 + j), 0.f);
+            hs[j] = h;
+            stg(a.h1 + (size_t)g * DH + j, h);
+        }
+    }
+    __syncthreads();
+    if (tid < 64)
+        for (int c = 0; c < a.n_out; ++c) {
+            float s = 0.f;
+            for (int j = tid; j < DH; j += 64) s = fmaf(hs[j], ldg(a.w2 + (size_t)c * DH + j), s);
+            s = wave_sum(s);
+            if (tid == 0) {
+                const float v = s + ldg(a.b2 + c);
+                a.logits[g * a.n_out + c] = v;
+                if (a.logits_user) a.logits_user[g * a.n_out + c] = v;
+            }
+        }
+}
+__global__ __launch_bounds__(256) void k_head_gen_bwd(HeadGenArgs a) {
+    __shared__ float ds[kHeadGenMaxDH];
+    __shared__ float dl[2];
+    const int g = blockIdx.x, tid = threadIdx.x, K = a.n_res * kD, DH = a.DH;
+    if (tid == 0) {      // loss and d loss / d logits of the gene (CrossEntropyLoss / MSELoss, mean over the batch: train.py:156, 193)
+        float l = 0.f, d0 = 0.f, d1 = 0.f;
+        if (!a.labels) {
+            d0 = a.dlogits[g * a.n_out];
+            if (a.n_out == 2) d1 = a.dlogits[g * 2 + 1];
+        } else if (a.n_out == 1) {
+            const float d = a.logits[g] - reinterpret_cast<const float*>(a.labels)[g];
+            l = d * d;
+            d0 = 2.0f * d * a.gscale / (float)a.B;
+            a.dlogits[g] = d0;
+        } else {
+            const int y = (int)reinterpret_cast<const long long*>(a.labels)[g];
+            const float z0 = a.logits[g * 2], z1 = a.logits[g * 2 + 1];
+            const float m = fmaxf(z0, z1);
+            const float lse = m + logf(expf(z0 - m) + expf(z1 - m));
+            l = lse - (y ? z1 : z0);
+            d0 = (expf(z0 - lse) - (y == 0 ? 1.f : 0.f)) * a.gscale / (float)a.B;
+            d1 = (expf(z1 - lse) - (y == 1 ? 1.f : 0.f)) * a.gscale / (float)a.B;
+            a.dlogits[g * 2] = d0;
+            a.dlogits[g * 2 + 1] = d1;
+        }
+        dl[0] = d0;
+        dl[1] = d1;
+        a.loss_part[g] = l;
+    }
+    __syncthreads();
+    for (int j = tid; j < DH; j += 256) {      // dh1 = (dlogits W2) * (h1 > 0)
+        float s = dl[0] * ldg(a.w2 + j);
+        if (a.n_out == 2) s = fmaf(dl[1], ldg(a.w2 + DH + j), s);
+        const float v = ldg(a.h1 + (size_t)g * DH + j) > 0.f ? s : 0.f;
+        ds[j] = v;
+        stg(a.dh1 + (size_t)g * DH + j, v);
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {       // dhin = dh1 W1; token 0 of the Regulation output gradient receives it
+        float s = 0.f;
+        for (int j = 0; j < DH; ++j) s = fmaf(ds[j], ldg(a.w1 + (size_t)j * K + k), s);
+        stg(a.dhin + (size_t)g * K + k, s);
+        stg(a.dxl[k >> 7] + (size_t)g * a.T * kD + (k & 127), s);
+    }
+    if (a.labels && tid == 0) {                // mean loss: summed in gene order by the last workgroup to arrive
+        __threadfence();
+        unsigned* counter = reinterpret_cast<unsigned*>(a.loss + 2);
+        if (atomicAdd(counter, 1u) == gridDim.x - 1) {
+            __threadfence();
+            float tot = 0.f;
+            for (int i = 0; i < a.B; ++i) tot += *(volatile float*)(a.loss_part + i);
+            tot /= (float)a.B;
+            a.loss[0] = tot;
+            if (a.loss_user) a.loss_user[0] = tot;
+            *counter = 0u;
+        }
+    }
+}
+
 }  // namespace cf

@@ -34,7 +34,7 @@ extern "C" {
 typedef struct cf_config {
     int n_feats;            /* histone marks per bin (7)                          net.py:276  */
     int d_emb;              /* 128                                                net.py:277  */
-    int d_head;             /* 128                                                net.py:278  */
+    int d_head;             /* 128 (any multiple of 4 <= 1024; != 128: slower head) net.py:278  */
     int n_out;              /* 2 = classifier, 1 = regressor                      net.py:329,427 */
     int n_res;              /* number of resolutions (3)                          net.py:297  */
     int binsizes[CF_MAX_RES];   /* e.g. 2000, 500, 100 (only used for names)               */

@@ -57,12 +57,16 @@ def test_unsupported_configs_are_rejected_loudly():
     assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
     assert b"embed.n_layers" in _lib.lib().cf_last_error()
     # widths the reference leaves free (net.py:277-278) and this library does not implement: refused by name, with the reference site
-    for field, site in (("d_emb", b"net.py:277"), ("d_head", b"net.py:278")):
+    # (d_head: any multiple of 4 up to 1024 -- 128 on the matrix cores, other widths on the vector ALUs; d_emb: 128 only)
+    for field, value, site in (("d_emb", 256, b"net.py:277"), ("d_head", 130, b"net.py:278"), ("d_head", 2048, b"net.py:278")):
         cfg = _cfg()
-        setattr(cfg, field, 256)
+        setattr(cfg, field, value)
         assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
         err = _lib.lib().cf_last_error()
         assert field.encode() in err and site in err and b"not supported" in err
+    cfg = _cfg()
+    cfg.d_head = 96
+    assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) == 0
 
 
 def test_model_state_dict_and_seeded_init_match_golden():
