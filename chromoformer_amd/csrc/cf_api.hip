@@ -606,7 +606,7 @@ static int build_tables(cf_handle* h) {
             push_wg(wg, wg1(h->dxp0[r], kD, h->Rx[r][0], T * kD, 1, h->G_(pre + "lin_proj_p.weight"), kD, kD, kD));
             LpJob j;
             memset(&j, 0, sizeof j);
-            // lin_proj_pcre collects two terms per layer (pair_layers <= 4 -> <= kLpMaxSeg segments)
+            // lin_proj_pcre collects two terms per layer (pair_layers <= 8 -> <= kLpMaxSeg segments)
             int ns = 0;
             for (int l = 0; l < c.pair_layers; ++l) {
                 j.seg[ns++] = WgSeg{h->P[r][l].dxbar, h->P[r][l].w, kD, 8, 2 * S};

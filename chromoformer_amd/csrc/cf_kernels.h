@@ -2043,7 +2043,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgTile* __restrict__ tiles,
 // Weight gradient of the 7-mark projections (lin_proj / lin_proj_pcre, [128, F]): too narrow
 // for an MFMA tile.  One workgroup sums a chunk of 8 genes into partial[chunk][128*F]; the
 // chunks are added by k_colsum.   dW[e][f] = sum over segments, sum_m A[m][e] * B[m][f]
-constexpr int kLpMaxSeg = 8;      // two terms per Pairwise layer: up to four layers
+constexpr int kLpMaxSeg = 16;     // two terms per Pairwise layer: up to eight layers
 struct LpJob {
     WgSeg seg[kLpMaxSeg];
     int nseg;

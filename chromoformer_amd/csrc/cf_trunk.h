@@ -23,7 +23,7 @@
 
 namespace cf {
 
-constexpr int kMaxPairLayers = 4;      // = kLpMaxSeg / 2
+constexpr int kMaxPairLayers = 4;      // (of the fused trunk kernels; the stand-alone kernels take up to kLpMaxSeg / 2 = 8)
 
 // one centre-row layer of one resolution: operands, saved activations, gradient buffers (device pointers, fixed at cf_bind)
 struct CentreLayerDev {
@@ -468,11 +468,11 @@ CF_PHASE void trunk_post_bwd_e(TrunkCtx c, float* smem) {
 constexpr int kLpRowsMax = 80;
 CF_PHASE void trunk_lp(const LpJob* jobs, int r, int g, int batch, float* smem) {
     const int tid = threadIdx.x;
-    const LpJob* J = jobs + 2 * r;      // [0] Embedding (<= 3 segments), [1] Pairwise (<= kLpMaxSeg)
+    const LpJob* J = jobs + 2 * r;      // [0] Embedding (<= 3 segments), [1] Pairwise (<= 2 kMaxPairLayers)
     float* As = smem;                   // [rows][128]
     float* Bs = smem + kLpRowsMax * kD; // [rows][8]
     (void)batch;
-    constexpr int NSEG = 3 + kLpMaxSeg;
+    constexpr int NSEG = 3 + 2 * kMaxPairLayers;
     const int ns0 = ldc(&J[0].nseg), ns1 = ldc(&J[1].nseg);
     // every segment holds <= 16 rows of 128 floats = one float4 per thread: all segments are requested before anything is put
     float4 va[NSEG], vb[NSEG];

@@ -18,6 +18,7 @@ VARIANTS = {
                            pairwise_interaction=dict(n_layers=1, n_heads=2, d_model=128, d_ff=128),
                            embed=dict(n_layers=1, n_heads=2, d_model=128, d_ff=256)),
     "three_pairwise_layers": dict(pairwise_interaction=dict(n_layers=3, n_heads=2, d_model=128, d_ff=256)),
+    "six_pairwise_layers": dict(pairwise_interaction=dict(n_layers=6, n_heads=2, d_model=128, d_ff=256)),
     "deep_reg": dict(regulation=dict(n_layers=8, n_heads=8, d_model=256, d_ff=256)),
     "d_head_96": dict(d_head=96),                                      # fc_head widths other than 128: the vector-ALU head (cf_head.h)
     "d_head_256": dict(d_head=256),
