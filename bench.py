@@ -106,6 +106,39 @@ def train_loop_rate(model, lr, steps, store_genes, regime, dev):
                     "the step graph, running metrics (train.py:205-232) on every 10-step window"}
 
 
+def val_auroc_run(n_genes=256, epochs=3):
+    """BASELINE.json's metric names `val AUROC` beside the rate: a SHORT end-to-end run of the shipped entrypoint
+    (`chromoformer_amd.train.main`: raw fp16 .npy regions in the reference's on-disk format -> GPU binning -> `epochs` epochs at bsz 64
+    -> validation on the held-out fold -> checkpoint) on a synthetic Roadmap-style cell line with a planted signal (expressed genes
+    carry more marks; tests/synth_data.py -- the real Roadmap tracks are not in the image).  Reports the last validation AUROC the
+    entrypoint printed; a number about the plumbing (labels, folds, metrics, optimiser all wired the reference's way), not about
+    biology."""
+    import contextlib
+    import io
+    import re
+    import tempfile
+    import yaml
+    from tests.synth_data import make_dataset
+    from chromoformer_amd import train as cf_train
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory() as d:
+        meta = make_dataset(os.path.join(d, "npy"), n_genes=n_genes, seed=7)
+        t_data = time.perf_counter() - t0
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "chromoformer_amd", "configs", "default.yaml")))
+        cfg["bsz"], cfg["num_epoch"] = 64, epochs + 1
+        yaml.safe_dump(cfg, open(os.path.join(d, "cfg.yaml"), "w"))
+        buf = io.StringIO()
+        t1 = time.perf_counter()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(buf):
+            cf_train.main(["-o", os.path.join(d, "ck.pt"), "-c", os.path.join(d, "cfg.yaml"), "--exp-id", "bench", "-m", meta,
+                           "-d", os.path.join(d, "npy"), "--fold", "0"])
+        t_train = time.perf_counter() - t1
+    aucs = [float(m.group(1)) for m in re.finditer(r"Validation loss=[^\n]*?auc=([0-9.]+)", buf.getvalue())]
+    return {"value": aucs[-1] if aucs else None, "unit": "percent", "per_epoch": aucs, "epochs": epochs,
+            "train_genes": n_genes * 3 // 4, "val_genes": n_genes // 4, "seconds": {"dataset": round(t_data, 1), "train.main": round(t_train, 1)},
+            "what": "chromoformer_amd.train.main on a synthetic planted-signal cell line (tests/synth_data.make_dataset), fold 0"}
+
+
 def dp_path_ms(model, batch, steps, warmup, dev):
     """Fixed overhead of the data-parallel code path, measurable on ONE GPU: the same step through a one-rank RCCL group
     (two graphs, two all-reduces of the 16.6 MB / 4.6 MB buckets -- in-place no-ops for RCCL at world 1 but launched --,
@@ -230,7 +263,11 @@ def main():
     ap.add_argument("--dp-path", action="store_true", default=None, help="also time the data-parallel code path on a one-rank RCCL group "
                     "(`dp_path_ms_per_step`; default: on for --gpus 1)")
     ap.add_argument("--no-dp-path", dest="dp_path", action="store_false")
-    ap.add_argument("--roofline-kernel", default="k_reg_bwd", help="kernel timed with HIP events: k_reg_bwd (dominant), k_reg_fwd (needs --no-graph), k_wgrad, k_adamw")
+    ap.add_argument("--roofline-kernel", default="k_reg_bwd", help="kernel timed with HIP events: k_reg_bwd (dominant), k_reg_fwd (needs --no-graph), "
+                    "k_trunk_fwd, k_trunk_bwd (the centre-row trunk; bwd includes its rider tiles' time, not their flops), k_wgrad, k_adamw")
+    ap.add_argument("--val-auroc", dest="val_auroc", action="store_true", default=True,
+                    help="also run the entrypoint end to end on a small planted-signal cell line and report its validation AUROC (`val_auroc`; ~10 s)")
+    ap.add_argument("--no-val-auroc", dest="val_auroc", action="store_false")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints a
@@ -249,9 +286,13 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
     # test hooks (tests/test_dp_gpu.py drives the multi-process path on a one-GPU box): every rank on device 0, gloo
     # instead of RCCL (RCCL refuses two ranks on one device)
-    if os.environ.get("CF_SHARE_DEVICE") == "1":
+    share = os.environ.get("CF_SHARE_DEVICE") == "1"
+    if share:
         local = 0
     backend = os.environ.get("CF_DIST_BACKEND", "nccl")
+    if world > 1 and not share and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible to rank %d -- one rank per GPU (set CF_SHARE_DEVICE=1 CF_DIST_BACKEND=gloo "
+                         "only for the one-device test mode)" % (world, torch.cuda.device_count(), rank))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -262,6 +303,13 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
+        # self-check 1: every rank drives its OWN device (a launcher that hands two ranks the same LOCAL_RANK would still "scale")
+        props = torch.cuda.get_device_properties(local)
+        ident = "%s/%d/%s" % (os.uname().nodename, local, getattr(props, "uuid", "") or getattr(props, "pci_bus_id", ""))
+        idents = [None] * world
+        torch.distributed.all_gather_object(idents, ident)
+        if not share and len(set(idents)) != world:
+            raise SystemExit("bench.py: %d ranks on %d distinct devices: %s" % (world, len(set(idents)), idents))
 
     from chromoformer_amd import ChromoformerClassifier
     from chromoformer_amd.engine import Trainer
@@ -294,6 +342,21 @@ def main():
         el = t.item()
     kernel_ms, kernel_n = trainer.timing_read()
 
+    # self-check 2 (outside the timed region): data parallelism means every rank holds the SAME parameters after the same number of
+    # steps -- an all-reduce that silently did nothing (or ran on a subset of the ranks) shows here.  Bit-level checksum of the
+    # trainable range: the sum of its words as integers.
+    checks = None
+    if world > 1:
+        words = model._flat[: model._layout.n_active].view(torch.int32).to(torch.int64)
+        mine = torch.stack([words.sum(), (words * (torch.arange(words.numel(), device=dev) % 65521 + 1)).sum()])
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        agree = all(bool(torch.equal(e, every[0])) for e in every)
+        checks = {"param_checksum_agree": agree, "param_checksum": [int(v) for v in every[0].tolist()], "devices": idents,
+                  "rccl_ranks": world if backend == "nccl" else 0, "backend": backend}
+        if not agree:
+            raise SystemExit("bench.py: ranks disagree on the parameters after %d steps: %s" % (args.warmup + args.steps, [e.tolist() for e in every]))
+
     if rank == 0:
         ms = 1e3 * el / args.steps
         value = BSZ * world * args.steps / el
@@ -305,11 +368,13 @@ def main():
             "config": {"workload": "default config (d_emb 128, i_max 8, binsizes 2000/500/100 -> L 20/80/400), bsz 64 genes per GPU, "
                                    "%s synthetic 7-mark signals, fwd+loss+bwd+allreduce+AdamW" % args.regime,
                        "parallelism": "dp%d" % world, "global_batch": BSZ * world, "hip_graph": bool(args.graph),
-                       "launches_per_step": sum(model.launch_counts()),
+                       "launches_per_step": sum(model.launch_counts()),      # (of the last step: counted at the launch sites, graph replays included)
                        "adamw": "in the epilogue of the gradient reductions (cf_reduce_opt_part)" if trainer.fuse_opt else "own launches"},
             "roofline": roof,
             "loss": round(float(trainer.last_loss()), 6),
         }
+        if checks is not None:
+            out["dp_self_check"] = checks
         if world == 1 and not args.graph:      # the same step replayed as ONE hipGraph + AdamW (what train_epoch does), no events inside
             tg = Trainer(model, lr=3e-5)
             sg = tg.stage(batch)
@@ -325,6 +390,8 @@ def main():
             out["dp_path_ms_per_step"] = dp_path_ms(model, batch, args.steps, args.warmup, dev)
         if world == 1 and args.train_loop_steps > 0:
             out["train_loop"] = train_loop_rate(model, 3e-5, args.train_loop_steps, args.train_loop_genes, args.regime, dev)
+        if world == 1 and args.val_auroc:
+            out["val_auroc"] = val_auroc_run()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         json_out.write(json.dumps(out) + "\n")

@@ -11,6 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CF_LIB_PATH") or os.path.join(_HERE, "libchromoformer_hip.so")      # override: A/B experiments only
+FLAGS_PATH = LIB_PATH + ".flags"       # the CF_HIPCC_FLAGS the library was built with (part of the reuse check of build())
 CSRC = os.path.join(_HERE, "csrc")
 MAX_RES = 3
 BUCKET_REG, BUCKET_PE = 1, 2
@@ -88,6 +89,7 @@ SYMBOLS = {
     "cf_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_backward_part": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "cf_kernel_flops": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int]),
+    "cf_cu_count": (C.c_int, [C.c_void_p]),
     "cf_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cf_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "cf_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -125,17 +127,30 @@ _lib = None
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/ for gfx950 into libchromoformer_hip.so (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/ for gfx950 into libchromoformer_hip.so (hipcc cross-compiles without a GPU).  The library is reused only when
+    it is newer than every source AND was built with the same extra flags (CF_HIPCC_FLAGS, recorded in a sidecar file): an A/B
+    experiment can neither pick up the shipped library silently nor leave its own behind as the shipped one.  Says which it did."""
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "chromoformer_hip.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+    flags = " ".join(os.environ.get("CF_HIPCC_FLAGS", "").split())
+    try:
+        built_with = open(FLAGS_PATH).read().strip()
+    except OSError:
+        built_with = ""
+    fresh = os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)
+    if not force and fresh and built_with == flags:
+        if verbose:
+            print("build: reused %s (newer than all %d sources, flags '%s')" % (LIB_PATH, len(srcs), flags))
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed",
            os.path.join(CSRC, "cf_api.hip"), "-o", LIB_PATH]
-    cmd[6:6] = os.environ.get("CF_HIPCC_FLAGS", "").split()      # experiments (-DCF_...); the shipped library is built without
+    cmd[6:6] = flags.split()      # experiments (-DCF_...); the shipped library is built without
     if verbose:
-        print(" ".join(cmd))
+        why = "forced" if force else ("flags changed: '%s' -> '%s'" % (built_with, flags) if fresh else "sources newer than the library")
+        print("build: compiling (%s): %s" % (why, " ".join(cmd)))
     subprocess.run(cmd, check=True)
+    with open(FLAGS_PATH, "w") as f:
+        f.write(flags + "\n")
     return LIB_PATH
 
 

@@ -237,7 +237,6 @@ struct cf_handle {
         long long step = -1;
         AdamFuse o;
     } rider;
-    int n_wg_uniform = 0;                      // leading tiles of the table that are one segment of the same length (the Regulation layers')
     int xcd_reduce = 0;                        // XCD-aware order of the weight-gradient tiles (measured slower: cf_kernels.h, xcd_tile)
     int xcd_reduce_opt = 1;                    // ... in the fused reduction + AdamW launch, which moves 5.5 TB/s: there it pays (0.568 -> 0.563 ms)
     int defer_retile = 1;                      // Regulation + head units ride in the Embedding layer's chain launch (CF_DEFER_RETILE=0: all in the prologue)
@@ -279,6 +278,7 @@ struct cf_handle {
     float *lp_part_e[kMaxRes], *lp_part_p[kMaxRes];
     int last_fwd_B = 0;
     int n_fwd = 0, n_bwd = 0, n_opt = 0;
+    int n_cu = 256;                     // hipDeviceAttributeMultiprocessorCount of the device the handle was created on
     double wg_flops_per_gene = 0.0;     // 2*M*N*K summed over the weight-gradient jobs, per gene
     // optional HIP-event timing of one of the eagerly launched kernels
     std::string timed;
@@ -301,6 +301,10 @@ struct cf_handle {
         hipGraphExec_t first = nullptr, second = nullptr;
         bool has_hole = false;
         Hole hole;
+        // launch accounting of the captured sequence (cf_launch_counts must describe ONE step under replay as well): the forward
+        // launches it holds (-1: none), whether it starts a backward pass (head: the per-step counters restart), the backward launches it holds
+        int n_fwd = -1, n_bwd = 0;
+        bool starts_bwd = false;
     };
     std::vector<Replay> replays;
     Replay cap;                    // under construction
@@ -672,10 +676,6 @@ static int build_tables(cf_handle* h) {
     HIP_TRY(hipMemcpy(h->lp_jobs, lpj.data(), lpj.size() * sizeof(LpJob), hipMemcpyHostToDevice));
     h->n_wg_r = (int)wgR.size();
     h->n_cs_r = (int)csR.size();
-    h->n_wg_uniform = 0;
-    while (h->n_wg_uniform < (int)wgR.size() && wgR[h->n_wg_uniform].nseg == 1 &&
-           wgR[h->n_wg_uniform].seg[0].rows_per_gene == wgR[0].seg[0].rows_per_gene)
-        ++h->n_wg_uniform;
     wg.insert(wg.begin(), wgR.begin(), wgR.end());      // table layout: [Regulation + head | Embedding + Pairwise]
     cs.insert(cs.begin(), csR.begin(), csR.end());
     h->wg_flops_per_gene = 0.0;
@@ -734,6 +734,11 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         return fail("cf_create: no HIP device visible -- libchromoformer_hip has no CPU fallback");
     cf_handle* h = new cf_handle();
     h->cfg = *cfg;
+    {   // compute units of the current device: sizes the rows of rider workgroups that share a launch with one-per-CU workgroups
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
+            h->n_cu = ncu;
+    }
     if (build_layout(h->cfg, h->table, h->lay)) {
         delete h;
         return -1;
@@ -1159,8 +1164,10 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
             ta.rt_tiledT = h->reg8 ? h->tiledT : nullptr;
         }
         void* kargs[] = {&ta};
+        h->time_mark("k_trunk_fwd", st);
         HIP_TRY(hipLaunchKernel(trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + (defer && ta.rt_n > 0 ? 1 : 0)), dim3(kAT), kargs,
                                 h->trunk_smem_bytes, st));
+        h->time_mark("k_trunk_fwd", st);
         LAUNCH_CHECK("k_trunk_fwd");
     }
     // one centre-row layer: query chain -> attention -> post chain
@@ -1450,6 +1457,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
     }
     h->last_fwd_B = save ? B : 0;
     h->n_fwd = (int)(g_launches - launches0);
+    if (h->capturing) h->cap.n_fwd = h->n_fwd;
     return 0;
 }
 
@@ -1590,22 +1598,32 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         ta.rd_n = 0;
         ta.rd_batch = B;
         memset(&ta.rd_opt, 0, sizeof ta.rd_opt);
-        if (h->rider.armed) {      // (cf_rider_arm) a multiple of the team count, all of the same length
+        const bool riding = h->rider.armed;
+        if (riding) {      // (cf_rider_arm) one tile per rider wave at a time: any leading part of the bucket's table
             if (h->capturing) return fail("cf_backward_part: armed riders carry this step's AdamW scalars as launch arguments and cannot be captured");
-            h->rider.armed = false;
-            ta.rd_n = std::min(h->rider.max_tiles, h->n_wg_r);      // (one tile per wave at a time: any leading part of the bucket's table)
+            ta.rd_n = std::min(h->rider.max_tiles, h->n_wg_r);
             ta.rd_tiles = h->wg_tiles;
             ta.rd_opt = h->rider.o;
-            h->rider.done = ta.rd_n;
         }
         void* kargs[] = {&ta};
         const size_t rider_lds = (size_t)(kAT / 64) * kWgWaveLds * sizeof(float);      // eight wave-private stages
-        // one tile per rider wave: rows of B workgroups x 8 waves until every tile has a wave.  The first 256 - 3 B workgroups start at once on
+        // one tile per rider wave: rows of B workgroups x 8 waves until every tile has a wave.  The first (CUs - 3 B) workgroups start at once on
         // the idle CUs, the others as the short-resolution workgroups of the trunk (dispatched last, done first) leave theirs
         const int rider_rows = ta.rd_n > 0 ? (ta.rd_n + B * (kAT / 64) - 1) / (B * (kAT / 64)) : 0;
-        HIP_TRY(hipLaunchKernel(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + rider_rows), dim3(kAT), kargs,
-                                ta.rd_n > 0 ? std::max(h->trunk_smem_bytes, rider_lds) : h->trunk_smem_bytes, st));
-        LAUNCH_CHECK("k_trunk_bwd");
+        h->time_mark("k_trunk_bwd", st);
+        const hipError_t le = hipLaunchKernel(trunk_kernel(true, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + rider_rows), dim3(kAT), kargs,
+                                              ta.rd_n > 0 ? std::max(h->trunk_smem_bytes, rider_lds) : h->trunk_smem_bytes, st);
+        h->time_mark("k_trunk_bwd", st);
+        ++g_launches;
+        if (le != hipSuccess || hipGetLastError() != hipSuccess) {
+            // nothing was reduced or stepped: the riders stay armed for a retry, rider.done stays 0 and the reduction launch of the
+            // step covers every tile
+            return fail("launch k_trunk_bwd failed: %s", hipGetErrorString(le));
+        }
+        if (riding) {      // only a launch that was accepted counts as having reduced (and stepped) its tiles
+            h->rider.armed = false;
+            h->rider.done = ta.rd_n;
+        }
         return 0;
     }
     // one centre-row layer backward: post chain -> attention -> query chain
@@ -1801,6 +1819,10 @@ extern "C" int cf_backward_part(cf_handle* h, const cf_batch* bt, const void* la
     if (parts & 1) h->n_bwd = h->n_opt = 0;      // a backward pass starts with the head: its pieces, the bucket reductions and the optimiser launches add up
     const int rc = backward_impl(h, bt, st, parts, labels, loss_scale, loss_out);
     h->n_bwd += (int)(g_launches - launches0);
+    if (h->capturing) {
+        if (parts & 1) h->cap.starts_bwd = true, h->cap.n_bwd = 0;
+        h->cap.n_bwd += (int)(g_launches - launches0);
+    }
     return rc;
 }
 
@@ -1825,6 +1847,7 @@ extern "C" int cf_backward_reduce_part(cf_handle* h, int B, int buckets, void* s
     const long long launches0 = g_launches;
     const int rc = reduce_impl(h, B, (hipStream_t)stream, buckets);
     h->n_bwd += (int)(g_launches - launches0);
+    if (h->capturing) h->cap.n_bwd += (int)(g_launches - launches0);
     return rc;
 }
 
@@ -1887,6 +1910,9 @@ extern "C" int cf_graph_launch(cf_handle* h, int graph_id, void* stream) {
     if (!h || graph_id < 0 || graph_id >= (int)h->replays.size()) return fail("cf_graph_launch: bad graph id %d", graph_id);
     cf_handle::Replay& rp = h->replays[graph_id];
     hipStream_t st = (hipStream_t)stream;
+    if (rp.n_fwd >= 0) h->n_fwd = rp.n_fwd;
+    if (rp.starts_bwd) h->n_bwd = h->n_opt = 0;
+    h->n_bwd += rp.n_bwd;
     HIP_TRY(hipGraphLaunch(rp.first, st));
     if (rp.has_hole) {
         void* kargs[] = {&rp.hole.args};
@@ -1935,8 +1961,28 @@ extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
     const double att_fwd = 2.0 * T * T * kRDm * 2.0;                                                   // q k^T and p v
     if (k == "k_reg_fwd") return (lin_fwd + att_fwd) * c.reg_layers * c.n_res * B;
     if (k == "k_reg_bwd") return (lin_fwd + 2.0 * T * T * kRDm * 5.0) * c.reg_layers * c.n_res * B;    // dX products + p v, dp, dq, dk, dv
+    if (k == "k_trunk_fwd" || k == "k_trunk_bwd") {
+        // The centre-row trunk of one (gene, resolution): ONE Embedding row and S = i_max Pairwise rows per layer.  Per row and layer the
+        // 128-wide products q = x Wq^T, qt[h] = q[h] Wk[h], a[h] = xbar[h] Wv[h]^T, a Wo^T (4 x 128 x 128 MACs), the FFN (2 x 128 x d_ff) and the
+        // attention of 2 heads over the L bins of the region in two passes of (128 + F) MACs per bin and head (scores, weighted sum; the key /
+        // value projections are absorbed into the query); lin_proj_p on the Embedding row (128 x 128), the
+        // Embedding input row (F x 128, forward only).  Backward: the dX product of each of these maps and the attention backward
+        // (the same two passes with (dxbar, p) in and (dqt, du) out); weight gradients belong to k_wgrad, riders are not counted.
+        const double S = c.i_max, F = c.n_feats, PL = c.pair_layers;
+        const bool bwd = k == "k_trunk_bwd";
+        double mac = 0.0;
+        for (int r = 0; r < c.n_res; ++r) {
+            const double L = c.n_bins[r];
+            const double row_e = 4.0 * kD * kD + 2.0 * kD * c.embed_dff + kD * kD + (bwd ? 0.0 : F * kD);
+            const double row_p = 4.0 * kD * kD + 2.0 * kD * c.pair_dff;
+            const double att = 2.0 * 2.0 * L * (kD + F);
+            mac += row_e + att + S * PL * (row_p + att);
+        }
+        return 2.0 * mac * B;
+    }
     return 0.0;
 }
+extern "C" int cf_cu_count(cf_handle* h) { return h ? h->n_cu : 0; }
 
 // ------------------------------------------------------------------------------------
 // optimiser

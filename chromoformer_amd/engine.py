@@ -207,7 +207,7 @@ class Trainer:
             _lib.check(self._L.cf_grad_bucket(model._handle, b, C.byref(off), C.byref(n)), "cf_grad_bucket")
             self._buckets[b] = model._gflat[off.value: off.value + n.value]
         self.timed_kernel = timed_kernel
-        if timed_kernel in ("k_wgrad", "k_colsum", "k_adamw"):
+        if timed_kernel in ("k_wgrad", "k_colsum", "k_adamw", "k_trunk_fwd", "k_trunk_bwd"):
             self.use_graph = False        # launched once per bucket: timed on the eager path, where every launch gets its events
         # Measured and left off by default: AdamW inside the graph (scalars from device memory) costs +5 us per step (one
         # more launch per bucket plus cf_adamw_set), and running the early bucket's update as a parallel branch under the
@@ -253,6 +253,9 @@ class Trainer:
         self.rider_tiles = int(rider_tiles) if self.fuse_opt and self.fuse_one else 0
         if self.rider_tiles > 0 and self._L.cf_rider_arm(model._handle, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, 0, 0) != 0:
             self.rider_tiles = 0          # (configurations without the fused trunk kernels)
+        # riders fit on the CUs the trunk's n_res x B one-per-CU workgroups leave idle: sized from the device's CU count (256 on an
+        # MI355X; a partition or another part has fewer / more), none when the trunk alone fills the device
+        self._n_cu = int(self._L.cf_cu_count(model._handle)) or 256
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -381,8 +384,8 @@ class Trainer:
             if self.fuse_one and self.rider_tiles > 0:
                 # riders: part of the Regulation bucket's tiles (with their AdamW) inside the trunk's backward launch, on the CUs it leaves idle
                 # (one tile per rider wave, eight waves per idle CU: 256 CUs minus the trunk's n_res x B workgroups)
-                n_rd = min(self.rider_tiles, 8 * max(0, 256 - len(m.binsizes) * slot.B))
-                _lib.check(L.cf_rider_arm(m._handle, *hp, kg, n_rd), "cf_rider_arm")
+                n_rd = min(self.rider_tiles, 8 * max(0, self._n_cu - len(m.binsizes) * slot.B))
+                _lib.check(L.cf_rider_arm(m._handle, *hp, kg, n_rd), "cf_rider_arm")      # (n_rd = 0 disarms: no idle CU)
                 self._part(slot, st, 4)
                 _lib.check(L.cf_reduce_opt_part(m._handle, slot.B, _lib.BUCKET_REG | _lib.BUCKET_PE, *hp, kg, st), "cf_reduce_opt_part")
             elif self.fuse_one:       # both buckets' tiles in ONE launch behind the whole backward pass
@@ -453,6 +456,7 @@ class Trainer:
         if not oig and not self.dp and not self.merge_opt:
             m.adamw_step(self.lr, self.betas, self.eps, self.wd)
         self._last = slot
+        m._mark_grads(self.fuse_opt and not self.keep_grads)
         return slot.logits, slot.loss
 
     def evaluate(self, slot):
@@ -473,6 +477,10 @@ class Trainer:
             return out
         struct = store.struct()                                   # raises for a host-side store
         cache = self.__dict__.setdefault("_eval_slots", {})
+        cursors = []
+        # labels travel only when the store's label kind is the model's (a prediction run may open a store packed for the other
+        # task: the gather would copy 4-byte labels out of an 8-byte column)
+        with_labels = bool(getattr(store, "regression", m.n_out == 1)) == (m.n_out == 1)
         with torch.cuda.stream(self.stream):
             order = torch.arange(n, dtype=torch.int32, device=m._device)
             n_full = n // bsz
@@ -483,12 +491,19 @@ class Trainer:
                 if slot is None:
                     slot = cache[B] = Slot(m, B)
                 cursor = torch.tensor([0, nb, 0, 0], dtype=torch.int32).to(m._device)
+                cursors.append(cursor)
                 st = self._stream()
                 for k in range(nb):
                     _lib.check(L.cf_gather_batch(m._handle, C.byref(struct), order[lo:].data_ptr(), cursor.data_ptr(), C.byref(slot.struct),
-                                                 slot.label.data_ptr(), st), "cf_gather_batch")
+                                                 slot.label.data_ptr() if with_labels else None, st), "cf_gather_batch")
                     _lib.check(L.cf_forward(m._handle, C.byref(slot.struct), out[lo + k * B:].data_ptr(), 0, st), "cf_forward")
             self.stream.synchronize()                             # `order` / `cursor` may be released; the result is complete
+            # the gather is bounded on the device and SKIPS what it cannot serve (batch index past the upload, gene index outside the
+            # store), leaving the previous batch's rows in the slot: its error flags decide whether the logits mean anything
+            flags = [int(c[2].item()) for c in cursors]
+            if any(flags):
+                raise RuntimeError("evaluate_store: the device-side gather reported errors (flags %s): store / order mismatch, "
+                                   "the logits of the skipped genes would be those of an earlier batch" % flags)
         return out
 
     def scheduler_step(self):
@@ -519,7 +534,7 @@ class Trainer:
         if kernel == "k_wgrad":
             launches = (launches + 1) // 2            # one launch per gradient bucket; the flop count is the step's
             avg_s = total_ms / launches * 1e-3
-        if kernel in ("k_wgrad", "k_reg_fwd", "k_reg_bwd"):
+        if kernel in ("k_wgrad", "k_reg_fwd", "k_reg_bwd", "k_trunk_fwd", "k_trunk_bwd"):
             flops = self._L.cf_kernel_flops(self.model._handle, kernel.encode(), B)
             ach = flops / avg_s / 1e12
             return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",

@@ -310,6 +310,7 @@ class ChromoformerBase(nn.Module):
         st = torch.cuda.current_stream(self._device).cuda_stream
         _lib.check(_lib.lib().cf_backward(self._handle, C.byref(bs), labels.data_ptr(), float(loss_scale),
                                           self._loss_buf.data_ptr(), st), "cf_backward")
+        self._grads_stale = False
         return logits, self._loss_buf
 
     def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
@@ -319,8 +320,20 @@ class ChromoformerBase(nn.Module):
                    "cf_adamw_step")
 
     def active_grads(self):
-        """The contiguous gradient range the optimiser / all-reduce operate on."""
+        """The contiguous gradient range the optimiser / all-reduce operate on.  Raises after a step that never wrote it (the
+        single-GPU Trainer applies AdamW in the epilogue of the gradient reductions and stores gradients only with
+        keep_grads=True): stale values must not reach clip_grad_norm_ / logging / a custom all-reduce silently."""
+        if getattr(self, "_grads_stale", False):
+            raise RuntimeError("the gradient buffer was not written by the last step (Trainer(fuse_opt=True, keep_grads=False) "
+                               "updates parameters inside the gradient reductions); construct the Trainer with keep_grads=True")
         return self._gflat[: self._layout.n_active]
+
+    def _mark_grads(self, stale):
+        """Called by the Trainer after every step: `stale` = the step did not store its gradients."""
+        if stale and not getattr(self, "_grads_stale", False):
+            for p in self._named().values():      # `.grad` views of the flat buffer (loss.backward() publishes them) would read old values
+                p.grad = None
+        self._grads_stale = bool(stale)
 
     def train_step(self, packed, labels, lr, process_group=None, world_size=1):
         """zero_grad -> forward -> loss -> backward -> [all-reduce] -> AdamW (train.py:182-196)."""

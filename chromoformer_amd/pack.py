@@ -188,22 +188,29 @@ class PackedStore:
         return st
 
 
+last_skip_reason = None      # why the last find() returned None (train.py prints it: a skipped store means re-binning every .npy file)
+
+
 def find(npy_dir, explicit, binsizes, i_max, w_prom, w_max, n_feats, genes=None, meta=None):
     """The packed store a run should use: `explicit` if given (must match, else an error), else `<npy_dir>/chromoformer.cfstore`
     when it exists, matches the binning configuration, holds all `genes` AND was packed from the metadata rows and signal
     files the run sees now (`meta`: the run's metadata file or DataFrame; labels, expression, partner sets, scores and TSS
     windows are frozen at pack time, so a store that no longer agrees with them is stale: an automatic pick-up skips it with
     a warning, an explicit --store is an error); None otherwise."""
+    global last_skip_reason
+    last_skip_reason = None
     path = explicit or os.path.join(npy_dir, DEFAULT_NAME)
     if not os.path.exists(path):
         if explicit:
             raise FileNotFoundError(explicit)
+        last_skip_reason = "no %s" % path
         return None
     ps = PackedStore(path)
     ok = ps.matches(binsizes, i_max, w_prom, w_max, n_feats) and (genes is None or all(g in ps._row for g in genes))
     if not ok:
         if explicit:
             raise ValueError("%s was packed for %s, the run needs %s" % (path, ps.signature, signature(binsizes, i_max, w_prom, w_max, n_feats)))
+        last_skip_reason = "%s was packed for another binning configuration or gene set" % path
         return None
     if meta is not None:
         table = pd.read_csv(meta) if isinstance(meta, (str, os.PathLike)) else meta
@@ -215,6 +222,7 @@ def find(npy_dir, explicit, binsizes, i_max, w_prom, w_max, n_feats, genes=None,
                 raise ValueError(why + "; re-run `python -m chromoformer_amd.pack`")
             import warnings
             warnings.warn(why + "; ignoring it and binning the raw .npy files (re-run `python -m chromoformer_amd.pack`)")
+            last_skip_reason = why
             return None
     return ps
 

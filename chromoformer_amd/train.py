@@ -157,7 +157,7 @@ def main(argv=None):
 
     from . import pack
     packed = pack.find(args.npy_dir, args.store, args.binsizes, i_max, w_prom, w_max, n_feats, train_genes + val_genes, meta=meta)
-    say("packed store:", packed.path if packed is not None else "none (binning the raw .npy files)")
+    say("packed store:", packed.path if packed is not None else "none (binning the raw .npy files): %s" % (pack.last_skip_reason or "not looked for"))
 
     def store_of(genes):
         if packed is not None:          # a row gather out of the memory-mapped store, resident in HBM afterwards

@@ -187,7 +187,7 @@ int cf_capture_end(cf_handle* h, void* stream, int* graph_id);
 int cf_graph_launch(cf_handle* h, int graph_id, void* stream);
 
 /* ---- introspection (tests / profiling) -------------------------------------------- */
-/* HIP-event timing of one eagerly launched kernel ("k_wgrad", "k_colsum", "k_adamw", "k_reg_fwd", "k_reg_bwd"; NULL
+/* HIP-event timing of one eagerly launched kernel ("k_wgrad", "k_colsum", "k_adamw", "k_reg_fwd", "k_reg_bwd", "k_trunk_fwd", "k_trunk_bwd"; NULL
  * = off): events are recorded on the launch stream around every launch of that kernel;
  * cf_timing_read waits for them and returns the summed duration and the launch count. */
 int cf_timing_select(cf_handle* h, const char* kernel);
@@ -197,8 +197,13 @@ int cf_timing_read(cf_handle* h, float* total_ms, int* count);
  * before cf_capture_begin. */
 /* Executed flops (2*M*N*K summed over the tile table) of one k_wgrad launch at batch B. */
 double cf_wgrad_flops(cf_handle* h, int B);
-/* Algorithmic flops (2 * MAC over the valid rows) of one launch of "k_wgrad", "k_reg_fwd" or "k_reg_bwd". */
+/* Algorithmic flops (2 * MAC over the valid rows) of one launch of "k_wgrad", "k_reg_fwd", "k_reg_bwd", "k_trunk_fwd" or
+ * "k_trunk_bwd" (the centre-row trunk: row products + two-pass centre-row attention of the Embedding row and the i_max Pairwise
+ * rows of every gene and resolution; riders of the launch are not counted). */
 double cf_kernel_flops(cf_handle* h, const char* kernel, int B);
+/* Compute units of the device the handle lives on (hipDeviceAttributeMultiprocessorCount): callers that add rider workgroups to
+ * a launch of one-per-CU workgroups (cf_rider_arm) size them with it. */
+int cf_cu_count(cf_handle* h);
 /* Copies a named workspace buffer (e.g. "E0.qt", "dP2.1.xbar") to dst (device);
  * *n_floats receives its size; dst may be NULL to query. */
 int cf_debug_copy(cf_handle* h, const char* name, float* dst, long long* n_floats, void* stream);
