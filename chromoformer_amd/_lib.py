@@ -110,6 +110,7 @@ SYMBOLS = {
     "cf_op_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_op_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cf_bin_regions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "cf_bin_regions_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]),
     "cf_embed_full": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.POINTER(C.c_void_p), C.c_void_p]),
     "cf_gather_batch": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
     "cf_record_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

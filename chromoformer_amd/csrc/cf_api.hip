@@ -2371,6 +2371,37 @@ extern "C" int cf_bin_regions(const cf_bin_job* jobs, int n_jobs, int n_feats, i
     return 0;
 }
 
+static_assert(sizeof(cf_bin_job_multi) == sizeof(BinJobMulti), "cf_bin_job_multi layout");
+extern "C" int cf_bin_regions_multi(const cf_bin_job_multi* jobs, int n_jobs, int n_feats, int n_res, const int* bin_sizes, const int* n_bins_out,
+                                    int max_cols, void* stream) {
+    if (!jobs || !bin_sizes || !n_bins_out) return fail("cf_bin_regions_multi: null argument");
+    if (n_jobs < 0 || n_feats < 1 || n_feats > 64 || n_res < 1 || n_res > kBinMaxRes || max_cols < 0) return fail("cf_bin_regions_multi: bad argument");
+    if (n_jobs == 0) return 0;
+    BinPlan pl;
+    memset(&pl, 0, sizeof pl);
+    pl.n_res = n_res;
+    pl.F = n_feats;
+    for (int r = 0; r < n_res; ++r) {
+        if (bin_sizes[r] < 1 || n_bins_out[r] < 1 || n_bins_out[r] > kBinMaxBins) return fail("cf_bin_regions_multi: bad bin size / bin count at resolution %d", r);
+        if (r && bin_sizes[r] >= bin_sizes[r - 1]) return fail("cf_bin_regions_multi: bin sizes must be listed coarsest first (%d after %d)", bin_sizes[r], bin_sizes[r - 1]);
+        pl.b[r] = bin_sizes[r];
+        pl.L[r] = n_bins_out[r];
+    }
+    // one pass over the raw bytes when the bins nest and a unit (one coarsest bin) fits a wave's registers and lanes
+    bool nested = n_res >= 2 && n_feats <= kBinMaxF && (pl.b[n_res - 1] & 3) == 0 && pl.b[0] <= kBinMaxLoads * 256 && pl.b[0] / pl.b[n_res - 1] <= 64;
+    for (int r = 0; r + 1 < n_res; ++r) nested = nested && pl.b[r] % pl.b[r + 1] == 0;
+    pl.nested = nested ? 1 : 0;
+    const int units = nested ? std::max(1, (max_cols + pl.b[0] - 1) / pl.b[0]) : 1;
+    const dim3 grid((units + 3) / 4, n_jobs);
+    const int nload = nested ? (pl.b[0] / 4 + 63) / 64 : 4;
+    const BinJobMulti* jm = reinterpret_cast<const BinJobMulti*>(jobs);
+    if (nload <= 4) hipLaunchKernelGGL(k_bin_multi<4>, grid, dim3(256), 0, (hipStream_t)stream, jm, pl);
+    else if (nload <= 8) hipLaunchKernelGGL(k_bin_multi<8>, grid, dim3(256), 0, (hipStream_t)stream, jm, pl);
+    else hipLaunchKernelGGL(k_bin_multi<16>, grid, dim3(256), 0, (hipStream_t)stream, jm, pl);
+    LAUNCH_CHECK("k_bin_multi");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // dense (all rows) layer: projections -> attention core -> out-projection / LN / FFN / LN chain, and its backward
 // ------------------------------------------------------------------------------------

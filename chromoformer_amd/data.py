@@ -137,6 +137,11 @@ BIN_JOB = np.dtype([("raw", "<u8"), ("ld", "<i8"), ("col0", "<i4"), ("ncols", "<
                     ("out", "<u8"), ("mask", "<u8")])
 
 
+#: layout of cf_bin_job_multi: out / mask per resolution, coarsest resolution first
+BIN_JOB_MULTI = np.dtype([("raw", "<u8"), ("ld", "<i8"), ("col0", "<i4"), ("ncols", "<i4"), ("flip", "<i4"), ("reserved", "<i4"),
+                          ("out", "<u8", (3,)), ("mask", "<u8", (3,))])
+
+
 class GeneStore:
     """All genes of a split, binned once, compact layout.
 
@@ -219,22 +224,41 @@ class GeneStore:
             flat = torch.from_numpy(np.concatenate([a.reshape(-1) for _, _, _, a in pending]))
             raw = (flat.pin_memory() if torch.cuda.is_available() else flat).to(dev, non_blocking=True)
             base, off = raw.data_ptr(), 0
+            # every resolution of a region in ONE launch (cf_bin_regions_multi: nested bin sizes read the raw bytes once); more than
+            # three resolutions or repeated bin sizes: one cf_bin_regions launch per resolution
+            order = sorted(range(len(self.binsizes)), key=lambda r: -self.binsizes[r])      # coarsest first
+            multi = len(self.binsizes) <= 3 and len(set(self.binsizes)) == len(self.binsizes)
             jobs = [[] for _ in self.binsizes]
-            for i, s, flip, a in pending:
+            mjobs = np.zeros(len(pending), dtype=BIN_JOB_MULTI)
+            max_cols = 0
+            for k, (i, s, flip, a) in enumerate(pending):
                 ld = a.shape[1]
                 c0, nc = (col0, max(0, min(col0 + ds.w_prom, ld) - col0)) if s < 0 else (0, ld)
+                max_cols = max(max_cols, nc)
+                mjobs[k]["raw"], mjobs[k]["ld"], mjobs[k]["col0"], mjobs[k]["ncols"], mjobs[k]["flip"] = base + 2 * off, ld, c0, nc, int(flip)
                 for r, b in enumerate(self.binsizes):
                     L = self.n_bins[r]
                     if -(-nc // b) > L:
                         raise ValueError("region spans %d bins but w_max allows %d" % (-(-nc // b), L))
                     out = pf[r][i, 0] if s < 0 else cf[r][i, s]
                     msk = pm[r][i] if s < 0 else cm[r][i, s]
-                    jobs[r].append((base + 2 * off, ld, c0, nc, int(flip), 0, out.data_ptr(), msk.data_ptr()))
+                    if multi:
+                        mjobs[k]["out"][order.index(r)], mjobs[k]["mask"][order.index(r)] = out.data_ptr(), msk.data_ptr()
+                    else:
+                        jobs[r].append((base + 2 * off, ld, c0, nc, int(flip), 0, out.data_ptr(), msk.data_ptr()))
                 off += a.size
-            for r, b in enumerate(self.binsizes):
-                tab = torch.from_numpy(np.array(jobs[r], dtype=BIN_JOB).view(np.uint8)).to(dev)
-                _lib.check(L_.cf_bin_regions(C.c_void_p(tab.data_ptr()), len(jobs[r]), F, b, self.n_bins[r], stream.cuda_stream),
-                           "cf_bin_regions")
+            if multi:
+                tab = torch.from_numpy(mjobs.view(np.uint8)).to(dev)
+                nr = len(order)
+                bs = (C.c_int * nr)(*[self.binsizes[r] for r in order])
+                nb = (C.c_int * nr)(*[self.n_bins[r] for r in order])
+                _lib.check(L_.cf_bin_regions_multi(C.c_void_p(tab.data_ptr()), len(pending), F, nr, bs, nb, int(max_cols), stream.cuda_stream),
+                           "cf_bin_regions_multi")
+            else:
+                for r, b in enumerate(self.binsizes):
+                    tab = torch.from_numpy(np.array(jobs[r], dtype=BIN_JOB).view(np.uint8)).to(dev)
+                    _lib.check(L_.cf_bin_regions(C.c_void_p(tab.data_ptr()), len(jobs[r]), F, b, self.n_bins[r], stream.cuda_stream),
+                               "cf_bin_regions")
             stream.synchronize()                                                # raw / job tables may be released
             pending, pending_bytes = [], 0
 

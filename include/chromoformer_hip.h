@@ -297,6 +297,24 @@ typedef struct cf_bin_job {
     unsigned char* mask;
 } cf_bin_job;
 int cf_bin_regions(const cf_bin_job* jobs, int n_jobs, int n_feats, int bin_size, int n_bins_out, void* stream);
+/* All resolutions of every region in ONE launch and -- when the bin sizes nest (each a multiple of the next, the finest a
+ * multiple of 4 samples: the default 2000 / 500 / 100) and the rows are 8-byte aligned -- ONE pass over the raw bytes: the
+ * reference calls _bin_and_pad once per bin size on the same window (data.py:134-140, 168-176 -> 68-100); here a wave reads a
+ * coarsest bin's samples once and derives the finer resolutions' sums from the same chunk sums.  bin_sizes / n_bins_out:
+ * host arrays [n_res], coarsest resolution first; out[r] / mask[r] of a job as in cf_bin_job, per resolution; max_cols: an
+ * upper bound of `ncols` over the jobs (sizes the launch).  Same results as n_res calls of cf_bin_regions up to the order
+ * of the fp32 additions inside a bin (1e-7 relative).  Other configurations / unaligned rows: the per-resolution walk of
+ * cf_bin_regions inside the same launch. */
+typedef struct cf_bin_job_multi {
+    const void* raw;
+    long long ld;
+    int col0, ncols;
+    int flip, reserved;
+    float* out[3];
+    unsigned char* mask[3];
+} cf_bin_job_multi;
+int cf_bin_regions_multi(const cf_bin_job_multi* jobs, int n_jobs, int n_feats, int n_res, const int* bin_sizes,
+                         const int* n_bins_out, int max_cols, void* stream);
 
 /* ---- resident split, batch gather inside the step graph --------------------------------- */
 /* The binned genes of a split, resident in HBM (what chromoformer_amd.data.GeneStore builds with cf_bin_regions):
