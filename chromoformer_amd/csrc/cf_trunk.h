@@ -165,6 +165,13 @@ __device__ __forceinline__ void trunk_attc_args(Attc2Args& at, const TrunkCtx& c
     float* wide_raw = (scratch) + 3 * kTile * (kD + 4);                                               \
     (void)xs, (void)as_, (void)ts, (void)wide_raw
 
+}  // namespace cf
+#include "cf_trunk_e.h"      // the Embedding layer's one-row chains on the vector ALUs
+namespace cf {
+#ifndef CF_TRUNK_E_VALU      // 0: the Embedding layer's chains as 16-row matrix-core tiles (round 3; A/B switch)
+#define CF_TRUNK_E_VALU 1
+#endif
+
 // ---- forward phases
 CF_PHASE void trunk_x0_qchain_e(TrunkCtx c, float* smem) {
     const TrunkResDev* R = c.R;
@@ -332,11 +339,13 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
         launder(c, sm, persist);
     }
     // ---------------------------------------------------------------- Embedding layer: one row (the promoter's centre bin)
-    trunk_x0_qchain_e(c, sm);
+    if (CF_TRUNK_E_VALU) trunk_e_front(c, sm);
+    else trunk_x0_qchain_e(c, sm);
     CF_NEXT_PHASE;
     trunk_attc1_e<false>(c, sm);
     CF_NEXT_PHASE;
-    trunk_post_e<DFF_E>(c, sm);
+    if (CF_TRUNK_E_VALU) trunk_e_post_fwd<DFF_E>(c, sm);
+    else trunk_post_e<DFF_E>(c, sm);
     // ---------------------------------------------------------------- Pairwise stack: S rows (the gene's pairs)
     c.feats = a.cfeats[r];
     c.mask = a.cmask[r];
@@ -574,11 +583,13 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     c.mask = a.pmask[r];
     c.mstride = a.pmstride[r];
     CF_NEXT_PHASE;
-    trunk_post_bwd_e<DFF_E>(c, sm);
+    if (CF_TRUNK_E_VALU) trunk_e_post_bwd<DFF_E>(c, sm);
+    else trunk_post_bwd_e<DFF_E>(c, sm);
     CF_NEXT_PHASE;
     trunk_attc1_e<true>(c, sm);
     CF_NEXT_PHASE;
-    trunk_qchain_bwd(c, &c.R->E, c.g, c.g + 1, sm);
+    if (CF_TRUNK_E_VALU) trunk_e_q_bwd(c, sm);
+    else trunk_qchain_bwd(c, &c.R->E, c.g, c.g + 1, sm);
     // ---------------------------------------------------------------- 7-mark projection partials of this gene (k_wgrad_lp)
     CF_NEXT_PHASE;
     trunk_lp(a.lp_jobs, r, c.g, a.B, sm);

@@ -91,18 +91,15 @@ def test_bsz64_independent_kernel_implementations_agree(case, env):
 
 def test_bsz64_fused_trunk_equals_the_stand_alone_kernels(case):
     """The fused centre-row trunk (cf_trunk.h: Embedding + Pairwise stage of a gene in one workgroup, one launch per direction)
-    runs the BODIES of the stand-alone kernels in the same order: the forward pass is bit-identical; in the backward pass only
-    the bias / LayerNorm column sums are associated differently (one partial row per gene instead of one per 16-row tile)."""
+    against the stand-alone kernels (CF_TRUNK=0).  The Pairwise phases ARE the stand-alone kernels' bodies; the Embedding layer's
+    one-row chains run on the vector ALUs in the trunk (cf_trunk_e.h: the same products, another summation order), so the two
+    paths agree to fp32 rounding, not bit for bit: logits 2e-6, every gradient 1e-5 of its largest element (the Regulation and
+    head gradients see the Embedding row only through the forward pass)."""
     batch, P = case
     logits, loss, grads = _model_run({}, batch, P)
     logits2, loss2, grads2 = _model_run({"CF_TRUNK": "0"}, batch, P)
-    assert torch.equal(logits, logits2) and loss == loss2
+    assert (logits - logits2).abs().max() <= 2e-6 and abs(loss - loss2) <= 1e-6, ((logits - logits2).abs().max().item(), loss, loss2)
     assert grads.keys() == grads2.keys()
-    exact = 0
     for k in grads:
-        if torch.equal(grads[k], grads2[k]):
-            exact += 1
-        else:
-            assert _close(grads2[k], grads[k]), (k, ((grads[k] - grads2[k]).norm() / grads[k].norm()).item())
-            assert (grads[k] - grads2[k]).abs().max() <= 1e-5 * grads[k].abs().max() + 1e-12, k
-    assert exact >= 200, exact      # every weight gradient, every Regulation / head tensor
+        assert _close(grads2[k], grads[k]), (k, ((grads[k] - grads2[k]).norm() / grads[k].norm()).item())
+        assert (grads[k] - grads2[k]).abs().max() <= 1e-5 * grads[k].abs().max() + 1e-12, (k, ((grads[k] - grads2[k]).abs().max() / grads[k].abs().max()).item())
