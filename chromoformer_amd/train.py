@@ -63,9 +63,10 @@ def epoch_permutation(n):
     return torch.randperm(n, generator=g).tolist()
 
 
-def optimizer_state_dict(model, lr, initial_lr=None):
+def optimizer_state_dict(model, lr, initial_lr=None, m_host=None, v_host=None):
     """torch.optim.AdamW.state_dict() layout: entries only for parameters that ever had a gradient,
-    `step` as a 0-dim float32 tensor (train.py:325, 336)."""
+    `step` as a 0-dim float32 tensor (train.py:325, 336).  m_host / v_host: host copies of the flat moment buffers (one
+    device-to-host copy each instead of one per tensor); default: copied here."""
     named = list(model.named_parameters())
     ref = torch.optim.AdamW([nn.Parameter(torch.zeros(1)) for _ in named], lr=float(lr))
     sd = ref.state_dict()
@@ -75,15 +76,132 @@ def optimizer_state_dict(model, lr, initial_lr=None):
     sd["param_groups"][0]["initial_lr"] = float(initial_lr if initial_lr is not None else lr)
     state = {}
     if model._step > 0:
+        if m_host is None:
+            m_host, v_host = model._mflat.detach().cpu(), model._vflat.detach().cpu()
         for i, e in enumerate(model._table):
             if not e["trainable"]:
                 continue
             sl = slice(e["offset"], e["offset"] + e["numel"])
             state[i] = {"step": torch.tensor(float(model._step)),
-                        "exp_avg": model._mflat[sl].view(e["shape"]).detach().cpu().clone(),
-                        "exp_avg_sq": model._vflat[sl].view(e["shape"]).detach().cpu().clone()}
+                        "exp_avg": m_host[sl].view(e["shape"]).clone(),
+                        "exp_avg_sq": v_host[sl].view(e["shape"]).clone()}
     sd["state"] = state
     return sd
+
+
+class CheckpointWriter:
+    """The per-epoch checkpoint (train.py:321-341) off the critical path.  A Roadmap-sized epoch is 0.13 s of GPU work; building
+    the reference's checkpoint the obvious way (one .cpu() per tensor: 370 + 668 copies, a fresh torch.optim.AdamW for its
+    state layout, then torch.save of 64 MB) took 0.9 s.  Here the epoch loop pays three device-to-host copies of the flat
+    parameter / moment buffers into pinned memory (~3 ms); the dictionaries in the reference's layout -- state_dict order and
+    (legacy-aware) key names, AdamW's state / param_groups -- are built ONCE as views of those pinned buffers, so a checkpoint
+    is torch.save + rename on a worker thread under the next epoch, with next to no Python work that would compete with the
+    step loop for the interpreter.  (The tensors of a loaded checkpoint therefore share three storages; values, shapes, dtypes,
+    keys and order are the reference's.)  One save is in flight at a time -- submit() waits for the previous one before it
+    overwrites the buffers --, wait() re-raises a failed save, and the run writes its `.done` marker only behind the last wait()."""
+
+    def __init__(self, model):
+        import threading
+        self._threading = threading
+        self.model = model
+        n = model._flat.numel()
+        self._host = [torch.empty(n, dtype=torch.float32).pin_memory() for _ in range(3)]
+        self._thread, self._err = None, None
+        self._go = threading.Event()
+        p_h, m_h, v_h = self._host
+        table = {e["name"]: e for e in model._table}
+        keys, named = list(model.state_dict().keys()), [n_ for n_, _ in model.named_parameters()]
+        if len(keys) != len(named):
+            raise RuntimeError("state_dict keys and parameters disagree")
+        view = lambda buf, e: buf[e["offset"]:e["offset"] + e["numel"]].view(e["shape"])
+        self._net = type(model.state_dict())((k, view(p_h, table[n_])) for k, n_ in zip(keys, named))
+        # torch.optim.AdamW.state_dict() layout (train.py:325, 336): entries only for parameters that ever had a gradient, `step` a
+        # 0-dim float32 tensor per parameter; param_groups from a real AdamW over as many parameters (defaults, ids), plus the
+        # `initial_lr` the reference's attached StepLR adds
+        self._opt = torch.optim.AdamW([nn.Parameter(torch.zeros(1)) for _ in named], lr=1.0).state_dict()
+        self._steps = []
+        self._state = {}
+        for i, e in enumerate(model._table):
+            if e["trainable"]:
+                st = torch.zeros((), dtype=torch.float32)
+                self._steps.append(st)
+                self._state[i] = {"step": st, "exp_avg": view(m_h, e), "exp_avg_sq": view(v_h, e)}
+
+    def go(self):
+        """The step loop has queued its epoch (train_epoch's `after_issue`): the pending save may start.  Until then the worker
+        stays off the interpreter -- a thread that pickles while the main thread issues the first steps of an epoch into an empty
+        stream costs the GPU ~13 ms of idling per epoch (5 ms interpreter switch intervals; measured 0.137 vs 0.124 s per
+        222-step epoch)."""
+        self._go.set()
+
+    def wait(self):
+        if self._thread is not None:
+            self._go.set()
+            self._thread.join()
+            self._thread = None
+        if self._err is not None:
+            err, self._err = self._err, None
+            raise err
+
+    def submit(self, path, ckpt, lr, initial_lr):
+        """ckpt: the epoch's dictionary with net / optimizer still None (filled here, in the reference's key order)."""
+        self.wait()                                   # the pinned buffers are the previous save's until it has finished
+        m = self.model
+        for dst, src in zip(self._host, (m._flat, m._mflat, m._vflat)):
+            dst.copy_(src.detach(), non_blocking=True)
+        torch.cuda.current_stream(m._device).synchronize()
+        for st in self._steps:
+            st.fill_(float(m._step))
+        self._opt["param_groups"][0]["lr"] = float(lr)
+        self._opt["param_groups"][0]["initial_lr"] = float(initial_lr if initial_lr is not None else lr)
+        self._opt["state"] = self._state if m._step > 0 else {}
+        ckpt["net"], ckpt["optimizer"] = self._net, self._opt
+
+        self._go.clear()
+
+        def work():
+            try:
+                self._go.wait(timeout=2.0)            # (released by go() / wait(); the timeout only bounds a caller that does neither)
+                torch.save(ckpt, path + ".tmp")
+                os.replace(path + ".tmp", path)
+            except BaseException as e:                # surfaced by the next wait()
+                self._err = e
+
+        self._thread = self._threading.Thread(target=work, name="cf-checkpoint", daemon=False)
+        self._thread.start()
+
+
+def validation_metrics(val_out, val_lab, regression):
+    """The numbers train.py:277-318 prints and stores after an epoch, from the logits [n, n_out] and labels [n] of the validation
+    split (numpy arrays): -> (loss, score array, dict of metrics in percent).  Same definitions as the reference's calls --
+    nn.CrossEntropyLoss / nn.MSELoss (for the regressor the reference compares [n,1] outputs with [n] labels, i.e. a broadcast
+    [n,n] mean, train.py:280-283: `last_val_loss` in the checkpoint is that number, so it is kept), sklearn's accuracy / ROC AUC /
+    average precision / r2, scipy's pearsonr (tests/test_metrics_cpu.py pins them to those) -- in a few numpy passes: the sklearn
+    calls cost 0.3 s on a 4,700-gene split, twice the GPU time of the whole epoch in front of them, and a torch CPU op would wake
+    torch's intra-op pool next to the step loop."""
+    z = np.asarray(val_out, dtype=np.float32)
+    if regression:
+        pred, lab = z.reshape(-1), np.asarray(val_lab, dtype=np.float32).reshape(-1)
+        p64, l64 = pred.astype(np.float64), lab.astype(np.float64)
+        # mean over the [n, n] broadcast of (p_i - l_j)^2, without materialising it
+        loss = np.float32((p64 ** 2).mean() - 2.0 * p64.mean() * l64.mean() + (l64 ** 2).mean())
+        ss_res, ss_tot = float(((l64 - p64) ** 2).sum()), float(((l64 - l64.mean()) ** 2).sum())
+        r2 = (1.0 - ss_res / ss_tot) * 100 if ss_tot > 0 else float("nan")
+        pc, lc = p64 - p64.mean(), l64 - l64.mean()
+        den = float(np.sqrt((pc ** 2).sum() * (lc ** 2).sum()))
+        r = float((pc * lc).sum()) / den * 100 if den > 0 else float("nan")
+        return loss, pred.copy(), {"r2": r2, "r": r}
+    lab = np.asarray(val_lab).astype(np.int64).reshape(-1)
+    zmax = z.max(axis=1, keepdims=True)
+    lse = (zmax[:, 0] + np.log(np.exp(z - zmax).sum(axis=1))).astype(np.float32)
+    loss = np.float32((lse - z[np.arange(z.shape[0]), lab]).astype(np.float64).mean())
+    score, pred = _softmax1(z), z.argmax(axis=1)
+    acc = float((pred == lab).mean()) * 100
+    try:
+        auc, ap = (100 * v for v in binary_auc_ap(lab, score))
+    except ValueError:
+        auc = ap = float("nan")
+    return loss, score, {"acc": acc, "auc": auc, "ap": ap}
 
 
 def main(argv=None):
@@ -97,6 +215,9 @@ def main(argv=None):
     parser.add_argument("--binsizes", nargs="+", type=int, default=[2000, 500, 100])
     parser.add_argument("--regression", action="store_true", default=False)
     parser.add_argument("--use-wandb", action="store_true", default=False)
+    parser.add_argument("--timing", action="store_true", default=os.environ.get("CF_TRAIN_TIMING") == "1",
+                        help="print a wall-clock breakdown of the run (store load, set-up, per epoch: steps / validation / metrics / checkpoint); "
+                             "adds a device synchronisation at each of those boundaries")
     parser.add_argument("--store", default=None, help="packed store written by `python -m chromoformer_amd.pack` "
                         "(default: <npy-dir>/chromoformer.cfstore when it exists and matches the configuration)")
     parser.add_argument("--dp-shard", choices=["static", "global"], default="static",
@@ -129,6 +250,14 @@ def main(argv=None):
             torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
     say = print if rank == 0 else (lambda *a, **k: None)
+    import time
+    marks = [("start", time.perf_counter())]
+
+    def mark(what):      # --timing: wall clock between named boundaries (device drained first, so that a phase owns its GPU work)
+        if args.timing:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            marks.append((what, time.perf_counter()))
     say(config)
 
     config["exp_id"] = args.exp_id
@@ -175,6 +304,7 @@ def main(argv=None):
     per_val = (n_val + world - 1) // world
     val_lo, val_hi = min(n_val, rank * per_val), min(n_val, (rank + 1) * per_val)
     val_store = store_of(val_genes[val_lo:val_hi])
+    mark("store load (train + validation splits resident in HBM)")
     label_of = {r["gene_id"]: (np.log2(r["expression"] + 1) if args.regression else r["label"]) for r in meta.to_dict("records")}
     val_labels = torch.tensor([label_of[g] for g in val_genes], dtype=torch.float32 if args.regression else torch.int64)
 
@@ -190,6 +320,8 @@ def main(argv=None):
         print("[rank %d/%d] dp-shard %s: train store %d of %d genes, validation slice %d of %d genes, %d steps per epoch"
               % (rank, world, args.dp_shard, len(train_store), len(train_genes), len(val_store), n_val, n_steps), file=sys.stderr, flush=True)
 
+    writer = CheckpointWriter(model) if rank == 0 else None
+    mark("model, trainer, feed")
     val_score = val_label = val_loss = None
     for epoch in range(1, num_epoch):
         perm = epoch_permutation(len(train_genes))            # the same draws on every rank
@@ -198,51 +330,49 @@ def main(argv=None):
         else:
             batches = shard_indices(perm, rank, world, bsz, drop_last=True)
         train_epoch(trainer, feed, batches,
-                    lambda lo, la, ls: _report_train(say, wandb, epoch, float(ls.numpy().mean()), trainer.lr, lo, la, args.regression))
+                    lambda lo, la, ls: _report_train(say, wandb, epoch, float(ls.numpy().mean()), trainer.lr, lo, la, args.regression),
+                    after_issue=writer.go if writer is not None else None)      # the previous epoch's checkpoint is written under this one's steps
+        mark("epoch %d: %d steps (permutation, begin_epoch, steps, running metrics)" % (epoch, len(batches)))
 
         # validation (sharded over ranks, gathered on every rank)
         _draw_loader_seed()                                         # the val DataLoader's base seed draw
         val_out, val_lab = _validate(model, trainer, val_store, n_val, bsz, world), val_labels.clone()
-        # NB: for the regressor the reference compares [n,1] outputs with [n] labels here (train.py:280-283),
-        # i.e. a broadcast [n,n] MSE; `last_val_loss` in the checkpoint is that number, so it is kept.
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            val_loss = criterion(val_out, val_lab)
+        mark("epoch %d: validation forward (%d genes)" % (epoch, n_val))
         val_label = val_lab.numpy()
-        from scipy import stats
-        from sklearn import metrics
+        v_loss, val_score, vm = validation_metrics(val_out.numpy(), val_label, args.regression)
+        val_loss = torch.tensor(v_loss)                             # (a 0-dim float32 tensor, as criterion(...) returns)
         if args.regression:
-            val_score = val_out.flatten().numpy()
-            val_r2 = metrics.r2_score(val_label, val_score) * 100
-            val_r = stats.pearsonr(val_label, val_score)[0] * 100
+            val_r2, val_r = vm["r2"], vm["r"]
             say(f"Validation loss={val_loss:.4f}, r2={val_r2:.4f}, r={val_r:.4f}")
             wandb.log({"val/loss": val_loss, "val/r2": val_r2, "val/r": val_r})
             ckpt = {"net": None, "optimizer": None, "epoch": epoch, "last_val_loss": val_loss, "last_val_r2": val_r2,
                     "val_score": val_score, "val_label": val_label}
         else:
-            val_score = val_out.softmax(axis=1)[:, 1].numpy()
-            val_pred = val_out.argmax(axis=1).numpy()
-            val_acc = metrics.accuracy_score(val_label, val_pred) * 100
-            val_auc = metrics.roc_auc_score(val_label, val_score) * 100
-            val_ap = metrics.average_precision_score(val_label, val_score) * 100
+            val_acc, val_auc, val_ap = vm["acc"], vm["auc"], vm["ap"]
             say(f"Validation loss={val_loss:.4f}, acc={val_acc:.4f}, auc={val_auc:.4f}, ap={val_ap:.4f}")
             wandb.log({"val/loss": val_loss, "val/acc": val_acc, "val/auc": val_auc, "val/ap": val_ap, "val/epoch": epoch})
             ckpt = {"net": None, "optimizer": None, "epoch": epoch, "last_val_loss": val_loss, "last_val_auc": val_auc,
                     "val_score": val_score, "val_label": val_label}
+        mark("epoch %d: validation metrics" % epoch)
         if rank == 0:
-            torch.cuda.synchronize()
-            ckpt["net"] = type(model.state_dict())((k, v.detach().cpu().clone()) for k, v in model.state_dict().items())
-            ckpt["optimizer"] = optimizer_state_dict(model, trainer.lr, float(config["lr"]))
-            # written to a temporary name and renamed: a job killed mid-write never leaves a truncated file under the final
-            # name (torch.save is not atomic); `<output>.done` marks a run that reached its last epoch (what the sweep checks)
-            torch.save(ckpt, args.output + ".tmp")
-            os.replace(args.output + ".tmp", args.output)
+            # three flat device-to-host copies here; the reference's per-tensor layout, torch.save to a temporary name and the rename
+            # (a job killed mid-write never leaves a truncated file under the final name) on a worker thread under the next epoch
+            writer.submit(args.output, ckpt, trainer.lr, float(config["lr"]))
+            if os.environ.get("CF_CKPT_SYNC") == "1":      # (A/B switch: the save on the critical path, as the reference has it)
+                writer.wait()
+        mark("epoch %d: checkpoint hand-off (flat copies to pinned memory; layout + torch.save on a worker thread)" % epoch)
         trainer.scheduler_step()
 
     if rank == 0:
+        writer.wait()                                 # the last checkpoint is on disk (or its error is raised) before the run vouches for it
+        mark("last checkpoint on disk")
         with open(args.output + ".done", "w") as f:
             f.write("epochs %d\n" % max(0, num_epoch - 1))
+    if args.timing and rank == 0:
+        total = marks[-1][1] - marks[0][1]
+        say("wall-clock breakdown (%.2f s):" % total)
+        for (_, t0), (what, t1) in zip(marks[:-1], marks[1:]):
+            say("  %8.3f s  %5.1f %%  %s" % (t1 - t0, 100 * (t1 - t0) / total, what))
     if val_loss is not None:
         key = "last_val_r2" if args.regression else "last_val_auc"
         wandb.summary.update({"last_val_loss": val_loss, key: ckpt[key]})
@@ -251,7 +381,7 @@ def main(argv=None):
     return 0
 
 
-def train_epoch(trainer, feed, batches, report=None, every=10):
+def train_epoch(trainer, feed, batches, report=None, every=10, after_issue=None):
     """The optimisation steps of one epoch (train.py:171-232): per step four host calls (graph replay, cf_rider_arm, the trunk's backward launch with its riders, reduction + AdamW) and no
     host synchronisation.  Every `every` steps an event is recorded; `report(logits, labels, losses)` receives each window
     of `every` steps as soon as its event has completed (polled, never waited for inside the epoch), read from the feed's
@@ -265,6 +395,8 @@ def train_epoch(trainer, feed, batches, report=None, every=10):
             while pending and pending[0][2].query():
                 lo, hi, _ = pending.pop(0)
                 report(*feed.window(lo, hi))
+    if after_issue is not None:                           # every step of the epoch is queued: background host work may take the interpreter
+        after_issue()
     for lo, hi, ev in pending:
         ev.synchronize()
         report(*feed.window(lo, hi))

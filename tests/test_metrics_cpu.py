@@ -41,3 +41,31 @@ def test_report_lines_equal_the_reference_formulas():
     got = logs[-1]
     assert abs(got["train/r2"] - metrics.r2_score(labr.flatten(), outr.flatten()) * 100) < 1e-3      # sklearn / scipy work in the float32 of their inputs
     assert abs(got["train/r"] - stats.pearsonr(labr.flatten(), outr.flatten())[0] * 100) < 1e-6
+
+
+def test_validation_metrics_equal_the_reference_calls():
+    """validation_metrics (numpy) against what train.py:277-318 calls: nn.CrossEntropyLoss / nn.MSELoss (the regressor's
+    broadcast [n, n] comparison included), sklearn accuracy / ROC AUC / average precision / r2, scipy pearsonr."""
+    import warnings
+    from scipy import stats
+    from sklearn import metrics
+    from chromoformer_amd.train import validation_metrics
+    rng = np.random.default_rng(2)
+    out = torch.from_numpy(rng.normal(size=(517, 2)).astype(np.float32) * 3)
+    lab = torch.from_numpy(rng.integers(0, 2, size=517))
+    loss, score, m = validation_metrics(out.numpy(), lab.numpy(), False)
+    assert loss.dtype == np.float32 and abs(float(loss) - float(torch.nn.CrossEntropyLoss()(out, lab))) < 1e-6
+    ref_score = out.softmax(axis=1)[:, 1].numpy()
+    assert score.dtype == ref_score.dtype and np.abs(score - ref_score).max() < 1e-6
+    assert abs(m["acc"] - metrics.accuracy_score(lab, out.argmax(axis=1)) * 100) < 1e-9
+    assert abs(m["auc"] - metrics.roc_auc_score(lab, ref_score) * 100) < 1e-4 and abs(m["ap"] - metrics.average_precision_score(lab, ref_score) * 100) < 1e-4
+    outr = torch.from_numpy(rng.normal(size=(300, 1)).astype(np.float32))
+    labr = torch.from_numpy((outr[:, 0] * 0.7 + rng.normal(size=300).astype(np.float32) * 0.5).numpy().astype(np.float32))
+    loss, score, m = validation_metrics(outr.numpy(), labr.numpy(), True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_loss = float(torch.nn.MSELoss()(outr, labr))          # [300, 1] against [300]: the reference's broadcast
+    assert abs(float(loss) - ref_loss) < 1e-5 * max(1.0, ref_loss)
+    assert score.dtype == np.float32 and np.array_equal(score, outr.flatten().numpy())
+    assert abs(m["r2"] - metrics.r2_score(labr.numpy(), outr.flatten().numpy()) * 100) < 1e-3
+    assert abs(m["r"] - stats.pearsonr(labr.numpy(), outr.flatten().numpy())[0] * 100) < 1e-4
