@@ -57,7 +57,7 @@ for ln in out.splitlines():
         print("  " + ln.strip()[:200])
     elif keep and ln.startswith("  "):
         print("  " + ln.rstrip()[:200])
-rows = re.findall(r"([0-9.]+) s\s+[0-9.]+ %\s+epoch (\d+): ([a-z ]+?)(?: \(|$)", out, re.M)
+rows = re.findall(r"([0-9.]+) s\s+[0-9.]+ %\s+epoch (\d+): ([a-z0-9 -]+?)(?: \(|$)", out, re.M)
 steps_n = {int(e): int(n) for e, n in re.findall(r"epoch (\d+): (\d+) steps", out)}
 per = {}
 for sec, e, what in rows:
