@@ -36,7 +36,8 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
         out[s] = {"hbm_bytes_per_launch": hbm, "fetch_kb": f, "write_kb": w, "instantiation": k}
 json.dump({"note": __doc__.split("\n\n")[0].replace("\n", " ") if False else
            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --no-graph`, bsz 64; hbm = (2*FETCH_SIZE + WRITE_SIZE) * 1024: "
-           "FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (calibrated on k_adamw)", "kernels": out},
+           "FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (calibrated on k_adamw)",
+           "commit": sys.argv[5] if len(sys.argv) > 5 else "unknown", "kernels": out},
           open(sys.argv[3], "w"), indent=1)
 with open(sys.argv[4], "w") as fh:
     fh.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch_corrected\n")

@@ -13,7 +13,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats --output-format csv
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch --output-format csv -- python3 $B --eager > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_write --output-format csv -- python3 $B --eager > /dev/null 2>&1
-python3 $R/tools/pmc_summary.py $(find /tmp/p_fetch -name "*counter_collection.csv" | head -1) $(find /tmp/p_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json $OUT/pmc_hbm_traffic.csv
+python3 $R/tools/pmc_summary.py $(find /tmp/p_fetch -name "*counter_collection.csv" | head -1) $(find /tmp/p_write -name "*counter_collection.csv" | head -1) $OUT/pmc_traffic.json $OUT/pmc_hbm_traffic.csv "${CF_COMMIT:-unknown}"
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p_mfma --output-format csv -- python3 $B --eager > /dev/null 2>&1
 python3 - <<PY
 import csv, collections
@@ -35,8 +35,12 @@ timeout 400 python3 bench.py --steps 300 --warmup 30 > $OUT/bench.json 2> /dev/n
 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --graph > $OUT/bench_graph.json 2> /dev/null
 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --roofline-kernel k_reg_fwd > $OUT/bench_k_reg_fwd.json 2> /dev/null
 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --roofline-kernel k_wgrad > $OUT/bench_k_wgrad.json 2> /dev/null
+timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --no-val-auroc --roofline-kernel k_trunk_fwd > $OUT/bench_k_trunk_fwd.json 2> /dev/null
+timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --no-val-auroc --roofline-kernel k_trunk_bwd > $OUT/bench_k_trunk_bwd.json 2> /dev/null
 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --regime realistic > $OUT/bench_realistic.json 2> /dev/null
 timeout 200 python3 bench.py --config stress --steps 20 --warmup 3 > $OUT/bench_stress.json 2> /dev/null
 CF_TRUNK=0 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 > $OUT/bench_no_trunk.json 2> /dev/null
 timeout 100 python3 tools/trunk_stamps.py > $OUT/trunk_stamps.txt 2> /dev/null
+timeout 100 python3 tools/bin_bench.py 2> /dev/null | tail -1 > $OUT/binning.json
+timeout 200 python3 tools/epoch_evidence.py --bench-genes-per-s $(python3 -c "import json; print(json.load(open('$OUT/bench.json'))['train_loop']['value'])" 2> /dev/null || echo 0) > $OUT/epoch_18955.txt 2>&1
 ls -la $OUT
