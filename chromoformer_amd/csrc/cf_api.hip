@@ -56,6 +56,10 @@ struct PDesc {
     bool trainable;
 };
 
+static int getenv_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 static std::string fmt(const char* f, ...) {
     char buf[256];
     va_list ap;
@@ -2331,6 +2335,24 @@ extern "C" int cf_op_attention_fwd(const cf_attn_shape* sh, const float* q, cons
     LAUNCH_CHECK("k_attn_fwd");
     return 0;
 }
+// dQ, dK, dV of the dense attention core (delta = rowsum(dO * O) is in a.delta already).  One fused pass per (sequence, head)
+// (k_attn_bwd: 5 tile products per key / query tile pair) when the launch has enough (sequence, head) workgroups to fill the chip;
+// otherwise the two kernels split by output owner (7 products per pair, but (Lk / 64 + Lq / 64) workgroups per sequence and head).
+// CF_ATTN_BWD_SPLIT=1 forces the split kernels, -1 the fused one (A/B runs, cross-checks in the tests; read at every call).  Same
+// results either way up to the order of the fp32 additions inside dQ.
+static int attn_bwd_launch(const AttnArgs& a, hipStream_t st) {
+    const int mode = getenv_int("CF_ATTN_BWD_SPLIT", 0);
+    if (mode < 0 || (mode == 0 && (long long)a.N * a.H >= 512)) {
+        hipLaunchKernelGGL(k_attn_bwd, dim3(a.H, a.N), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_attn_bwd");
+        return 0;
+    }
+    hipLaunchKernelGGL(k_attn_bwd_kv, dim3((a.Lk + kABk - 1) / kABk, a.H, a.N), dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_attn_bwd_kv");
+    hipLaunchKernelGGL(k_attn_bwd_q, dim3((a.Lq + kABq - 1) / kABq, a.H, a.N), dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_attn_bwd_q");
+    return 0;
+}
 extern "C" int cf_op_attention_bwd(const cf_attn_shape* sh, const float* q, const float* k, const float* v, const unsigned char* qvalid,
                                    const unsigned char* kvalid, const unsigned char* mask, const float* o, const float* stats,
                                    const float* d_o, float* dq, float* dk, float* dv, float* delta_ws, void* stream) {
@@ -2353,10 +2375,7 @@ extern "C" int cf_op_attention_bwd(const cf_attn_shape* sh, const float* q, cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_attn_delta, dim3((a.Lq + 15) / 16, a.H, a.N), dim3(256), 0, st, a);
     LAUNCH_CHECK("k_attn_delta");
-    hipLaunchKernelGGL(k_attn_bwd_kv, dim3((a.Lk + kABk - 1) / kABk, a.H, a.N), dim3(256), 0, st, a);
-    LAUNCH_CHECK("k_attn_bwd_kv");
-    hipLaunchKernelGGL(k_attn_bwd_q, dim3((a.Lq + kABq - 1) / kABq, a.H, a.N), dim3(256), 0, st, a);
-    LAUNCH_CHECK("k_attn_bwd_q");
+    if (attn_bwd_launch(a, st)) return -1;
     return 0;
 }
 
@@ -2627,10 +2646,7 @@ extern "C" int cf_op_dense_layer_bwd(const cf_dense_layer* w, const float* x_q, 
         a.delta = ws + L.delta;
         hipLaunchKernelGGL(k_attn_delta, dim3((Lq + 15) / 16, 2, N), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_attn_delta");
-        hipLaunchKernelGGL(k_attn_bwd_kv, dim3((Lk + kABk - 1) / kABk, 2, N), dim3(256), 0, st, a);
-        LAUNCH_CHECK("k_attn_bwd_kv");
-        hipLaunchKernelGGL(k_attn_bwd_q, dim3((Lq + kABq - 1) / kABq, 2, N), dim3(256), 0, st, a);
-        LAUNCH_CHECK("k_attn_bwd_q");
+        if (attn_bwd_launch(a, st)) return -1;
     }
     {   // input gradients: dx_q = dt1 (residual) + dq Wq;  dx_kv = dkv Wkv
         DgradArgs d;

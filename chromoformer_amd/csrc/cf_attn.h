@@ -399,4 +399,146 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_q(AttnArgs a) {
     }
 }
 
+// dQ, dK, dV in ONE pass (round 4): a workgroup owns one (sequence, head) and walks the key tiles (outer) and the query tiles (inner).
+// The split kernels above recompute S and dP in both of them: 7 tile products per (key tile, query tile) pair for 5 of algorithmic
+// work.  Here a pair is S^T, dP^T, dV += P^T dO, dK += dS^T Q (wave w = keys 16 w .. 16 w + 15 of the tile, as in k_attn_bwd_kv) and
+//   dQ[rows 16 w .. + 15 of the query tile] += dS[those rows][64 keys] . K[64 keys][64]
+// with the A operand read TRANSPOSED out of the four waves' dS^T patches (one more barrier per pair) and the K tile kept in LDS in
+// natural layout.  dQ is complete per query tile only after the last key tile: the wave adds its 16 x 64 block to the rows in global
+// memory every pair (read at the top of the pair, written at the bottom; the first key tile stores without reading).  One workgroup
+// per (sequence, head) owns those rows, the key tiles follow each other in a fixed order: no atomics, bit-reproducible.  The
+// read-modify-write is 8 KB per wave and pair against 320 MFMAs, and stays in L2 / Infinity Cache (205 KB per workgroup at L = 800).
+__global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
+    __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
+    __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];      // K tile, natural layout (B operand of the dQ product)
+    __shared__ __attribute__((aligned(16))) float Pt[4][16 * kALd];     // per-wave patches: p^T / ds^T [16 keys][64 rows]
+    const int n = blockIdx.y, h = blockIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
+    const float* qbase = a.q + (size_t)n * a.Lq * a.ldq + h * kADh;
+    const float* gbase = a.d_o + (size_t)n * a.Lq * a.ldo + h * kADh;
+    const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
+    const float* stp = a.stats + ((size_t)n * a.H + h) * a.Lq * 2;
+    const float* dlp = a.delta + ((size_t)n * a.H + h) * a.Lq;
+    float* dqb = a.dq + (size_t)n * a.Lq * a.ldq + h * kADh;
+    for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
+        // this wave's 16 keys as the A operand of S^T = K Q^T and dP^T = V dO^T
+        const int key_a = k0 + 16 * w + r;
+        float4 kf[4], vf[4];
+        {
+            const float* kp = a.k + ((size_t)n * a.Lk + min(key_a, a.Lk - 1)) * a.ldk + h * kADh;
+            const float* vp = a.v + ((size_t)n * a.Lk + min(key_a, a.Lk - 1)) * a.ldv + h * kADh;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kf[u] = key_a < a.Lk ? ldg4(kp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+                vf[u] = key_a < a.Lk ? ldg4(vp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        int keyi[4];
+        bool kv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            keyi[g] = k0 + 16 * w + 4 * qd + g;              // keys this lane holds in D layout (rows of S^T)
+            kv[g] = keyi[g] < a.Lk && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + keyi[g]] != 0 : true);
+        }
+        {
+            AttnTileRegs kr;
+            attn_fetch(kr, kbase, a.ldk, k0, a.Lk);
+            attn_put(Ks, kr);                                // (the barrier that ends a pair has let everybody finish with the previous Ks)
+        }
+        f32x4 dk[4], dv[4];
+        zero_acc(dk);
+        zero_acc(dv);
+        {   // first query tile of this key tile (the previous key tile's last pair has passed the barrier above: Qs / Gs are free)
+            AttnTileRegs qr, gr;
+            attn_fetch(qr, qbase, a.ldq, 0, a.Lq);
+            attn_fetch(gr, gbase, a.ldo, 0, a.Lq);
+            attn_put(Qs, qr);
+            attn_put(Gs, gr);
+        }
+        __syncthreads();
+        for (int q0 = 0; q0 < a.Lq; q0 += kABq) {
+            // the rows of dQ this wave will add to (D layout: row 4 qd + g of its 16, column 16 t + r), requested first
+            float dqo[4][4];
+            if (k0 > 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = min(q0 + 16 * w + 4 * qd + g, a.Lq - 1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dqo[g][t] = ldg(dqb + (size_t)row * a.ldq + 16 * t + r);
+                }
+            }
+            f32x4 st[4], dpt[4];                               // S^T, dP^T: rows = keys 4qd+g, columns = query 16t + r
+            zero_acc(st);
+            zero_acc(dpt);
+            attn_mma_nt(kf, Qs, st);
+            attn_mma_nt(vf, Gs, dpt);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = q0 + 16 * t + r;
+                const bool iv = i < a.Lq;
+                const float mrow = iv ? stp[2 * i] : 0.f, linv = iv ? stp[2 * i + 1] : 0.f, dl = iv ? dlp[i] : 0.f;
+                const bool qvi = iv && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + i] != 0 : true);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float p = 0.f, d = 0.f;
+                    if (iv && keyi[g] < a.Lk) {
+                        const bool mk = a.mask ? a.mask[((size_t)n * a.Lq + i) * a.Lk + keyi[g]] != 0 : !(qvi && kv[g]);
+                        const float x = mk ? kMaskFill : st[t][g] * a.rscale;
+                        p = __expf(x - mrow) * linv;
+                        d = mk ? 0.f : p * (dpt[t][g] - dl) * a.rscale;
+                    }
+                    st[t][g] = p;
+                    dpt[t][g] = d;
+                }
+            }
+            attn_store_d(&Pt[w][0], st);
+            __builtin_amdgcn_wave_barrier();
+            attn_mma_nn(&Pt[w][0], Gs, dv);                   // dV[16 keys x 64] += P^T[16 x 64 rows] . dO[64 rows x 64]
+            __builtin_amdgcn_wave_barrier();
+            attn_store_d(&Pt[w][0], dpt);
+            __builtin_amdgcn_wave_barrier();
+            attn_mma_nn(&Pt[w][0], Qs, dk);                   // dK += dS^T . Q
+            __syncthreads();                                  // all four dS^T patches are written; nobody reads Qs / Gs any more
+            f32x4 dq[4];
+            zero_acc(dq);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)                       // keys 16 u .. 16 u + 15: wave u's patch
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float av = Pt[u][(4 * qd + i) * kALd + 16 * w + r];      // dS[row 16 w + r][key 16 u + 4 qd + i]
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dq[t] = mfma4(av, Ks[(16 * u + 4 * qd + i) * kALd + 16 * t + r], dq[t]);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = q0 + 16 * w + 4 * qd + g;
+                if (row < a.Lq) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) stg(dqb + (size_t)row * a.ldq + 16 * t + r, k0 > 0 ? dqo[g][t] + dq[t][g] : dq[t][g]);
+                }
+            }
+            if (q0 + kABq < a.Lq) {      // the next query tile (requesting it in front of the dQ product costs 36 spilled VGPRs and buys nothing: two workgroups per CU cover it)
+                AttnTileRegs qr, gr;
+                attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
+                attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
+                attn_put(Qs, qr);
+                attn_put(Gs, gr);
+            }
+            __syncthreads();                                  // the next tile is in LDS; every wave is done with the patches and (last pair) Ks
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (keyi[g] >= a.Lk) continue;
+            float* dkp = a.dk + ((size_t)n * a.Lk + keyi[g]) * a.ldk + h * kADh;
+            float* dvp = a.dv + ((size_t)n * a.Lk + keyi[g]) * a.ldv + h * kADh;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dkp[16 * t + r] = dk[t][g];
+                dvp[16 * t + r] = dv[t][g];
+            }
+        }
+    }
+}
+
 }  // namespace cf

@@ -12,6 +12,14 @@ from oracle import chromoformer_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(params=["split", "fused"], autouse=True)
+def attention_backward_form(request, monkeypatch):
+    """Every test of this module runs twice: with the backward as two kernels split by output owner (k_attn_bwd_kv + k_attn_bwd_q)
+    and as the one-pass kernel (k_attn_bwd; the library picks it by itself only for launches with >= 512 (sequence, head) pairs)."""
+    monkeypatch.setenv("CF_ATTN_BWD_SPLIT", "1" if request.param == "split" else "-1")
+    return request.param
+
+
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
