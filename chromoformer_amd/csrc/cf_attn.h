@@ -402,25 +402,26 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_q(AttnArgs a) {
 // dQ, dK, dV in ONE pass (round 4): a workgroup owns one (sequence, head) and walks the key tiles (outer) and the query tiles (inner).
 // The split kernels above recompute S and dP in both of them: 7 tile products per (key tile, query tile) pair for 5 of algorithmic
 // work.  Here a pair is S^T, dP^T, dV += P^T dO, dK += dS^T Q (wave w = keys 16 w .. 16 w + 15 of the tile, as in k_attn_bwd_kv) and
-//   dQ[rows 16 w .. + 15 of the query tile] += dS[those rows][64 keys] . K[64 keys][64]
-// with the A operand read TRANSPOSED out of the four waves' dS^T patches (one more barrier per pair) and the K tile kept in LDS in
-// natural layout.  dQ is complete per query tile only after the last key tile: the wave adds its 16 x 64 block to the rows in global
-// memory every pair (read at the top of the pair, written at the bottom; the first key tile stores without reading).  One workgroup
-// per (sequence, head) owns those rows, the key tiles follow each other in a fixed order: no atomics, bit-reproducible.  The
-// read-modify-write is 8 KB per wave and pair against 320 MFMAs, and stays in L2 / Infinity Cache (205 KB per workgroup at L = 800).
+//   dQ^T[columns 16 w .. + 15 of the head][64 rows of the query tile] += K^T[those columns][64 keys] . dS^T[64 keys][64 rows]
+// -- the transposed form keeps everything a wave needs where it is: the A operand (16 columns of the K tile, 16 registers, loaded once
+// per key tile) in registers, the B operand = the four waves' dS^T patches in natural layout (one more barrier per pair), and the
+// result in the accumulator layout is, per query row, FOUR CONSECUTIVE head columns: the update of dQ in global memory is one 16-byte
+// load and one 16-byte store per lane and 16-row block.  dQ is complete only after the last key tile: every pair adds to the rows in
+// global memory (the first key tile stores without reading).  One workgroup per (sequence, head) owns those rows and the key tiles
+// follow each other in a fixed order: no atomics, bit-reproducible.  Two workgroups per CU: the 52 KB of LDS would allow the three the
+// other attention kernels run with, 170 registers do not (131 spilled VGPRs: backward 26.5 ms against 21.0 with two workgroups of
+// 256-register waves).  Stress configuration: backward 24.2 -> 21.0 ms (73.5 -> 84.9 TFLOP/s of algorithmic work).
 __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
     __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
-    __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];      // K tile, natural layout (B operand of the dQ product)
     __shared__ __attribute__((aligned(16))) float Pt[4][16 * kALd];     // per-wave patches: p^T / ds^T [16 keys][64 rows]
     const int n = blockIdx.y, h = blockIdx.x;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
     const float* qbase = a.q + (size_t)n * a.Lq * a.ldq + h * kADh;
     const float* gbase = a.d_o + (size_t)n * a.Lq * a.ldo + h * kADh;
-    const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
     const float* stp = a.stats + ((size_t)n * a.H + h) * a.Lq * 2;
     const float* dlp = a.delta + ((size_t)n * a.H + h) * a.Lq;
-    float* dqb = a.dq + (size_t)n * a.Lq * a.ldq + h * kADh;
+    float* dqb = a.dq + (size_t)n * a.Lq * a.ldq + h * kADh + 16 * w + 4 * qd;      // this lane's four columns
     for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
         // this wave's 16 keys as the A operand of S^T = K Q^T and dP^T = V dO^T
         const int key_a = k0 + 16 * w + r;
@@ -434,6 +435,21 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
                 vf[u] = key_a < a.Lk ? ldg4(vp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        // column 16 w + r of the K tile as the A operand of dQ^T = K^T dS^T: kt[u] = K[keys k0 + 16 u + 4 qd .. + 3][that column]
+        float4 kt[4];
+        {
+            const float* kc = a.k + (size_t)n * a.Lk * a.ldk + h * kADh + 16 * w + r;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = k0 + 16 * u + 4 * qd + i;
+                    v4[i] = key < a.Lk ? ldg(kc + (size_t)key * a.ldk) : 0.f;
+                }
+                kt[u] = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            }
+        }
         int keyi[4];
         bool kv[4];
 #pragma unroll
@@ -441,15 +457,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
             keyi[g] = k0 + 16 * w + 4 * qd + g;              // keys this lane holds in D layout (rows of S^T)
             kv[g] = keyi[g] < a.Lk && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + keyi[g]] != 0 : true);
         }
-        {
-            AttnTileRegs kr;
-            attn_fetch(kr, kbase, a.ldk, k0, a.Lk);
-            attn_put(Ks, kr);                                // (the barrier that ends a pair has let everybody finish with the previous Ks)
-        }
         f32x4 dk[4], dv[4];
         zero_acc(dk);
         zero_acc(dv);
-        {   // first query tile of this key tile (the previous key tile's last pair has passed the barrier above: Qs / Gs are free)
+        {   // first query tile of this key tile (the barrier that ended the previous key tile's last pair has freed Qs / Gs)
             AttnTileRegs qr, gr;
             attn_fetch(qr, qbase, a.ldq, 0, a.Lq);
             attn_fetch(gr, gbase, a.ldo, 0, a.Lq);
@@ -458,16 +469,6 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
         }
         __syncthreads();
         for (int q0 = 0; q0 < a.Lq; q0 += kABq) {
-            // the rows of dQ this wave will add to (D layout: row 4 qd + g of its 16, column 16 t + r), requested first
-            float dqo[4][4];
-            if (k0 > 0) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row = min(q0 + 16 * w + 4 * qd + g, a.Lq - 1);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dqo[g][t] = ldg(dqb + (size_t)row * a.ldq + 16 * t + r);
-                }
-            }
             f32x4 st[4], dpt[4];                               // S^T, dP^T: rows = keys 4qd+g, columns = query 16t + r
             zero_acc(st);
             zero_acc(dpt);
@@ -497,35 +498,42 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
             attn_mma_nn(&Pt[w][0], Gs, dv);                   // dV[16 keys x 64] += P^T[16 x 64 rows] . dO[64 rows x 64]
             __builtin_amdgcn_wave_barrier();
             attn_store_d(&Pt[w][0], dpt);
+            // the rows of dQ this lane adds to (query row q0 + 16 t + r, its four columns): requested here, behind the last use of S^T / dP^T
+            float4 dqo[4];
+            if (k0 > 0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dqo[t] = ldg4(dqb + (size_t)min(q0 + 16 * t + r, a.Lq - 1) * a.ldq);
+            }
             __builtin_amdgcn_wave_barrier();
             attn_mma_nn(&Pt[w][0], Qs, dk);                   // dK += dS^T . Q
             __syncthreads();                                  // all four dS^T patches are written; nobody reads Qs / Gs any more
-            f32x4 dq[4];
+            f32x4 dq[4];                                      // dQ^T: rows = head columns 16 w + 4 qd + g, columns = query row 16 t + r
             zero_acc(dq);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)                       // keys 16 u .. 16 u + 15: wave u's patch
+            for (int u = 0; u < 4; ++u) {                     // keys 16 u .. 16 u + 15: wave u's patch
+                const float a4[4] = {kt[u].x, kt[u].y, kt[u].z, kt[u].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float av = Pt[u][(4 * qd + i) * kALd + 16 * w + r];      // dS[row 16 w + r][key 16 u + 4 qd + i]
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) dq[t] = mfma4(av, Ks[(16 * u + 4 * qd + i) * kALd + 16 * t + r], dq[t]);
-                }
+                    for (int t = 0; t < 4; ++t) dq[t] = mfma4(a4[i], Pt[u][(4 * qd + i) * kALd + 16 * t + r], dq[t]);
+            }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = q0 + 16 * w + 4 * qd + g;
+            for (int t = 0; t < 4; ++t) {
+                const int row = q0 + 16 * t + r;
                 if (row < a.Lq) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) stg(dqb + (size_t)row * a.ldq + 16 * t + r, k0 > 0 ? dqo[g][t] + dq[t][g] : dq[t][g]);
+                    float4 v = make_float4(dq[t][0], dq[t][1], dq[t][2], dq[t][3]);
+                    if (k0 > 0) v = make_float4(v.x + dqo[t].x, v.y + dqo[t].y, v.z + dqo[t].z, v.w + dqo[t].w);
+                    stg4(dqb + (size_t)row * a.ldq, v);
                 }
             }
-            if (q0 + kABq < a.Lq) {      // the next query tile (requesting it in front of the dQ product costs 36 spilled VGPRs and buys nothing: two workgroups per CU cover it)
+            if (q0 + kABq < a.Lq) {      // the next query tile
                 AttnTileRegs qr, gr;
                 attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
                 attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
                 attn_put(Qs, qr);
                 attn_put(Gs, gr);
             }
-            __syncthreads();                                  // the next tile is in LDS; every wave is done with the patches and (last pair) Ks
+            __syncthreads();                                  // the next tile is in LDS; every wave is done with the patches
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
