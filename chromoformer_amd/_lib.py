@@ -88,6 +88,8 @@ SYMBOLS = {
     "cf_adamw_step_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "cf_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_backward_part": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_forward_train": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "cf_head_rides": (C.c_int, [C.c_void_p]),
     "cf_kernel_flops": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int]),
     "cf_cu_count": (C.c_int, [C.c_void_p]),
     "cf_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -233,6 +233,11 @@ struct cf_handle {
     bool trunk = false;                        // the Embedding + Pairwise stage runs as k_trunk_fwd / k_trunk_bwd (CF_TRUNK=0: the stand-alone kernels)
     size_t trunk_smem_bytes = 0;
     bool head_deferred = false;                // cf_forward(save = 2) left the head to cf_backward_part (k_head_train)
+    bool head_done = false;                    // cf_forward_train ran head forward + loss + head backward at the tail of the Regulation launch
+    bool head_loss_due = false;                // ... and the mean loss is still to be summed (by the Regulation backward launch)
+    bool head_ride = true;                     // CF_HEAD_RIDE=0 (read at cf_create): the head stays a launch of its own (k_head_train)
+    HeadRide ride;
+    int* head_cnt = nullptr;
     float* deferred_logits_user = nullptr;
     // riders of the next k_trunk_bwd launch (cf_rider_arm): leading Regulation weight-gradient tiles with AdamW in their epilogues
     struct Rider {
@@ -432,6 +437,7 @@ static void plan_workspace(cf_handle* h) {
     h->dhin = h->ws_get("dH.in", MB * 3 * kD);
     h->loss = h->ws_get("H.loss", 4);
     h->loss_part = h->ws_get("H.loss_part", MB + 1);      // (per 16-gene tile; per gene in the generic-width head)
+    h->head_cnt = reinterpret_cast<int*>(h->ws_get("H.cnt", MB + 1));      // arrivals per gene + genes done (cf_head_ride.h); zero between launches
     h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 64);      // shader-clock stamps (uint64) of the fused Regulation kernels
 }
 
@@ -854,6 +860,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     if (const char* e = getenv("CF_ATTC_CAP")) h->attc_cap = atoi(e);
     if (const char* e = getenv("CF_ATTC1")) h->attc1 = atoi(e) != 0;
     if (const char* e = getenv("CF_DEFER_RETILE")) h->defer_retile = atoi(e) != 0;
+    if (const char* e = getenv("CF_HEAD_RIDE")) h->head_ride = atoi(e) != 0;
     if (const char* e = getenv("CF_XCD_REDUCE")) h->xcd_reduce = h->xcd_reduce_opt = atoi(e) != 0;
     h->n_fwd = h->n_bwd = h->n_opt = 0;      // counted at the launch sites by the first calls (cf_launch_counts)
     *out = h;
@@ -1127,7 +1134,7 @@ static void head_fwd_args(const cf_handle* h, int B, float* logits_user, HeadFwd
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
-extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int save, void* stream) {
+static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int save, void* stream, const HeadRide* ride) {
     if (check_batch(h, bt)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const long long launches0 = g_launches;
@@ -1382,6 +1389,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         ra.freq = bt->interaction_freq;
         ra.save = save;
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
+        memset(&ra.head, 0, sizeof ra.head);
+        if (ride) ra.head = *ride;
         if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T, h->reg8, save != 0), dim3(8 * ((B * nres + 7) / 8)),
                        h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), ra, st))
             return -1;
@@ -1446,7 +1455,8 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
         launch_post_fwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         LAUNCH_CHECK("k_post_fwd<reg>");
     }
-    h->head_deferred = save == 2;
+    h->head_deferred = save == 2 && !ride;
+    h->head_done = ride != nullptr;
     h->deferred_logits_user = logits;
     if (save != 2 && c.d_head != kD) {
         HeadGenArgs a;
@@ -1467,6 +1477,45 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
 
 // ------------------------------------------------------------------------------------
 // backward
+extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int save, void* stream) {
+    return forward_impl(h, bt, logits, save, stream, nullptr);
+}
+// Can cf_forward_train run the head at the tail of the Regulation launch?  (512-thread Regulation kernels, three resolutions, the
+// default head width; CF_HEAD_RIDE=0 at cf_create switches it off: A/B runs, cross-checks.)
+extern "C" int cf_head_rides(cf_handle* h) {
+    if (!h) return 0;
+    return h->reg_fused && h->reg8 && h->cfg.n_res == kMaxRes && h->cfg.d_head == kD && h->head_ride ? 1 : 0;
+}
+// cf_forward(save_for_backward = 2) for a training step whose labels are known at forward time: where cf_head_rides(h), the
+// prediction head -- forward, loss, its backward down to the gradient of token 0 of every Regulation output -- runs at the tail of the
+// Regulation forward launch, by the last of a gene's three workgroups to finish (cf_head_ride.h), and the cf_backward_part /
+// cf_backward call that follows skips the head (its labels / loss arguments are ignored then).  Elsewhere it is cf_forward(save = 2).
+// logits: caller's [B, n_out] buffer (may be null); loss_out: one float (may be null); loss_scale as in cf_backward.
+extern "C" int cf_forward_train(cf_handle* h, const cf_batch* bt, float* logits, const void* labels, float loss_scale, float* loss_out,
+                                void* stream) {
+    if (!h) return fail("null handle");
+    if (!labels || !cf_head_rides(h)) return forward_impl(h, bt, logits, 2, stream, nullptr);
+    if (!h->grads) return fail("cf_forward_train: no gradient buffer bound");
+    const cf_config& c = h->cfg;
+    HeadRide hd;
+    memset(&hd, 0, sizeof hd);
+    hd.on = 1;
+    hd.n_out = c.n_out;
+    hd.gscale = loss_scale;
+    hd.labels = labels;
+    hd.w1_t = h->T_("fc_head.0.weight");
+    hd.w1 = h->P_("fc_head.0.weight");
+    hd.b1 = h->P_("fc_head.0.bias");
+    hd.w2 = h->P_("fc_head.2.weight");
+    hd.b2 = h->P_("fc_head.2.bias");
+    hd.hin = h->hin, hd.h1 = h->h1, hd.logits = h->logits, hd.logits_user = logits, hd.dlogits = h->dlogits, hd.dh1 = h->dh1, hd.dhin = h->dhin;
+    for (int r = 0; r < c.n_res; ++r) hd.dxl[r] = h->dRx[r][c.reg_layers];
+    hd.loss = h->loss, hd.loss_part = h->loss_part, hd.loss_user = loss_out;
+    hd.cnt = h->head_cnt;
+    h->ride = hd;                 // (the backward launch finishes the mean loss)
+    return forward_impl(h, bt, logits, 2, stream, &hd);
+}
+
 // ------------------------------------------------------------------------------------
 // parts: 1 = head, 2 = Regulation stack, 4 = Pairwise + Embedding (the activation-gradient chain in order)
 static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int parts = 7, const void* labels = nullptr,
@@ -1475,6 +1524,11 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
     const float scale_c = sqrtf(64.f);
+    if ((parts & 1) && h->head_done) {         // cf_forward_train has run head forward, loss and head backward already
+        h->head_done = false;
+        h->head_loss_due = true;
+        parts &= ~1;
+    }
     if ((parts & 1) && c.d_head != kD) {      // loss + head, any hidden width
         if (h->head_deferred && !labels) return fail("cf_backward: cf_forward(save_for_backward = 2) needs the fused loss (labels)");
         HeadGenArgs a;
@@ -1533,6 +1587,12 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         ra.freq = bt->interaction_freq;
         ra.save = 1;
         ra.tdbg = getenv("CF_STAMP_BWD") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
+        memset(&ra.head, 0, sizeof ra.head);
+        if (h->head_loss_due) {
+            ra.head = h->ride;
+            if (loss_out) ra.head.loss_user = loss_out;
+            h->head_loss_due = false;
+        }
         if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T, h->reg8), dim3(8 * ((B * nres + 7) / 8)),
                        h->reg8 ? reg8_bwd_smem(c.reg_dff) : reg_bwd_smem(T), ra, st))
             return -1;
@@ -1818,7 +1878,7 @@ extern "C" int cf_backward_part(cf_handle* h, const cf_batch* bt, const void* la
                                 void* stream) {
     if (check_bwd(h, bt, (parts & 1) != 0)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    if ((parts & 1) && !labels) return fail("cf_backward: labels is null");
+    if ((parts & 1) && !labels && !h->head_done) return fail("cf_backward: labels is null");
     const long long launches0 = g_launches;
     if (parts & 1) h->n_bwd = h->n_opt = 0;      // a backward pass starts with the head: its pieces, the bucket reductions and the optimiser launches add up
     const int rc = backward_impl(h, bt, st, parts, labels, loss_scale, loss_out);

@@ -2310,6 +2310,8 @@ __global__ __launch_bounds__(256) void k_dense_cs_tables(DenseCsTab a) {
 
 }  // namespace cf
 
+#include "cf_valu_mv.h"
+#include "cf_head_ride.h"
 #include "cf_reg_fused.h"
 #include "cf_reg8.h"
 #include "cf_attc2.h"

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2.  XCD x
     // takes the contiguous slice [x * per, (x + 1) * per) of the (resolution-major) sequence list, so six XCDs stream
     // the weights of one resolution (5.5 MB) and two of them those of two, instead of all eight streaming all three.
+    if (SAVE && a.head.on && blockIdx.x == 0) head_ride_begin(a.head, a.B);
     const int per = gridDim.x >> 3, v = a.xcd_map ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : (int)blockIdx.x;
     if (v >= a.B * a.n_res) return;
     const int g = __builtin_amdgcn_readfirstlane(v % a.B), r = __builtin_amdgcn_readfirstlane(v / a.B), T = a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
@@ -481,6 +482,9 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         CF_STAMP8(8);
         __syncthreads();
     }
+    // the prediction head of the gene, forward + loss + backward, by the last of its resolutions' workgroups to get here (cf_head_ride.h);
+    // row 0 of xs is the stack's output for token 0, everything behind it in the LDS is free
+    if (SAVE && a.head.on) head_ride_tail(a.head, g, r, a.B, T, a.n_res, xs, load_layer(tab).xin + (size_t)row0 * kD, as_);
 }
 
 // Backward of the same stack.  LDS: ds = d(layer output) -> dy1 -> dt1 -> d(layer input); t2 = dt2; wide = dpre1;
@@ -488,6 +492,8 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
 template <int DFF>
 __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool ride_loss = a.head.on && blockIdx.x == 0 && (threadIdx.x >> 6) == 7;      // (the head ran at the tail of the forward launch: cf_head_ride.h)
+    const float ride_l = ride_loss ? head_ride_loss_request(a.head, a.B) : 0.f;
     const int per = gridDim.x >> 3, v = a.xcd_map ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : (int)blockIdx.x;
     if (v >= a.B * a.n_res) return;
     const int g = __builtin_amdgcn_readfirstlane(v % a.B), r = __builtin_amdgcn_readfirstlane(v / a.B), T = a.T, TT = T * T, row0 = g * T, tid = threadIdx.x;
@@ -756,6 +762,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         CF_STAMP8(6);
         __syncthreads();
     }
+    if (ride_loss) head_ride_loss(a.head, a.B, ride_l);
 }
 
 }  // namespace cf

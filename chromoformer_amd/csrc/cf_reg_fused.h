@@ -24,6 +24,7 @@ struct RegArgs {
     const float* freq;               // [B,T,T]
     int save;
     unsigned long long* tdbg;        // optional: shader-clock stamps of workgroup (0,0), 16 per layer
+    HeadRide head;                   // forward (cf_reg8.h): the gene's prediction head at the tail of its last workgroup (cf_head_ride.h)
 };
 #define CF_STAMP(slot)                                                                                 \
     do {                                                                                               \

@@ -282,8 +282,10 @@ class Trainer:
         if feed is not None:
             _lib.check(L.cf_gather_batch(m._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
                                          C.byref(slot.struct), slot.label.data_ptr(), st), "cf_gather_batch")
-        # save = 2: the head is left to cf_backward_part, where head forward, loss and head backward are one launch
-        _lib.check(L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 2, st), "cf_forward")
+        # the training forward: head forward, loss and head backward at the tail of the Regulation launch where the library can
+        # (cf_head_rides), else left to cf_backward_part, where the three are one launch; part 1 below is a no-op in the first case
+        _lib.check(L.cf_forward_train(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), slot.label.data_ptr(), 1.0 / self.world,
+                                      slot.loss.data_ptr(), st), "cf_forward_train")
         self._part(slot, st, 3)
         if feed is not None:
             _lib.check(L.cf_record_step(m._handle, feed.cursor.data_ptr(), slot.logits.data_ptr(), slot.label.data_ptr(),

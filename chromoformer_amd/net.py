@@ -304,10 +304,14 @@ class ChromoformerBase(nn.Module):
     def forward_backward(self, packed, labels, loss_scale=1.0):
         """Fused forward + loss + backward.  Returns (logits, loss tensor on device)."""
         bs, _ = packed
-        logits = self._run_forward(bs, save=2)       # filled by cf_backward below (head forward + loss + head backward: one launch)
         labels = labels.to(self._device)
         labels = labels.float().contiguous() if self.n_out == 1 else labels.long().contiguous()
         st = torch.cuda.current_stream(self._device).cuda_stream
+        # head forward + loss + head backward at the tail of the Regulation forward launch where the library can (cf_forward_train),
+        # else as one launch inside the cf_backward below; logits / loss are filled by whichever runs
+        logits = torch.empty(bs.B, self.n_out, device=self._device)
+        _lib.check(_lib.lib().cf_forward_train(self._handle, C.byref(bs), logits.data_ptr(), labels.data_ptr(), float(loss_scale),
+                                               self._loss_buf.data_ptr(), st), "cf_forward_train")
         _lib.check(_lib.lib().cf_backward(self._handle, C.byref(bs), labels.data_ptr(), float(loss_scale),
                                           self._loss_buf.data_ptr(), st), "cf_backward")
         self._grads_stale = False

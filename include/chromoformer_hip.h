@@ -113,6 +113,14 @@ int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg, float* ex
  * call that must follow with labels: head forward, loss and head backward then run as one launch, and `logits` (which has to
  * stay valid until then) is written by that call -- the training step of a caller that does not need the logits in between. */
 int cf_forward(cf_handle* h, const cf_batch* batch, float* logits, int save_for_backward, void* stream);
+/* cf_forward(save_for_backward = 2) for a training step whose labels are known at forward time (train.py:182-193: they always are).
+ * Where cf_head_rides(h) -- the 512-thread Regulation kernels, three resolutions, d_head = 128 -- the prediction head (net.py:377-380),
+ * the loss (train.py:156) and the head's backward run at the TAIL of the Regulation forward launch, on the last of a gene's three
+ * workgroups to finish, instead of in a launch of their own; the cf_backward_part / cf_backward call that follows skips the head
+ * (its labels / loss arguments are ignored).  Elsewhere identical to cf_forward(..., 2, ...).  logits / loss_out may be null. */
+int cf_forward_train(cf_handle* h, const cf_batch* batch, float* logits, const void* labels, float loss_scale,
+                     float* loss_out, void* stream);
+int cf_head_rides(cf_handle* h);
 /* criterion(out, label) + loss.backward() (train.py:156, 193-195).  labels: int64 [B]
  * (n_out = 2, CrossEntropyLoss) or float [B] (n_out = 1, MSELoss).  `loss_scale`
  * multiplies the mean-over-B loss gradient (1.0 single GPU; 1/world for an all-reduce SUM).
