@@ -13,8 +13,9 @@
 //   backward  { post chain -> attention -> q chain } x layers (last to first) -> join + lin_proj_p backward
 //                -> [post chain -> attention -> q chain] of the Embedding layer -> 7-mark projection partials of the gene
 //
-// The phases are the BODIES of the stand-alone kernels (cf_kernels.h, cf_attc1.h, cf_attc2.h), unchanged arithmetic in
-// unchanged order: activations of the forward pass are bit-identical to the unfused path.  Between two phases the rows travel
+// The Pairwise phases and both attentions are the BODIES of the stand-alone kernels (cf_kernels.h, cf_attc1.h, cf_attc2.h), unchanged
+// arithmetic in unchanged order; the Embedding layer's one-row chains run on the vector ALUs (cf_trunk_e.h, round 4: same products,
+// another summation order -- the fused and the stand-alone path agree to fp32 rounding).  Between two phases the rows travel
 // through global memory exactly as between two launches -- but written and read by the same workgroup, i.e. out of the CU's
 // own L1 / the XCD's L2 behind a workgroup barrier (workgroup-scope release / acquire: all waves of a workgroup share the L1)
 // instead of across a launch boundary -- and the S regions' features, masks and Wlp are staged in LDS ONCE for all Pairwise
@@ -168,38 +169,8 @@ __device__ __forceinline__ void trunk_attc_args(Attc2Args& at, const TrunkCtx& c
 }  // namespace cf
 #include "cf_trunk_e.h"      // the Embedding layer's one-row chains on the vector ALUs
 namespace cf {
-#ifndef CF_TRUNK_E_VALU      // 0: the Embedding layer's chains as 16-row matrix-core tiles (round 3; A/B switch)
-#define CF_TRUNK_E_VALU 1
-#endif
 
 // ---- forward phases
-CF_PHASE void trunk_x0_qchain_e(TrunkCtx c, float* smem) {
-    const TrunkResDev* R = c.R;
-    const int g = c.g, tid = threadIdx.x;
-    CF_CHAIN_TILES(smem);
-    if (tid < kD) {
-        X0Args x;
-        x.feats[0] = c.feats;
-        x.pe[0] = TF(pe);
-        x.wlp[0] = TF(wlp_e);
-        x.x0[0] = TF(ex0);
-        x.featc[0] = TF(featc);
-        x.L[0] = TF(L);
-        x.F = c.F;
-        embed_x0_row(x, 0, g, tid);
-    }
-    __syncthreads();
-    QChainArgs q;
-    q.x[0] = TF(ex0);
-    q.xmap = identity_map();
-    q.wq[0] = TF(E.wq_t);
-    q.wk[0] = TF(E.wk);
-    q.q[0] = TF(E.q);
-    q.qt[0] = TF(E.qt);
-    q.xcopy[0] = nullptr;
-    q.N = g + 1;
-    qchain_fwd_body<kAT / 64>(q, 0, g, xs, as_);
-}
 template <bool BWD>
 CF_PHASE void trunk_attc1_e(TrunkCtx c, float* smem) {
     const TrunkResDev* R = c.R;
@@ -231,22 +202,6 @@ __device__ __forceinline__ void trunk_post_args(PostArgs& po, const CentreLayerD
     po.save = save;
     po.lin_w[0] = nullptr;
     po.nq_wq[0] = nullptr;
-}
-template <int DFF>
-CF_PHASE void trunk_post_e(TrunkCtx c, float* smem) {
-    const TrunkResDev* R = c.R;
-    const int g = c.g;
-    CF_CHAIN_TILES(smem);
-    PostArgs po;
-    trunk_post_args(po, &R->E, c.save);
-    po.x[0] = TF(ex0);
-    po.xmap = identity_map();
-    po.out[0] = TF(rx0);
-    po.omap = RowMap{1, c.T, 0, 0};        // token 0 of the gene's Regulation input
-    po.N = g + 1;
-    po.lin_w[0] = TF(lin_p_t);             // lin_proj_p on the centre embedding (net.py:118)
-    po.lin_y[0] = TF(xp0);
-    post_fwd_body<true, 128, DFF, kAT / 64>(po, 0, g, g + 1, xs, as_, ts, reinterpret_cast<float (*)[PostFwdLds<DFF>::HW + 4]>(wide_raw));
 }
 CF_PHASE void trunk_qchain_p0(TrunkCtx c, float* smem) {
     const TrunkResDev* R = c.R;
@@ -339,13 +294,11 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
         launder(c, sm, persist);
     }
     // ---------------------------------------------------------------- Embedding layer: one row (the promoter's centre bin)
-    if (CF_TRUNK_E_VALU) trunk_e_front(c, sm);
-    else trunk_x0_qchain_e(c, sm);
+    trunk_e_front(c, sm);
     CF_NEXT_PHASE;
     trunk_attc1_e<false>(c, sm);
     CF_NEXT_PHASE;
-    if (CF_TRUNK_E_VALU) trunk_e_post_fwd<DFF_E>(c, sm);
-    else trunk_post_e<DFF_E>(c, sm);
+    trunk_e_post_fwd<DFF_E>(c, sm);
     // ---------------------------------------------------------------- Pairwise stack: S rows (the gene's pairs)
     c.feats = a.cfeats[r];
     c.mask = a.cmask[r];
@@ -456,19 +409,6 @@ CF_PHASE void trunk_join(TrunkCtx c, const float* dhin, int r, int n_res, float*
         const float res = ldg(TF(drx0) + (size_t)g * c.T * kD + tid) + ldg(dhin + (size_t)g * (n_res * kD) + r * kD + tid);
         stg(TF(edout) + (size_t)g * kD + tid, v + res);
     }
-}
-template <int DFF>
-CF_PHASE void trunk_post_bwd_e(TrunkCtx c, float* smem) {
-    const TrunkResDev* R = c.R;
-    const int g = c.g;
-    CF_CHAIN_TILES(smem);
-    CF_BWD_TILES(DFF);
-    PostBwdArgs pb;
-    trunk_post_bwd_args(pb, &R->E);
-    pb.dout[0] = TF(edout);
-    pb.dmap = identity_map();
-    pb.N = g + 1;
-    post_bwd_body<true, 128, DFF, kAT / 64>(pb, 0, g, g + 1, g, xs, as_, ts, wide);
 }
 // The 7-mark projection partials of the gene (k_wgrad_lp's arithmetic, same order): dW[e][f] = sum over the job's segments and
 // rows of A[m][e] B[m][f].  The <= 80 operand rows of both jobs (this workgroup wrote them a few phases ago) are staged in LDS
@@ -583,13 +523,11 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
     c.mask = a.pmask[r];
     c.mstride = a.pmstride[r];
     CF_NEXT_PHASE;
-    if (CF_TRUNK_E_VALU) trunk_e_post_bwd<DFF_E>(c, sm);
-    else trunk_post_bwd_e<DFF_E>(c, sm);
+    trunk_e_post_bwd<DFF_E>(c, sm);
     CF_NEXT_PHASE;
     trunk_attc1_e<true>(c, sm);
     CF_NEXT_PHASE;
-    if (CF_TRUNK_E_VALU) trunk_e_q_bwd(c, sm);
-    else trunk_qchain_bwd(c, &c.R->E, c.g, c.g + 1, sm);
+    trunk_e_q_bwd(c, sm);
     // ---------------------------------------------------------------- 7-mark projection partials of this gene (k_wgrad_lp)
     CF_NEXT_PHASE;
     trunk_lp(a.lp_jobs, r, c.g, a.B, sm);
