@@ -102,7 +102,7 @@ def train_loop_rate(model, lr, steps, store_genes, regime, dev):
     el = time.perf_counter() - t0
     return {"value": round(BSZ * done / el, 1), "unit": "genes/s", "ms_per_step": round(1e3 * el / done, 4), "steps": done,
             "store_genes": store_genes, "host_calls_per_step": ((4 if trainer.rider_tiles else 2) if trainer.fuse_one else 4) if trainer.fuse_opt else 3,
-            "what": "chromoformer_amd.train.train_epoch over a resident synthetic split: cf_gather_batch + cf_record_step inside "
+            "what": "chromoformer_amd.train.train_epoch over a resident synthetic split: batch gather (in the forward prologue launch) + cf_record_step inside "
                     "the step graph, running metrics (train.py:205-232) on every 10-step window"}
 
 

@@ -235,6 +235,9 @@ struct cf_handle {
     bool head_deferred = false;                // cf_forward(save = 2) left the head to cf_backward_part (k_head_train)
     bool head_done = false;                    // cf_forward_train ran head forward + loss + head backward at the tail of the Regulation launch
     bool head_loss_due = false;                // ... and the mean loss is still to be summed (by the Regulation backward launch)
+    bool pend_gather = false;                  // cf_gather_batch_fwd: the gather of the step shares a launch with the next forward's prologue
+    GatherArgs pend_ga;
+    int pend_ga_n = 0;
     bool head_ride = true;                     // CF_HEAD_RIDE=0 (read at cf_create): the head stays a launch of its own (k_head_train)
     HeadRide ride;
     int* head_cnt = nullptr;
@@ -1134,6 +1137,7 @@ static void head_fwd_args(const cf_handle* h, int B, float* logits_user, HeadFwd
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
+static int gather_launch(const GatherArgs& ga, int n, hipStream_t st);      // (with the gather entry points below)
 static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int save, void* stream, const HeadRide* ride) {
     if (check_batch(h, bt)) return -1;
     hipStream_t st = (hipStream_t)stream;
@@ -1146,6 +1150,7 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
     for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
     const bool defer = h->defer_retile && !h->embed_dense && kPostWaves == 8;      // Regulation + head units ride in the Embedding layer's chain launch
     const bool trunk = h->trunk;                                                   // Embedding + Pairwise stage as ONE launch (cf_trunk.h)
+    int* adv_cursor = nullptr;
     {   // refresh the tiled weight copies (the parameters may have been changed by anyone since the last call) and, in the same
         // launch, the Embedding centre-row input
         X0Args a;
@@ -1159,10 +1164,20 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         }
         a.F = F;
         const int n_now = defer ? h->n_retile_early : h->n_retile;
-        // (the fused trunk computes the Embedding input row itself: no x0 workgroups then)
-        hipLaunchKernelGGL(k_fwd_prologue, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
-                           h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, n_now, a, B);
-        LAUNCH_CHECK("k_fwd_prologue");
+        const bool with_gather = h->pend_gather && trunk && h->pend_ga.B == B;
+        if (h->pend_gather && !with_gather && gather_launch(h->pend_ga, h->pend_ga_n, st)) return -1;      // (launches of their own, as cf_gather_batch)
+        if (with_gather) {      // the step's batch gather in the same launch (cf_gather_batch_fwd); the trunk's forward launch advances the cursor
+            hipLaunchKernelGGL(k_prologue_gather, dim3(n_now + B * h->pend_ga_n), dim3(256), 0, st, (const float*)h->params, h->tiled,
+                               h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, n_now, h->pend_ga);
+            LAUNCH_CHECK("k_prologue_gather");
+        } else {
+            // (the fused trunk computes the Embedding input row itself: no x0 workgroups then)
+            hipLaunchKernelGGL(k_fwd_prologue, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
+                               h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, n_now, a, B);
+            LAUNCH_CHECK("k_fwd_prologue");
+        }
+        h->pend_gather = false;
+        if (with_gather) adv_cursor = h->pend_ga.cursor;
     }
     if (trunk) {
         TrunkArgs ta;
@@ -1174,6 +1189,7 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             ta.rt_tiled = h->tiled;
             ta.rt_tiledT = h->reg8 ? h->tiledT : nullptr;
         }
+        ta.adv_cursor = adv_cursor;
         void* kargs[] = {&ta};
         h->time_mark("k_trunk_fwd", st);
         HIP_TRY(hipLaunchKernel(trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers), dim3(B, nres + (defer && ta.rt_n > 0 ? 1 : 0)), dim3(kAT), kargs,
@@ -2235,15 +2251,13 @@ extern "C" int cf_launch_counts(cf_handle* h, int* fwd, int* bwd, int* opt) {
 // ------------------------------------------------------------------------------------
 // resident split: batch gather / step log inside the graph
 // ------------------------------------------------------------------------------------
-extern "C" int cf_gather_batch(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst,
-                               void* stream) {
+static int gather_args(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst, GatherArgs& ga, int& n) {
     if (!h || !st_ || !order || !cursor || !dst) return fail("cf_gather_batch: null argument");
     const cf_config& c = h->cfg;
     const int B = dst->B, S = c.i_max, T = S + 1, F = c.n_feats;
     if (B < 1 || B > c.max_batch) return fail("cf_gather_batch: B = %d outside [1, max_batch = %d]", B, c.max_batch);
-    GatherArgs ga;
     memset(&ga, 0, sizeof ga);
-    int n = 0;
+    n = 0;
     bool overflow = false;
     auto push = [&](const void* src, const void* d, long long gene_bytes) {
         const int chunk = kGatherChunk;
@@ -2272,11 +2286,32 @@ extern "C" int cf_gather_batch(cf_handle* h, const cf_store* st_, const int* ord
     ga.cursor = cursor;
     ga.n_genes = st_->n_genes;
     ga.B = B;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gather_batch, dim3(B, n), dim3(256), 0, st, ga);
+    return 0;
+}
+static int gather_launch(const GatherArgs& ga, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_batch, dim3(ga.B, n), dim3(256), 0, st, ga);
     LAUNCH_CHECK("k_gather_batch");
-    hipLaunchKernelGGL(k_gather_advance, dim3(1), dim3(1), 0, st, cursor);
+    hipLaunchKernelGGL(k_gather_advance, dim3(1), dim3(1), 0, st, ga.cursor);
     LAUNCH_CHECK("k_gather_advance");
+    return 0;
+}
+extern "C" int cf_gather_batch(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst,
+                               void* stream) {
+    GatherArgs ga;
+    int n;
+    if (gather_args(h, st_, order, cursor, dst, labels_dst, ga, n)) return -1;
+    return gather_launch(ga, n, (hipStream_t)stream);
+}
+// cf_gather_batch for the batch of a TRAINING step: nothing is launched here; the cf_forward / cf_forward_train that must follow on
+// the same stream (same batch buffers) copies the genes in the launch that refreshes its tiled weight copies -- the two do not depend
+// on each other -- and advances the cursor.  Three launches in front of every step of the training loop become one.
+extern "C" int cf_gather_batch_fwd(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst,
+                                   void* stream) {
+    (void)stream;
+    int n;
+    if (gather_args(h, st_, order, cursor, dst, labels_dst, h->pend_ga, n)) return -1;
+    h->pend_ga_n = n;
+    h->pend_gather = true;
     return 0;
 }
 

@@ -22,12 +22,12 @@ struct GatherArgs {
     long long n_genes;    // genes in the store
     int B;
 };
-__global__ __launch_bounds__(256) void k_gather_batch(GatherArgs a) {
-    const GatherSeg s = a.seg[blockIdx.y];
-    const int b = blockIdx.x;
+// one 4 KB chunk (segment s) of gene slot b of the batch
+__device__ __forceinline__ void gather_block(const GatherArgs& a, const int b, const int segi) {
+    const GatherSeg s = a.seg[segi];
     const int cur = a.cursor[0];
     if (cur < 0 || cur >= a.cursor[1]) {      // a step past the uploaded epoch: nothing is read (the batch buffers keep the last batch)
-        if (threadIdx.x == 0 && b == 0 && blockIdx.y == 0) a.cursor[2] |= 1;
+        if (threadIdx.x == 0 && b == 0 && segi == 0) a.cursor[2] |= 1;
         return;
     }
     const long long gene = a.order[(long long)cur * a.B + b];
@@ -43,6 +43,19 @@ __global__ __launch_bounds__(256) void k_gather_batch(GatherArgs a) {
         for (int i = threadIdx.x; i < s.len / 16; i += 256) d4[i] = s4[i];
     } else {
         for (int i = threadIdx.x; i < s.len; i += 256) dst[i] = src[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_batch(GatherArgs a) { gather_block(a, blockIdx.x, blockIdx.y); }
+// The gather of a training step and the prologue of its forward pass (the tiled weight copies the first kernels read) do not depend on
+// each other: one launch (cf_gather_batch_fwd + the cf_forward that follows; the cursor is advanced by the trunk's forward launch
+// behind it).  6.5 + 1 + 6 us as three launches in front of every step of the training loop.
+__global__ __launch_bounds__(256) void k_prologue_gather(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
+                                                         const RetileUnit* __restrict__ units, int n_units, GatherArgs ga) {
+    if ((int)blockIdx.x < n_units) {
+        retile_unit(params, tiled, tiledT, units[blockIdx.x]);
+    } else {
+        const int i = (int)blockIdx.x - n_units;
+        gather_block(ga, i % ga.B, i / ga.B);
     }
 }
 // The cursor is advanced by a launch of its own behind the gather (a ticket counter that lets the last workgroup do it

@@ -60,6 +60,7 @@ struct TrunkArgs {
     float* rt_tiled;
     float* rt_tiledT;
     int rt_n;
+    int* adv_cursor;                   // forward, optional: the batch cursor of a gather that shared the launch in front (k_prologue_gather): advanced here
     const LpJob* lp_jobs;              // backward: the 7-mark projection jobs, [2 r] = Embedding, [2 r + 1] = Pairwise of resolution r
     // backward, single-GPU training: the first rd_n weight-gradient tiles of the Regulation bucket (all equally long), with AdamW in
     // their epilogues, walked by an extra row of workgroups on the CUs the trunk leaves idle (k_trunk_bwd; cf_rider_arm)
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(kAT) void k_trunk_fwd(TrunkArgs a) {
         }
         return;
     }
+    if (a.adv_cursor && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.adv_cursor[0] < a.adv_cursor[1]) a.adv_cursor[0] += 1;
     // resolutions in reverse launch order: the long-sequence workgroups (last binsize) are dispatched first
     const int r = a.n_res - 1 - (int)blockIdx.y;
     const TrunkResDev* R = a.tab + r;

@@ -280,8 +280,9 @@ class Trainer:
         m, L = self.model, self._L
         feed = getattr(slot, "feed", None)
         if feed is not None:
-            _lib.check(L.cf_gather_batch(m._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
-                                         C.byref(slot.struct), slot.label.data_ptr(), st), "cf_gather_batch")
+            # (shares a launch with the prologue of the forward below: cf_gather_batch_fwd)
+            _lib.check(L.cf_gather_batch_fwd(m._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
+                                             C.byref(slot.struct), slot.label.data_ptr(), st), "cf_gather_batch_fwd")
         # the training forward: head forward, loss and head backward at the tail of the Regulation launch where the library can
         # (cf_head_rides), else left to cf_backward_part, where the three are one launch; part 1 below is a no-op in the first case
         _lib.check(L.cf_forward_train(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), slot.label.data_ptr(), 1.0 / self.world,

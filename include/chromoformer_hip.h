@@ -348,6 +348,12 @@ typedef struct cf_store {
  * cursor[2] = error flags (sticky until the caller clears them), cursor[3] reserved. */
 int cf_gather_batch(cf_handle* h, const cf_store* store, const int* order, int* cursor, const cf_batch* dst,
                     void* labels_dst, void* stream);
+/* cf_gather_batch for the batch of a TRAINING step: launches nothing; the cf_forward / cf_forward_train that must follow on the same
+ * stream (with `dst` as its batch) copies the genes in the launch that refreshes its tiled weight copies -- neither depends on the other --
+ * and its trunk launch advances the cursor: the three launches in front of every step of the training loop become one.  Configurations
+ * without the fused trunk kernels: the forward issues the two gather launches itself, as cf_gather_batch would. */
+int cf_gather_batch_fwd(cf_handle* h, const cf_store* store, const int* order, int* cursor, const cf_batch* dst,
+                        void* labels_dst, void* stream);
 /* Appends the step's logits [B, n_out], labels [B] and loss to per-epoch device logs at row cursor[0] - 1 (capturable;
  * what the loop's running metrics, train.py:198-232, read every tenth step instead of cloning tensors every step).
  * The logs must hold cursor[1] rows; nothing is written for a step past the epoch (cursor[2] bit 0). */
