@@ -116,6 +116,7 @@ SYMBOLS = {
     "cf_embed_full": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.POINTER(C.c_void_p), C.c_void_p]),
     "cf_gather_batch": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
     "cf_gather_batch_fwd": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
+    "cf_record_step_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_record_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_op_dense_layer_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "cf_op_dense_layer_fwd": (C.c_int, [C.POINTER(cf_dense_layer)] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 3),

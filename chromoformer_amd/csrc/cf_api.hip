@@ -235,6 +235,8 @@ struct cf_handle {
     bool head_deferred = false;                // cf_forward(save = 2) left the head to cf_backward_part (k_head_train)
     bool head_done = false;                    // cf_forward_train ran head forward + loss + head backward at the tail of the Regulation launch
     bool head_loss_due = false;                // ... and the mean loss is still to be summed (by the Regulation backward launch)
+    bool pend_record = false;                  // cf_record_step_bwd: the step log rides in the trunk's backward launch
+    RecordArgs pend_rec;
     bool pend_gather = false;                  // cf_gather_batch_fwd: the gather of the step shares a launch with the next forward's prologue
     GatherArgs pend_ga;
     int pend_ga_n = 0;
@@ -1670,9 +1672,18 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         LAUNCH_CHECK("k_dgrad<qkvg>");
     }
     if (!(parts & 4)) return 0;
+    if (h->pend_record && !h->trunk) {      // (cf_record_step_bwd without the fused trunk: a launch of its own, here)
+        hipLaunchKernelGGL(k_record_step, dim3(1), dim3(256), 0, st, h->pend_rec);
+        LAUNCH_CHECK("k_record_step");
+        h->pend_record = false;
+    }
     if (h->trunk) {      // Pairwise + Embedding backward, the join and the 7-mark projection partials: one launch (cf_trunk.h)
         TrunkArgs ta;
         trunk_args(h, bt, ta, 1);
+        if (h->pend_record) {
+            ta.rec = h->pend_rec;
+            h->pend_record = false;
+        }
         ta.lp_jobs = h->lp_jobs;
         ta.rd_tiles = nullptr;
         ta.rd_n = 0;
@@ -2322,6 +2333,17 @@ extern "C" int cf_record_step(cf_handle* h, const int* cursor, const float* logi
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_record_step, dim3(1), dim3(256), 0, st, ra);
     LAUNCH_CHECK("k_record_step");
+    return 0;
+}
+// cf_record_step without a launch of its own: the cf_backward_part(parts & 4) that must follow on the same stream writes the log rows at the
+// start of the trunk's backward launch (the loss is final by then).  Configurations without the fused trunk kernels: that call issues
+// k_record_step itself.
+extern "C" int cf_record_step_bwd(cf_handle* h, const int* cursor, const float* logits, const void* labels, const float* loss, int B,
+                                  float* logits_log, void* labels_log, float* loss_log, void* stream) {
+    (void)stream;
+    if (!h || !cursor || !logits || !labels || !loss || !logits_log || !labels_log || !loss_log) return fail("cf_record_step_bwd: null argument");
+    h->pend_rec = RecordArgs{cursor, logits, (const char*)labels, loss, logits_log, (char*)labels_log, loss_log, B, h->cfg.n_out, h->cfg.n_out == 1 ? 4 : 8};
+    h->pend_record = true;
     return 0;
 }
 

@@ -74,12 +74,14 @@ struct RecordArgs {
     float* loss_log;
     int B, n_out, label_bytes;
 };
-__global__ __launch_bounds__(256) void k_record_step(RecordArgs a) {
+// (by one workgroup of any size)
+__device__ __forceinline__ void record_block(const RecordArgs& a) {
     const long long row = (long long)a.cursor[0] - 1;
     if (row < 0 || row >= a.cursor[1] || (a.cursor[2] & 1)) return;      // the logs hold cursor[1] rows; a step past the epoch logs nothing
-    for (int i = threadIdx.x; i < a.B * a.n_out; i += 256) a.logits_log[row * a.B * a.n_out + i] = a.logits[i];
-    for (int i = threadIdx.x; i < a.B * a.label_bytes; i += 256) a.labels_log[row * a.B * a.label_bytes + i] = a.labels[i];
+    for (int i = threadIdx.x; i < a.B * a.n_out; i += blockDim.x) a.logits_log[row * a.B * a.n_out + i] = a.logits[i];
+    for (int i = threadIdx.x; i < a.B * a.label_bytes; i += blockDim.x) a.labels_log[row * a.B * a.label_bytes + i] = a.labels[i];
     if (threadIdx.x == 0) a.loss_log[row] = a.loss[0];
 }
+__global__ __launch_bounds__(256) void k_record_step(RecordArgs a) { record_block(a); }
 
 }  // namespace cf

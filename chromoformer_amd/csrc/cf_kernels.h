@@ -2316,9 +2316,9 @@ __global__ __launch_bounds__(256) void k_dense_cs_tables(DenseCsTab a) {
 #include "cf_reg8.h"
 #include "cf_attc2.h"
 #include "cf_attc1.h"
+#include "cf_gather.h"
 #include "cf_trunk.h"
 #include "cf_head.h"
 #include "cf_attn.h"
 #include "cf_bin.h"
-#include "cf_gather.h"
 #include "cf_embed_full.h"

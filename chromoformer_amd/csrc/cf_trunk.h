@@ -60,6 +60,7 @@ struct TrunkArgs {
     float* rt_tiled;
     float* rt_tiledT;
     int rt_n;
+    RecordArgs rec;                    // backward, optional (rec.cursor != null): the step's logits / labels / loss into the epoch logs (cf_record_step_bwd)
     int* adv_cursor;                   // forward, optional: the batch cursor of a gather that shared the launch in front (k_prologue_gather): advanced here
     const LpJob* lp_jobs;              // backward: the 7-mark projection jobs, [2 r] = Embedding, [2 r + 1] = Pairwise of resolution r
     // backward, single-GPU training: the first rd_n weight-gradient tiles of the Regulation bucket (all equally long), with AdamW in
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(kAT) void k_trunk_bwd(TrunkArgs a) {
         }
         return;
     }
+    if (a.rec.cursor && blockIdx.x == 0 && blockIdx.y == 0) record_block(a.rec);      // (the loss is final: the Regulation backward launch has run)
     const int r = a.n_res - 1 - (int)blockIdx.y;
     const TrunkResDev* R = a.tab + r;
     constexpr int DFF_MAX = DFF_E > DFF_P ? DFF_E : DFF_P;

@@ -270,6 +270,13 @@ class Trainer:
     # ---- launch sequences (eager or under capture)
     def _part(self, slot, st, parts):
         m, L = self.model, self._L
+        feed = getattr(slot, "feed", None)
+        if feed is not None and (parts & 4):
+            # the step log (logits / labels / loss of the step into the feed's pinned-host logs) is written by the Pairwise + Embedding
+            # backward launch itself (cf_record_step_bwd: no launch of its own; the loss is final once the Regulation backward has run)
+            _lib.check(L.cf_record_step_bwd(m._handle, feed.cursor.data_ptr(), slot.logits.data_ptr(), slot.label.data_ptr(),
+                                            slot.loss.data_ptr(), slot.B, feed.logits_log.data_ptr(), feed.labels_log.data_ptr(),
+                                            feed.loss_log.data_ptr(), st), "cf_record_step_bwd")
         _lib.check(L.cf_backward_part(m._handle, C.byref(slot.struct), slot.label.data_ptr(), 1.0 / self.world,
                                       slot.loss.data_ptr(), parts, st), "cf_backward_part")
 
@@ -288,10 +295,6 @@ class Trainer:
         _lib.check(L.cf_forward_train(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), slot.label.data_ptr(), 1.0 / self.world,
                                       slot.loss.data_ptr(), st), "cf_forward_train")
         self._part(slot, st, 3)
-        if feed is not None:
-            _lib.check(L.cf_record_step(m._handle, feed.cursor.data_ptr(), slot.logits.data_ptr(), slot.label.data_ptr(),
-                                        slot.loss.data_ptr(), slot.B, feed.logits_log.data_ptr(), feed.labels_log.data_ptr(),
-                                        feed.loss_log.data_ptr(), st), "cf_record_step")
         if reduce:
             self._reduce(slot, st, _lib.BUCKET_REG)
 

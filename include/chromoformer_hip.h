@@ -359,6 +359,10 @@ int cf_gather_batch_fwd(cf_handle* h, const cf_store* store, const int* order, i
  * The logs must hold cursor[1] rows; nothing is written for a step past the epoch (cursor[2] bit 0). */
 int cf_record_step(cf_handle* h, const int* cursor, const float* logits, const void* labels, const float* loss, int B,
                    float* logits_log, void* labels_log, float* loss_log, void* stream);
+/* cf_record_step without a launch of its own: the cf_backward_part(parts & 4) that must follow on the same stream writes the rows at the
+ * start of the Pairwise + Embedding backward launch (the step's loss is final by then). */
+int cf_record_step_bwd(cf_handle* h, const int* cursor, const float* logits, const void* labels, const float* loss, int B,
+                       float* logits_log, void* labels_log, float* loss_log, void* stream);
 
 /* Dense attention core with ALL query rows (MultiHeadAttention._attention, modules.py:58-77;
  * PairwiseMultiHeadAttention, modules.py:170-188), head width 64:
