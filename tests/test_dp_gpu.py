@@ -69,3 +69,15 @@ def test_bench_contract_under_torchrun_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["parallelism"] == "dp2"
+    # the N-rank self-checks: both ranks ended with the same parameters, bit for bit (the all-reduces really averaged the ranks'
+    # different batches), and the record says how the ranks were placed (here: shared device, gloo -> no RCCL rank)
+    chk = d["dp_self_check"]
+    assert chk["param_checksum_agree"] is True and len(chk["devices"]) == 2 and chk["rccl_ranks"] == 0 and chk["backend"] == "gloo"
+
+
+def test_bench_refuses_two_ranks_on_one_device_without_the_test_hook():
+    """Without CF_SHARE_DEVICE a launch with more ranks than visible GPUs must fail loudly, not report a scaling number."""
+    r = _launch(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {"CF_DIST_BACKEND": "gloo"}, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box: nothing to refuse")
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stdout + r.stderr)
