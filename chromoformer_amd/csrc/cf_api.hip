@@ -116,7 +116,10 @@ static int check_config(const cf_config& c) {
     if (c.embed_heads != 2 || c.embed_dmodel != 128) return fail("embed: n_heads=2, d_model=128 required");
     if (c.pair_heads != 2 || c.pair_dmodel != 128) return fail("pairwise_interaction: n_heads=2, d_model=128 required");
     if (c.pair_layers < 1 || 2 * c.pair_layers > kLpMaxSeg) return fail("pairwise_interaction.n_layers must be in 1..%d (got %d)", kLpMaxSeg / 2, c.pair_layers);
-    if (c.reg_heads != 8 || c.reg_dmodel != 256) return fail("regulation: n_heads=8, d_model=256 required");
+    // (the fused Regulation kernels are written for 8 heads x 32; the other shapes run the layer-by-layer kernels, whose attention
+    //  stage takes heads and width at run time and whose products are instantiated for both widths)
+    if ((c.reg_heads != 4 && c.reg_heads != 8) || (c.reg_dmodel != 128 && c.reg_dmodel != 256))
+        return fail("regulation: n_heads in {4, 8} and d_model in {128, 256} are supported (got n_heads = %d, d_model = %d)", c.reg_heads, c.reg_dmodel);
     if (c.reg_layers < 1 || c.reg_layers > 32) return fail("regulation.n_layers must be in 1..32");
     const int dffs[3] = {c.embed_dff, c.pair_dff, c.reg_dff};
     for (int d : dffs)
@@ -414,9 +417,10 @@ static void plan_workspace(cf_handle* h) {
             RegBuf& b = h->R[r][l];
             const std::string pre = fmt("R%d.%d.", r, l), d = "d" + pre;
             const int dff = c.reg_dff;
-            b.qkvg = h->ws_get(pre + "qkvg", NR * kRW);
-            b.p = h->ws_get(pre + "p", MB * kRH * T * T);
-            b.a = h->ws_get(pre + "a", NR * kRDm);
+            const int RH = c.reg_heads, RDm = c.reg_dmodel, RW = 4 * RDm;
+            b.qkvg = h->ws_get(pre + "qkvg", NR * RW);
+            b.p = h->ws_get(pre + "p", MB * RH * T * T);
+            b.a = h->ws_get(pre + "a", NR * RDm);
             b.xh1 = h->ws_get(pre + "xh1", NR * kD);
             b.rs1 = h->ws_get(pre + "rs1", NR);
             b.y1 = h->ws_get(pre + "y1", NR * kD);
@@ -426,11 +430,11 @@ static void plan_workspace(cf_handle* h) {
             b.dt2 = h->ws_get(d + "t2", NR * kD);
             b.dpre1 = h->ws_get(d + "pre1", NR * dff);
             b.dt1 = h->ws_get(d + "t1", NR * kD);
-            b.da = h->ws_get(d + "a", NR * kRDm);
-            b.dqkvg = h->ws_get(d + "qkvg", NR * kRW);
+            b.da = h->ws_get(d + "a", NR * RDm);
+            b.dqkvg = h->ws_get(d + "qkvg", NR * RW);
             b.partial = h->ws_get(d + "partial", std::max((NR + kTile - 1) / kTile, MB) * post_partial_width(dff));
-            b.dgam = h->ws_get(d + "gam", MB * kRH);
-            b.hq = h->ws_get(pre + "hq", MB * kRH * kHqFloats);
+            b.dgam = h->ws_get(d + "gam", MB * RH);
+            b.hq = h->ws_get(pre + "hq", MB * RH * kHqFloats);
             b.dy1 = h->ws_get(d + "y1", NR * kD);
         }
     }
@@ -651,8 +655,9 @@ static int build_tables(cf_handle* h) {
             const std::string lp = fmt("regulation.%d.transformer.layers.%d.", bs, l);
             const RegBuf& b = h->R[r][l];
             const int dff = c.reg_dff;
-            push_wg(wgR, wg1(b.dqkvg, kRW, h->Rx[r][l], kD, T, h->G_(lp + "self_att.att.weight"), kD, kRW, kD));
-            push_wg(wgR, wg1(b.dt1, kD, b.a, kRDm, T, h->G_(lp + "self_att.ff.weight"), kRDm, kD, kRDm));
+            const int RDm = c.reg_dmodel, RW = 4 * RDm;
+            push_wg(wgR, wg1(b.dqkvg, RW, h->Rx[r][l], kD, T, h->G_(lp + "self_att.att.weight"), kD, RW, kD));
+            push_wg(wgR, wg1(b.dt1, kD, b.a, RDm, T, h->G_(lp + "self_att.ff.weight"), RDm, kD, RDm));
             push_wg(wgR, wg1(b.dpre1, dff, b.y1, kD, T, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
             push_wg(wgR, wg1(b.dt2, kD, b.hdn, dff, T, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
             if (h->reg8) {            // column sums straight from the row-level arrays the backward kernel writes anyway
@@ -677,7 +682,7 @@ static int build_tables(cf_handle* h) {
             } else {
                 push_post_cs(csR, h, b.partial, dff, T, lp + "self_att.", lp + "ff.");
             }
-            push_cs(csR, b.dgam, kRH, kRH, 1, 1, h->G_(lp + "self_att.gamma_f"));
+            push_cs(csR, b.dgam, c.reg_heads, c.reg_heads, 1, 1, h->G_(lp + "self_att.gamma_f"));
         }
     }
     push_wg(wgR, wg1(h->dh1, c.d_head, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, c.d_head, 3 * kD));
@@ -832,7 +837,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         h->reg8 = T <= kTile;                  // 512-thread kernels (cf_reg8.h); CF_REG8=0 selects the 256-thread ones (A/B runs)
         if (const char* e = getenv("CF_REG8")) h->reg8 = h->reg8 && atoi(e) != 0;
         const size_t need = h->reg8 ? std::max(reg8_fwd_smem(c.reg_dff), reg8_bwd_smem(c.reg_dff)) : std::max(reg_fwd_smem(T), reg_bwd_smem(T));
-        h->reg_fused = T <= kTile && need <= 160 * 1024;
+        h->reg_fused = T <= kTile && need <= 160 * 1024 && c.reg_heads == kRH && c.reg_dmodel == kRDm;
         if (h->reg_fused) {
             const size_t sf = h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), sb = h->reg8 ? reg8_bwd_smem(c.reg_dff) : reg_bwd_smem(T);
             hipError_t e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, T, h->reg8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
@@ -915,8 +920,8 @@ static int embed_dense_backward(cf_handle* h, const cf_batch* bt, hipStream_t st
 // ------------------------------------------------------------------------------------
 static inline int tiles_of(int n) { return (n + kTile - 1) / kTile; }
 static size_t attc_smem(int L, int F, bool bwd) { return (size_t)(256 + 256 + 48 + 2 * L + (bwd ? 2 * L : 0) + L * F) * sizeof(float); }
-static size_t attr_smem(int T, bool bwd) {
-    return (size_t)(T * kRW + kRH * T * T + (bwd ? kRH * T * T + T * kRDm + kRH * T : 0)) * sizeof(float);
+static size_t attr_smem(int T, int H, int DM, bool bwd) {
+    return (size_t)(T * 4 * DM + H * T * T + (bwd ? H * T * T + T * DM + H * T : 0)) * sizeof(float);
 }
 
 #ifndef CF_POST_WAVES
@@ -1455,22 +1460,26 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         }
         la.xmap = identity_map();
         la.ldx = kD;
-        la.ldy = kRW;
+        const int RDm = c.reg_dmodel, RW = 4 * RDm;
+        la.ldy = RW;
         la.N = NR;
         la.K = kD;
-        la.Nout = kRW;
+        la.Nout = RW;
         la.relu = 0;
         at.freq = bt->interaction_freq;
         at.T = T;
+        at.H = c.reg_heads;
+        at.DM = RDm;
         po.xmap = identity_map();
         po.omap = identity_map();
         po.N = NR;
         po.save = save;
-        hipLaunchKernelGGL((k_linear_fwd<4>), dim3(tiles_of(NR), kRW / 256, nres), dim3(256), 0, st, la);
+        hipLaunchKernelGGL((k_linear_fwd<4>), dim3(tiles_of(NR), RW / 256, nres), dim3(256), 0, st, la);
         LAUNCH_CHECK("k_linear_fwd<qkvg>");
-        hipLaunchKernelGGL((k_attr<false>), dim3(B, nres), dim3(256), attr_smem(T, false), st, at);
+        hipLaunchKernelGGL((k_attr<false>), dim3(B, nres), dim3(256), attr_smem(T, at.H, RDm, false), st, at);
         LAUNCH_CHECK("k_attr<fwd>");
-        launch_post_fwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+        if (RDm == 128) launch_post_fwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+        else launch_post_fwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         LAUNCH_CHECK("k_post_fwd<reg>");
     }
     h->head_deferred = save == 2 && !ride;
@@ -1654,21 +1663,26 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         }
         pb.dmap = identity_map();
         pb.N = NR;
+        const int RDm = c.reg_dmodel, RW = 4 * RDm;
         at.freq = bt->interaction_freq;
         at.T = T;
-        dg.lddy = kRW;
+        at.H = c.reg_heads;
+        at.DM = RDm;
+        dg.lddy = RW;
         dg.ldw = kD;
         dg.rmap = identity_map();
         dg.ldres = kD;
         dg.lddx = kD;
         dg.N = NR;
-        dg.K = kRW;
+        dg.K = RW;
         dg.Ncols = kD;
-        launch_post_bwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+        if (RDm == 128) launch_post_bwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+        else launch_post_bwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
         LAUNCH_CHECK("k_post_bwd<reg>");
-        hipLaunchKernelGGL((k_attr<true>), dim3(B, nres), dim3(256), attr_smem(T, true), st, at);
+        hipLaunchKernelGGL((k_attr<true>), dim3(B, nres), dim3(256), attr_smem(T, at.H, RDm, true), st, at);
         LAUNCH_CHECK("k_attr<bwd>");
-        hipLaunchKernelGGL((k_dgrad<kRW / 64>), dim3(tiles_of(NR), kD / 32, nres), dim3(256), 0, st, dg);
+        if (RDm == 128) hipLaunchKernelGGL((k_dgrad<8>), dim3(tiles_of(NR), kD / 32, nres), dim3(256), 0, st, dg);
+        else hipLaunchKernelGGL((k_dgrad<16>), dim3(tiles_of(NR), kD / 32, nres), dim3(256), 0, st, dg);
         LAUNCH_CHECK("k_dgrad<qkvg>");
     }
     if (!(parts & 4)) return 0;
@@ -2048,10 +2062,11 @@ extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
     const double T = c.i_max + 1, dff = c.reg_dff;
     const std::string k = kernel;
     if (k == "k_wgrad") return h->wg_flops_per_gene * B;
-    const double lin_fwd = 2.0 * T * (kD * (double)kRW + kRDm * (double)kD + kD * dff + dff * kD);     // q|k|v|g, out-proj, FFN
-    const double att_fwd = 2.0 * T * T * kRDm * 2.0;                                                   // q k^T and p v
+    const double RDm = c.reg_dmodel;
+    const double lin_fwd = 2.0 * T * (kD * 4.0 * RDm + RDm * (double)kD + kD * dff + dff * kD);        // q|k|v|g, out-proj, FFN
+    const double att_fwd = 2.0 * T * T * RDm * 2.0;                                                    // q k^T and p v
     if (k == "k_reg_fwd") return (lin_fwd + att_fwd) * c.reg_layers * c.n_res * B;
-    if (k == "k_reg_bwd") return (lin_fwd + 2.0 * T * T * kRDm * 5.0) * c.reg_layers * c.n_res * B;    // dX products + p v, dp, dq, dk, dv
+    if (k == "k_reg_bwd") return (lin_fwd + 2.0 * T * T * RDm * 5.0) * c.reg_layers * c.n_res * B;     // dX products + p v, dp, dq, dk, dv
     if (k == "k_trunk_fwd" || k == "k_trunk_bwd") {
         // The centre-row trunk of one (gene, resolution): ONE Embedding row and S = i_max Pairwise rows per layer.  Per row and layer the
         // 128-wide products q = x Wq^T, qt[h] = q[h] Wk[h], a[h] = xbar[h] Wv[h]^T, a Wo^T (4 x 128 x 128 MACs), the FFN (2 x 128 x d_ff) and the

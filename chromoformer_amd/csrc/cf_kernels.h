@@ -1441,57 +1441,59 @@ __global__ __launch_bounds__(256) void k_dgrad(DgradArgs a) {
 }
 
 // =======================================================================================
-// Regulation attention: T <= 17 tokens, 8 heads x 32, gate + frequency bias
-// (modules.py:38-81).  One workgroup per (gene, resolution).
+// Regulation attention: T <= 17 tokens, H heads x DM / H, gate + frequency bias
+// (modules.py:38-81).  One workgroup per (gene, resolution).  The default shape (8 heads x 32, d_model 256) with T <= 16 runs
+// inside the fused Regulation kernels (cf_reg8.h / cf_reg_fused.h); this kernel is the stand-alone stage of the layer-by-layer
+// path: longer token rows, and the other head counts / widths check_config accepts (H in {4, 8}, DM in {128, 256}: run-time here).
 // =======================================================================================
-constexpr int kRH = 8, kRDh = 32, kRDm = 256, kRW = 1024, kRMaxT = 17;
+constexpr int kRH = 8, kRDh = 32, kRDm = 256, kRW = 1024, kRMaxT = 17;      // the default shape (what the fused kernels are written for)
 struct AttrArgs {
-    const float* qkvg[kMaxRes];      // [B*T, 1024]  q | k | v | gate
+    const float* qkvg[kMaxRes];      // [B*T, 4 DM]  q | k | v | gate
     const uint8_t* mask[kMaxRes];    // [B, T, T]
     const float* freq;               // [B, T, T]
-    const float* gamma[kMaxRes];     // [8]
-    float* p[kMaxRes];               // [B, 8, T, T]
-    float* a[kMaxRes];               // fwd out [B*T, 256]; bwd in: da
+    const float* gamma[kMaxRes];     // [H]
+    float* p[kMaxRes];               // [B, H, T, T]
+    float* a[kMaxRes];               // fwd out [B*T, DM]; bwd in: da
     float* dqkvg[kMaxRes];           // bwd out
-    float* dgam[kMaxRes];            // bwd out [B, 8] per-gene partials
+    float* dgam[kMaxRes];            // bwd out [B, H] per-gene partials
     int T;
+    int H, DM;                       // heads, d_model (H * d_head)
 };
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_attr(AttrArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, T = a.T, TT = T * T;
-    float* x_s = smem;                       // [T][1024]
-    float* p_s = x_s + T * kRW;              // [8][T][T]
-    float* ds_s = p_s + kRH * TT;            // [8][T][T]     (bwd)
-    float* do_s = ds_s + (BWD ? kRH * TT : 0);   // [T][256]  (bwd)
-    float* red_s = do_s + (BWD ? T * kRDm : 0);  // 8*T       (bwd)
-    const float inv = 1.0f;                  // division by sqrt(dh) done explicitly below
-    (void)inv;
-    const float scale = sqrtf((float)kRDh);
-    const float* xg = a.qkvg[r] + (size_t)g * T * kRW;
-    for (int i = tid; i < T * kRW / 4; i += 256) reinterpret_cast<float4*>(x_s)[i] = reinterpret_cast<const float4*>(xg)[i];
+    const int H = a.H, DM = a.DM, RW = 4 * DM, DH = DM / H;
+    float* x_s = smem;                       // [T][4 DM]
+    float* p_s = x_s + T * RW;               // [H][T][T]
+    float* ds_s = p_s + H * TT;              // [H][T][T]     (bwd)
+    float* do_s = ds_s + (BWD ? H * TT : 0);     // [T][DM]   (bwd)
+    float* red_s = do_s + (BWD ? T * DM : 0);    // H*T       (bwd)
+    const float scale = sqrtf((float)DH);
+    const float* xg = a.qkvg[r] + (size_t)g * T * RW;
+    for (int i = tid; i < T * RW / 4; i += 256) reinterpret_cast<float4*>(x_s)[i] = reinterpret_cast<const float4*>(xg)[i];
     if (BWD) {
-        const float* pg = a.p[r] + (size_t)g * kRH * TT;
-        for (int i = tid; i < kRH * TT; i += 256) p_s[i] = pg[i];
+        const float* pg = a.p[r] + (size_t)g * H * TT;
+        for (int i = tid; i < H * TT; i += 256) p_s[i] = pg[i];
     }
     __syncthreads();
     const uint8_t* mk = a.mask[r] + (size_t)g * TT;
     const float* fq = a.freq + (size_t)g * TT;
     if (!BWD) {
-        for (int idx = tid; idx < kRH * TT; idx += 256) {
+        for (int idx = tid; idx < H * TT; idx += 256) {
             const int h = idx / TT, ij = idx - h * TT, i = ij / T, j = ij - i * T;
-            const float* qp = x_s + i * kRW + h * kRDh;
-            const float* kp = x_s + j * kRW + kRDm + h * kRDh;
+            const float* qp = x_s + i * RW + h * DH;
+            const float* kp = x_s + j * RW + DM + h * DH;
             float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < kRDh; ++d) s = fmaf(qp[d], kp[d], s);
+#pragma unroll 16
+            for (int d = 0; d < DH; ++d) s = fmaf(qp[d], kp[d], s);
             s = s / scale + a.gamma[r][h] * fq[ij];
             if (mk[ij]) s = kMaskFill;
             p_s[idx] = s;
         }
         __syncthreads();
-        for (int row = tid; row < kRH * T; row += 256) {
+        for (int row = tid; row < H * T; row += 256) {
             float* pr = p_s + row * T;
             float m = -INFINITY;
             for (int j = 0; j < T; ++j) m = fmaxf(m, pr[j]);
@@ -1504,45 +1506,45 @@ __global__ __launch_bounds__(256) void k_attr(AttrArgs a) {
             for (int j = 0; j < T; ++j) pr[j] = pr[j] / z;
         }
         __syncthreads();
-        float* pg = a.p[r] + (size_t)g * kRH * TT;
-        for (int i = tid; i < kRH * TT; i += 256) pg[i] = p_s[i];
-        for (int idx = tid; idx < T * kRDm; idx += 256) {
-            const int i = idx >> 8, c = idx & 255, h = c >> 5;
+        float* pg = a.p[r] + (size_t)g * H * TT;
+        for (int i = tid; i < H * TT; i += 256) pg[i] = p_s[i];
+        for (int idx = tid; idx < T * DM; idx += 256) {
+            const int i = idx / DM, c = idx - i * DM, h = c / DH;
             const float* pr = p_s + (h * T + i) * T;
             float o = 0.f;
-            for (int j = 0; j < T; ++j) o = fmaf(pr[j], x_s[j * kRW + 2 * kRDm + c], o);
-            const float gt = x_s[i * kRW + 3 * kRDm + c];
+            for (int j = 0; j < T; ++j) o = fmaf(pr[j], x_s[j * RW + 2 * DM + c], o);
+            const float gt = x_s[i * RW + 3 * DM + c];
             const float sg = 1.0f / (1.0f + expf(-gt));
-            a.a[r][((size_t)g * T + i) * kRDm + c] = o * sg;
+            a.a[r][((size_t)g * T + i) * DM + c] = o * sg;
         }
     } else {
-        float* dx = a.dqkvg[r] + (size_t)g * T * kRW;
-        const float* dag = a.a[r] + (size_t)g * T * kRDm;
+        float* dx = a.dqkvg[r] + (size_t)g * T * RW;
+        const float* dag = a.a[r] + (size_t)g * T * DM;
         // gate / value-side: do = da * sigmoid(g); dgate = da * o * s(1-s)
-        for (int idx = tid; idx < T * kRDm; idx += 256) {
-            const int i = idx >> 8, c = idx & 255, h = c >> 5;
+        for (int idx = tid; idx < T * DM; idx += 256) {
+            const int i = idx / DM, c = idx - i * DM, h = c / DH;
             const float* pr = p_s + (h * T + i) * T;
             float o = 0.f;
-            for (int j = 0; j < T; ++j) o = fmaf(pr[j], x_s[j * kRW + 2 * kRDm + c], o);
-            const float gt = x_s[i * kRW + 3 * kRDm + c];
+            for (int j = 0; j < T; ++j) o = fmaf(pr[j], x_s[j * RW + 2 * DM + c], o);
+            const float gt = x_s[i * RW + 3 * DM + c];
             const float sg = 1.0f / (1.0f + expf(-gt));
             const float da = dag[idx];
             do_s[idx] = da * sg;
-            dx[i * kRW + 3 * kRDm + c] = da * o * sg * (1.0f - sg);
+            dx[i * RW + 3 * DM + c] = da * o * sg * (1.0f - sg);
         }
         __syncthreads();
         // dp[h][i][j] = do[i][h] . v[j][h]
-        for (int idx = tid; idx < kRH * TT; idx += 256) {
+        for (int idx = tid; idx < H * TT; idx += 256) {
             const int h = idx / TT, ij = idx - h * TT, i = ij / T, j = ij - i * T;
-            const float* dp = do_s + i * kRDm + h * kRDh;
-            const float* vp = x_s + j * kRW + 2 * kRDm + h * kRDh;
+            const float* dp = do_s + i * DM + h * DH;
+            const float* vp = x_s + j * RW + 2 * DM + h * DH;
             float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < kRDh; ++d) s = fmaf(dp[d], vp[d], s);
+#pragma unroll 16
+            for (int d = 0; d < DH; ++d) s = fmaf(dp[d], vp[d], s);
             ds_s[idx] = s;
         }
         __syncthreads();
-        for (int row = tid; row < kRH * T; row += 256) {
+        for (int row = tid; row < H * T; row += 256) {
             const float* pr = p_s + row * T;
             float* dr = ds_s + row * T;
             const int i = row % T;
@@ -1557,23 +1559,23 @@ __global__ __launch_bounds__(256) void k_attr(AttrArgs a) {
             red_s[row] = gsum;
         }
         __syncthreads();
-        if (tid < kRH) {
+        if (tid < H) {
             float s = 0.f;
             for (int i = 0; i < T; ++i) s += red_s[tid * T + i];
-            a.dgam[r][(size_t)g * kRH + tid] = s;
+            a.dgam[r][(size_t)g * H + tid] = s;
         }
         // dq, dk, dv
-        for (int idx = tid; idx < T * kRDm; idx += 256) {
-            const int i = idx >> 8, c = idx & 255, h = c >> 5;
+        for (int idx = tid; idx < T * DM; idx += 256) {
+            const int i = idx / DM, c = idx - i * DM, h = c / DH;
             float dq = 0.f, dk = 0.f, dv = 0.f;
             for (int j = 0; j < T; ++j) {
-                dq = fmaf(ds_s[(h * T + i) * T + j], x_s[j * kRW + kRDm + c], dq);     // ds[i][j] k[j]
-                dk = fmaf(ds_s[(h * T + j) * T + i], x_s[j * kRW + c], dk);            // ds[j][i] q[j]
-                dv = fmaf(p_s[(h * T + j) * T + i], do_s[j * kRDm + c], dv);           // p[j][i] do[j]
+                dq = fmaf(ds_s[(h * T + i) * T + j], x_s[j * RW + DM + c], dq);     // ds[i][j] k[j]
+                dk = fmaf(ds_s[(h * T + j) * T + i], x_s[j * RW + c], dk);          // ds[j][i] q[j]
+                dv = fmaf(p_s[(h * T + j) * T + i], do_s[j * DM + c], dv);          // p[j][i] do[j]
             }
-            dx[i * kRW + c] = dq / scale;
-            dx[i * kRW + kRDm + c] = dk / scale;
-            dx[i * kRW + 2 * kRDm + c] = dv;
+            dx[i * RW + c] = dq / scale;
+            dx[i * RW + DM + c] = dk / scale;
+            dx[i * RW + 2 * DM + c] = dv;
         }
     }
 }

@@ -20,6 +20,10 @@ VARIANTS = {
     "three_pairwise_layers": dict(pairwise_interaction=dict(n_layers=3, n_heads=2, d_model=128, d_ff=256)),
     "six_pairwise_layers": dict(pairwise_interaction=dict(n_layers=6, n_heads=2, d_model=128, d_ff=256)),
     "deep_reg": dict(regulation=dict(n_layers=8, n_heads=8, d_model=256, d_ff=256)),
+    # Regulation head counts / widths other than 8 x 32: the layer-by-layer kernels (run-time heads in k_attr, both widths of the products)
+    "reg_4_heads": dict(regulation=dict(n_layers=3, n_heads=4, d_model=256, d_ff=256)),
+    "reg_d_model_128": dict(regulation=dict(n_layers=3, n_heads=8, d_model=128, d_ff=256)),
+    "reg_4_heads_d_model_128": dict(regulation=dict(n_layers=2, n_heads=4, d_model=128, d_ff=128)),
     "d_head_96": dict(d_head=96),                                      # fc_head widths other than 128: the vector-ALU head (cf_head.h)
     "d_head_256": dict(d_head=256),
     "other_bins": dict(binsizes=[1000, 250, 50], w_max=20000),          # L = 20 / 80 / 400 again but other PE tables ... and
@@ -61,7 +65,7 @@ def test_forward_and_gradients_match_oracle(name, reg):
         assert err <= GRAD_TOL * v.grad.abs().max().item() + 1e-9, (k, err, v.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths", "d_head_96"])
+@pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths", "d_head_96", "reg_4_heads_d_model_128"])
 def test_fused_optimiser_and_riders_equal_the_separate_launches(name):
     """Away from the default shapes: AdamW in the reduction epilogues, both buckets in one launch, part of the tiles riding in the trunk's
     backward launch where the fused trunk kernels exist (elsewhere the trainer falls back) -- same parameters and moments, bit for bit,
