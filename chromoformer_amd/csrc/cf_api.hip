@@ -113,8 +113,15 @@ static int check_config(const cf_config& c) {
     if (c.i_max < 1 || c.i_max > 16) return fail("i_max must be in 1..16");
     if (c.embed_layers < 1 || c.embed_layers > kMaxEmbedLayers)
         return fail("embed.n_layers must be in 1..%d (got %d); more than one layer runs the all-rows path", kMaxEmbedLayers, c.embed_layers);
-    if (c.embed_heads != 2 || c.embed_dmodel != 128) return fail("embed: n_heads=2, d_model=128 required");
-    if (c.pair_heads != 2 || c.pair_dmodel != 128) return fail("pairwise_interaction: n_heads=2, d_model=128 required");
+    // (heads: 2 is what the fused trunk and the gene-batched attention kernels are written for; 1 and 4 run the stand-alone chain
+    //  kernels instantiated for that head count and the one-sequence-per-workgroup attention)
+    auto heads_ok = [](int n) { return n == 1 || n == 2 || n == 4; };
+    if (!heads_ok(c.embed_heads) || c.embed_dmodel != 128)
+        return fail("embed: n_heads in {1, 2, 4} and d_model = 128 (= d_emb, net.py:305) are supported (got n_heads = %d, d_model = %d)", c.embed_heads, c.embed_dmodel);
+    if (!heads_ok(c.pair_heads) || c.pair_dmodel != 128)
+        return fail("pairwise_interaction: n_heads in {1, 2, 4} and d_model = 128 are supported (got n_heads = %d, d_model = %d)", c.pair_heads, c.pair_dmodel);
+    if (c.embed_layers > 1 && c.embed_heads != 2)
+        return fail("embed: n_layers > 1 (the all-rows path) is implemented for n_heads = 2 only (got n_heads = %d)", c.embed_heads);
     if (c.pair_layers < 1 || 2 * c.pair_layers > kLpMaxSeg) return fail("pairwise_interaction.n_layers must be in 1..%d (got %d)", kLpMaxSeg / 2, c.pair_layers);
     // (the fused Regulation kernels are written for 8 heads x 32; the other shapes run the layer-by-layer kernels, whose attention
     //  stage takes heads and width at run time and whose products are instantiated for both widths)
@@ -354,13 +361,13 @@ struct cf_handle {
     float* G_(const std::string& name, long long extra = 0) const { return grads + table[index.at(name)].offset + extra; }
 };
 
-static void plan_centre(cf_handle* h, CentreBuf& b, const std::string& pre, size_t N, int L, int dff, bool own_out, bool own_xin) {
+static void plan_centre(cf_handle* h, CentreBuf& b, const std::string& pre, size_t N, int L, int dff, bool own_out, bool own_xin, int nh) {
     const size_t tiles = (N + kTile - 1) / kTile;
     b.q = h->ws_get(pre + "q", N * kD);
-    b.qt = h->ws_get(pre + "qt", N * 256);
-    b.p = h->ws_get(pre + "p", N * 2 * L);
-    b.w = h->ws_get(pre + "w", N * 16);
-    b.xbar = h->ws_get(pre + "xbar", N * 256);
+    b.qt = h->ws_get(pre + "qt", N * nh * kD);
+    b.p = h->ws_get(pre + "p", N * nh * L);
+    b.w = h->ws_get(pre + "w", N * nh * 8);
+    b.xbar = h->ws_get(pre + "xbar", N * nh * kD);
     b.a = h->ws_get(pre + "a", N * kD);
     b.xh1 = h->ws_get(pre + "xh1", N * kD);
     b.rs1 = h->ws_get(pre + "rs1", N);
@@ -375,9 +382,9 @@ static void plan_centre(cf_handle* h, CentreBuf& b, const std::string& pre, size
     b.dpre1 = h->ws_get(d + "pre1", N * dff);
     b.dt1 = h->ws_get(d + "t1", N * kD);
     b.da = h->ws_get(d + "a", N * kD);
-    b.dxbar = h->ws_get(d + "xbar", N * 256);
-    b.dqt = h->ws_get(d + "qt", N * 256);
-    b.du = h->ws_get(d + "u", N * 16);
+    b.dxbar = h->ws_get(d + "xbar", N * nh * kD);
+    b.dqt = h->ws_get(d + "qt", N * nh * kD);
+    b.du = h->ws_get(d + "u", N * nh * 8);
     b.dq = h->ws_get(d + "q", N * kD);
     b.dx = h->ws_get(d + "x", N * kD);
     b.partial = h->ws_get(d + "partial", std::max(tiles, (size_t)h->cfg.max_batch) * post_partial_width(dff));      // (the fused trunk writes one row per gene)
@@ -398,14 +405,14 @@ static void plan_workspace(cf_handle* h) {
         h->lp_part_e[r] = h->ws_get(fmt("dE%d.lp_partial", r), ((MB + kLpGenes - 1) / kLpGenes) * kD * 8);
         h->lp_part_p[r] = h->ws_get(fmt("dP%d.lp_partial", r), ((MB + kLpGenes - 1) / kLpGenes) * kD * 8);
         h->ex0[r] = h->ws_get(fmt("E%d.x0", r), NE * kD);
-        plan_centre(h, h->E[r], fmt("E%d.", r), NE, L, c.embed_dff, false, false);
+        plan_centre(h, h->E[r], fmt("E%d.", r), NE, L, c.embed_dff, false, false, c.embed_heads);
         h->edout[r] = h->ws_get(fmt("dE%d.out", r), NE * kD);
         h->xp0[r] = h->ws_get(fmt("P%d.xp0", r), NE * kD);
         h->dxp0[r] = h->ws_get(fmt("dP%d.xp0", r), NE * kD);
         h->resid[r] = h->ws_get(fmt("dE%d.resid", r), NE * kD);
         h->P[r].resize(c.pair_layers);
         for (int l = 0; l < c.pair_layers; ++l)
-            plan_centre(h, h->P[r][l], fmt("P%d.%d.", r, l), NP, L, c.pair_dff, l + 1 < c.pair_layers, l == 0);
+            plan_centre(h, h->P[r][l], fmt("P%d.%d.", r, l), NP, L, c.pair_dff, l + 1 < c.pair_layers, l == 0, c.pair_heads);
         h->Rx[r].resize(c.reg_layers + 1);
         h->dRx[r].resize(c.reg_layers + 1);
         for (int l = 0; l <= c.reg_layers; ++l) {
@@ -505,11 +512,12 @@ static void push_post_cs(std::vector<CsTile>& out, const cf_handle* h, const flo
 // weight gradients of one centre-row layer (q / k / v projections, out-projection, FFN)
 static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const CentreBuf& b, const float* xin, int ldxin,
                            int rpg, int dff, float* gWq, float* gWk, float* gWv, const std::string& att_pre,
-                           const std::string& ff_pre) {
+                           const std::string& ff_pre, int nh) {
+    const int dh = kD / nh, qw = nh * kD;
     push_wg(out, wg1(b.dq, kD, xin, ldxin, rpg, gWq, kD, kD, kD));
-    for (int hd = 0; hd < 2; ++hd) {
-        push_wg(out, wg1(b.q + hd * 64, kD, b.dqt + hd * kD, 256, rpg, gWk + (size_t)hd * 64 * kD, kD, 64, kD));
-        push_wg(out, wg1(b.da + hd * 64, kD, b.xbar + hd * kD, 256, rpg, gWv + (size_t)hd * 64 * kD, kD, 64, kD));
+    for (int hd = 0; hd < nh; ++hd) {
+        push_wg(out, wg1(b.q + hd * dh, kD, b.dqt + hd * kD, qw, rpg, gWk + (size_t)hd * dh * kD, kD, dh, kD));
+        push_wg(out, wg1(b.da + hd * dh, kD, b.xbar + hd * kD, qw, rpg, gWv + (size_t)hd * dh * kD, kD, dh, kD));
     }
     push_wg(out, wg1(b.dt1, kD, b.a, kD, rpg, h->G_(att_pre + "ff.weight"), kD, kD, kD));
     push_wg(out, wg1(b.dpre1, dff, b.y1, kD, rpg, h->G_(ff_pre + "l1.weight"), kD, dff, kD));
@@ -611,8 +619,8 @@ static int build_tables(cf_handle* h) {
             LpJob j;
             memset(&j, 0, sizeof j);
             j.seg[0] = WgSeg{h->edx0[r], h->featc[r], kD, 8, 1};
-            j.seg[1] = WgSeg{b.dxbar, b.w, kD, 8, 2};
-            j.seg[2] = WgSeg{b.qt, b.du, kD, 8, 2};
+            j.seg[1] = WgSeg{b.dxbar, b.w, kD, 8, c.embed_heads};      // (rows of [N, heads, .] arrays: heads per gene)
+            j.seg[2] = WgSeg{b.qt, b.du, kD, 8, c.embed_heads};
             j.nseg = 3;
             j.partial = h->lp_part_e[r];
             j.F = F;
@@ -620,7 +628,7 @@ static int build_tables(cf_handle* h) {
             push_cs(cs, j.partial, kD * F, kD * F, 1, kLpGenes, h->G_(pre + "lin_proj.weight"));
             float* gatt = h->G_(lp + "self_att.att.weight");
             push_centre_wg(wg, h, b, h->ex0[r], kD, 1, c.embed_dff, gatt, gatt + (size_t)kD * kD, gatt + (size_t)2 * kD * kD,
-                           lp + "self_att.", lp + "ff.");
+                           lp + "self_att.", lp + "ff.", c.embed_heads);
             if (h->trunk) push_post_cs(cs, h, b.partial, c.embed_dff, 1, lp + "self_att.", lp + "ff.", 1);
             else push_post_cs(cs, h, b.partial, c.embed_dff, 1, lp + "self_att.", lp + "ff.");
         }
@@ -632,8 +640,8 @@ static int build_tables(cf_handle* h) {
             // lin_proj_pcre collects two terms per layer (pair_layers <= 8 -> <= kLpMaxSeg segments)
             int ns = 0;
             for (int l = 0; l < c.pair_layers; ++l) {
-                j.seg[ns++] = WgSeg{h->P[r][l].dxbar, h->P[r][l].w, kD, 8, 2 * S};
-                j.seg[ns++] = WgSeg{h->P[r][l].qt, h->P[r][l].du, kD, 8, 2 * S};
+                j.seg[ns++] = WgSeg{h->P[r][l].dxbar, h->P[r][l].w, kD, 8, c.pair_heads * S};
+                j.seg[ns++] = WgSeg{h->P[r][l].qt, h->P[r][l].du, kD, 8, c.pair_heads * S};
             }
             j.nseg = ns;
             j.partial = h->lp_part_p[r];
@@ -646,7 +654,7 @@ static int build_tables(cf_handle* h) {
                 const float* xin = l == 0 ? b.xin : h->P[r][l - 1].out;
                 float* gc = h->G_(lp + "self_att.c_att.weight");
                 push_centre_wg(wg, h, b, xin, kD, S, c.pair_dff, h->G_(lp + "self_att.p_att.weight"), gc, gc + (size_t)kD * kD,
-                               lp + "self_att.", lp + "ff.");
+                               lp + "self_att.", lp + "ff.", c.pair_heads);
                 if (h->trunk) push_post_cs(cs, h, b.partial, c.pair_dff, 1, lp + "self_att.", lp + "ff.", 1);
                 else push_post_cs(cs, h, b.partial, c.pair_dff, S, lp + "self_att.", lp + "ff.");
             }
@@ -919,7 +927,9 @@ static int embed_dense_backward(cf_handle* h, const cf_batch* bt, hipStream_t st
 // launch helpers
 // ------------------------------------------------------------------------------------
 static inline int tiles_of(int n) { return (n + kTile - 1) / kTile; }
-static size_t attc_smem(int L, int F, bool bwd) { return (size_t)(256 + 256 + 48 + 2 * L + (bwd ? 2 * L : 0) + L * F) * sizeof(float); }
+static size_t attc_smem(int L, int F, bool bwd, int nh = 2) {
+    return (size_t)(2 * nh * kD + 20 * nh + nh * L + (bwd ? nh * L : 0) + L * F) * sizeof(float);
+}
 static size_t attr_smem(int T, int H, int DM, bool bwd) {
     return (size_t)(T * 4 * DM + H * T * T + (bwd ? H * T * T + T * DM + H * T : 0)) * sizeof(float);
 }
@@ -952,6 +962,34 @@ static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArg
         if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, 4>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, 4>), grid, dim3(256), 0, st, a);
     }
+}
+
+// The stand-alone stages of one centre-row layer for a head count other than 2 (eight-wave chain kernels, the one-sequence-per-workgroup
+// attention): the same argument structures as the default launches, [N, NH, .] arrays.
+template <int NH>
+static int centre_fwd_heads(hipStream_t st, int N, int nres, int dff, bool q_done, const QChainArgs& q, const AttcArgs& at, size_t smem,
+                            const PostArgs& po) {
+    if (!q_done) {
+        hipLaunchKernelGGL((k_qchain_fwd<8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, q);
+        LAUNCH_CHECK("k_qchain_fwd");
+    }
+    hipLaunchKernelGGL((k_attc<false, NH>), dim3(N, nres), dim3(256), smem, st, at);
+    LAUNCH_CHECK("k_attc<fwd>");
+    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<true, 128, 128, 8, false, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
+    else hipLaunchKernelGGL((k_post_fwd<true, 128, 256, 8, false, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
+    LAUNCH_CHECK("k_post_fwd<centre>");
+    return 0;
+}
+template <int NH>
+static int centre_bwd_heads(hipStream_t st, int N, int nres, int dff, const PostBwdArgs& pb, const AttcArgs& at, size_t smem, const QBwdArgs& qb) {
+    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<true, 128, 128, 8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
+    else hipLaunchKernelGGL((k_post_bwd<true, 128, 256, 8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
+    LAUNCH_CHECK("k_post_bwd<centre>");
+    hipLaunchKernelGGL((k_attc<true, NH>), dim3(N, nres), dim3(256), smem, st, at);
+    LAUNCH_CHECK("k_attc<bwd>");
+    hipLaunchKernelGGL((k_qchain_bwd<8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, qb);
+    LAUNCH_CHECK("k_qchain_bwd");
+    return 0;
 }
 
 struct CentreParams {   // weights of one centre-row layer (_t: tiled copies for the forward products)
@@ -1015,6 +1053,7 @@ static int build_trunk_table(cf_handle* h) {
     const cf_config& c = h->cfg;
     h->trunk = false;
     if (h->embed_dense || !h->attc2 || c.i_max > kAGMax || c.pair_layers > kMaxPairLayers || kPostWaves != 8) return 0;
+    if (c.embed_heads != 2 || c.pair_heads != 2) return 0;      // (the fused kernels are written for two heads)
     if (!trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers)) return 0;
     if (const char* e = getenv("CF_TRUNK"))      // CF_TRUNK=0: the stand-alone kernels (A/B runs, cross-checks in the tests)
         if (atoi(e) == 0) return 0;
@@ -1152,10 +1191,9 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
     const cf_config& c = h->cfg;
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
-    const float scale_c = sqrtf(64.f);
     CentreParams ep[kMaxRes], pp[kMaxRes];
     for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
-    const bool defer = h->defer_retile && !h->embed_dense && kPostWaves == 8;      // Regulation + head units ride in the Embedding layer's chain launch
+    const bool defer = h->defer_retile && !h->embed_dense && kPostWaves == 8 && c.embed_heads == 2;      // Regulation + head units ride in the Embedding layer's chain launch
     const bool trunk = h->trunk;                                                   // Embedding + Pairwise stage as ONE launch (cf_trunk.h)
     int* adv_cursor = nullptr;
     {   // refresh the tiled weight copies (the parameters may have been changed by anyone since the last call) and, in the same
@@ -1207,9 +1245,10 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
     // one centre-row layer: query chain -> attention -> post chain
     auto centre_layer = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* xin, RowMap xmap,
                             const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff,
-                            float* const* outp, RowMap omap, bool copy_x, const float* const* lin_w = nullptr,
+                            float* const* outp, RowMap omap, bool copy_x, int nh, const float* const* lin_w = nullptr,
                             float* const* lin_y = nullptr, bool q_done = false, const CentreParams* next_prm = nullptr,
                             CentreBuf* const* next_bufs = nullptr, bool host_retile = false) -> int {
+        const float scale_c = sqrtf((float)(kD / nh));      // sqrt(d_head), modules.py:60-61
         // q_done: the previous layer's chain kernel has already run this layer's query chain; next_prm / next_bufs: run the next
         // layer's query chain at the end of this layer's chain kernel (only for identity row maps: the output tile IS its input)
         QChainArgs q;
@@ -1245,7 +1284,7 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             at.w[r] = b.w;
             at.vout[r] = b.xbar;
             at.L[r] = c.n_bins[r];
-            smem = std::max(smem, attc_smem(c.n_bins[r], F, false));
+            smem = std::max(smem, attc_smem(c.n_bins[r], F, false, nh));
             po.x[r] = xin[r];
             po.ain[r] = b.xbar;
             po.wv[r] = prm[r].wv_t;
@@ -1276,6 +1315,8 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         po.omap = omap;
         po.N = N;
         po.save = save;
+        if (nh == 1) return centre_fwd_heads<1>(st, N, nres, dff, q_done, q, at, smem, po);
+        if (nh == 4) return centre_fwd_heads<4>(st, N, nres, dff, q_done, q, at, smem, po);
         if (!q_done) {
             hipLaunchKernelGGL((k_qchain_fwd<kPostWaves>), dim3(tiles_of(N), nres), dim3(kPostWaves * 64), 0, st, q);
             LAUNCH_CHECK("k_qchain_fwd");
@@ -1355,7 +1396,7 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             ly[r] = h->xp0[r];
         }
         if (centre_layer(bufs, ep, xin, identity_map(), bt->promoter_feats, bt->promoter_mask_row, bt->promoter_mask_stride, NE,
-                         c.embed_dff, outp, RowMap{1, T, 0, 0}, false, lw, ly, false, nullptr, nullptr, defer))
+                         c.embed_dff, outp, RowMap{1, T, 0, 0}, false, c.embed_heads, lw, ly, false, nullptr, nullptr, defer))
             return -1;
     }
     if (h->embed_dense) {   // lin_proj_p on the promoter centre embedding (net.py:118)
@@ -1397,7 +1438,7 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
                 nbufs[r] = &h->P[r][l + 1];
             }
         if (centre_layer(bufs, pp, xin, xmap, bt->pcre_feats, bt->pcre_mask_row, bt->pcre_mask_stride, NP, c.pair_dff, outp, omap,
-                         l == 0, nullptr, nullptr, l > 0, last ? nullptr : npp, last ? nullptr : nbufs))
+                         l == 0, c.pair_heads, nullptr, nullptr, l > 0, last ? nullptr : npp, last ? nullptr : nbufs))
             return -1;
     }
     if (h->reg_fused) {   // Regulation: all layers in one launch, one workgroup per (gene, resolution)
@@ -1550,7 +1591,6 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
     const cf_config& c = h->cfg;
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
-    const float scale_c = sqrtf(64.f);
     if ((parts & 1) && h->head_done) {         // cf_forward_train has run head forward, loss and head backward already
         h->head_done = false;
         h->head_loss_due = true;
@@ -1733,7 +1773,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
     }
     // one centre-row layer backward: post chain -> attention -> query chain
     auto centre_bwd = [&](CentreBuf* bufs[kMaxRes], const CentreParams* prm, const float* const* dout, RowMap dmap,
-                          const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff) -> int {
+                          const float* const* feats, const uint8_t* const* mask, const long long* mstride, int N, int dff, int nh) -> int {
+        const float scale_c = sqrtf((float)(kD / nh));
         PostBwdArgs pb;
         AttcArgs at;
         QBwdArgs qb;
@@ -1769,7 +1810,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             at.w[r] = b.du;
             at.vout[r] = b.dqt;
             at.L[r] = c.n_bins[r];
-            smem = std::max(smem, attc_smem(c.n_bins[r], F, true));
+            smem = std::max(smem, attc_smem(c.n_bins[r], F, true, nh));
             qb.dqt[r] = b.dqt;
             qb.dres[r] = b.dt1;
             qb.wk[r] = prm[r].wk_t;     // NT product in the backward: tiled copy
@@ -1782,6 +1823,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         at.F = F;
         at.scale = scale_c;
         qb.N = N;
+        if (nh == 1) return centre_bwd_heads<1>(st, N, nres, dff, pb, at, smem, qb);
+        if (nh == 4) return centre_bwd_heads<4>(st, N, nres, dff, pb, at, smem, qb);
         launch_post_bwd<true, 128>(dff, dim3(tiles_of(N), nres), st, pb);
         LAUNCH_CHECK("k_post_bwd<centre>");
         if (h->attc2) {
@@ -1839,7 +1882,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             dout[r] = last ? h->dRx[r][0] : h->P[r][l + 1].dx;
         }
         if (centre_bwd(bufs, prm, dout, last ? RowMap{S, T, 1, 1} : identity_map(), bt->pcre_feats, bt->pcre_mask_row,
-                       bt->pcre_mask_stride, NP, c.pair_dff))
+                       bt->pcre_mask_stride, NP, c.pair_dff, c.pair_heads))
             return -1;
     }
     {   // join the streams meeting at the promoter embedding, back through lin_proj_p: one launch
@@ -1870,7 +1913,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             dout[r] = h->edout[r];
         }
         if (centre_bwd(bufs, prm, dout, identity_map(), bt->promoter_feats, bt->promoter_mask_row, bt->promoter_mask_stride, NE,
-                       c.embed_dff))
+                       c.embed_dff, c.embed_heads))
             return -1;
     }
     return 0;

@@ -180,7 +180,7 @@ __device__ __forceinline__ void frag_chunk_nt(FragNT<NT, KS, RING>& f, int slot,
 // (k0 / 16) * 256 for a reduction offset k0; ldw: K of the full tensor.
 template <int NT, int KS, int RING>
 __device__ __forceinline__ void frag_load_nt(FragNT<NT, KS, RING>& f, const float* __restrict__ Wt, int ldw) {
-    static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
+    static_assert(KS % 2 == 0 && KS >= 2, "K must be a multiple of 32");
     f.wp = Wt + (threadIdx.x & 63) * 4;
     f.tstride = ldw * 16;
 #pragma unroll
@@ -248,7 +248,7 @@ __device__ __forceinline__ void frag_chunk_nn(FragNN<NT, KS, RING>& f, int slot,
 }
 template <int NT, int KS, int RING>
 __device__ __forceinline__ void frag_load_nn(FragNN<NT, KS, RING>& f, const float* __restrict__ Bm, int ldb) {
-    static_assert(KS % 2 == 0 && KS >= 4, "K must be a multiple of 32, at least 64");
+    static_assert(KS % 2 == 0 && KS >= 2, "K must be a multiple of 32");
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     f.bp = Bm + (size_t)(q * 4) * ldb + NT * r;
     f.ldb = ldb;
@@ -581,25 +581,27 @@ struct QChainArgs {
     const float* wq[kMaxRes];   // [128,128]
     const float* wk[kMaxRes];   // [128,128] rows = h*64+d
     float* q[kMaxRes];          // [N,128]
-    float* qt[kMaxRes];         // [N,2,128]
+    float* qt[kMaxRes];         // [N,NH,128]
     float* xcopy[kMaxRes];      // optional: the (row-mapped) input rows, materialised [N,128]
     int N;
 };
 // The chain kernels are written as BODIES over one 16-row tile (rows row0 .. row0 + 15 of resolution r, valid below N; LDS tiles
 // passed in) with thin __global__ wrappers: the fused centre-row kernels of cf_trunk.h run the same bodies back to back in one
 // workgroup per gene.
-template <int NWV>
+// NH: heads of the layer (d_head = 128 / NH; the default 2 everywhere but in the stand-alone launches of a configuration with 1 or 4 heads)
+template <int NWV, int NH = 2>
 __device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r, const int row0, float (*xs)[kD + 4], float (*qs)[kD + 4]) {
+    constexpr int DH = kD / NH, QW = NH * kD;
     constexpr int CW = kD / NWV, NTC = CW / 16;           // q columns per wave
-    constexpr int EW = 256 / NWV, NTE = EW / 16;          // qt columns per wave (2 heads x 128)
+    constexpr int EW = QW / NWV, NTE = EW / 16;           // qt columns per wave (NH heads x 128)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
     TileReq<kD, NWV * 64> tx;
     tile_req(tx, a.x[r], kD, row0, a.N, a.xmap);
     FragNT<NTC, 8> fq;
     frag_load_nt(fq, a.wq[r] + (size_t)(w * CW) * kD, kD);
-    FragNN<NTE, 4> fk;
-    frag_load_nn(fk, a.wk[r] + (size_t)(h * 64) * kD + e0, kD);
+    FragNN<NTE, DH / 16> fk;
+    frag_load_nn(fk, a.wk[r] + (size_t)(h * DH) * kD + e0, kD);
     tile_put(tx, &xs[0][0], kD + 4, row0, a.N);
     __syncthreads();
     if (a.xcopy[r])
@@ -622,7 +624,7 @@ __device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r
     {
         f32x4 acc[NTE];
         zero_acc(acc);
-        frag_mma_nn(fk, &qs[0][h * 64], kD + 4, acc);
+        frag_mma_nn(fk, &qs[0][h * DH], kD + 4, acc);
         typedef typename VecN<NTE>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -631,16 +633,16 @@ __device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r
 #pragma unroll
             for (int t = 0; t < NTE; ++t) v[t] = acc[t][i];
             if (row0 + row < a.N)
-                LdgN<NTE>::st(a.qt[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
+                LdgN<NTE>::st(a.qt[r] + (size_t)(row0 + row) * QW + h * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
         }
     }
 }
 
-template <int NWV>
+template <int NWV, int NH = 2>
 __global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
     __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
-    qchain_fwd_body<NWV>(a, blockIdx.y, blockIdx.x * kTile, xs, qs);
+    qchain_fwd_body<NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, xs, qs);
 }
 
 struct QBwdArgs {
@@ -652,23 +654,24 @@ struct QBwdArgs {
     float* dx[kMaxRes];          // [N,128]
     int N;
 };
-template <int NWV>
-__device__ __forceinline__ void qchain_bwd_body(const QBwdArgs& a, const int r, const int row0, float (*ds)[256 + 4], float (*qs)[kD + 4]) {
+template <int NWV, int NH = 2>
+__device__ __forceinline__ void qchain_bwd_body(const QBwdArgs& a, const int r, const int row0, float (*ds)[NH * kD + 4], float (*qs)[kD + 4]) {
+    constexpr int DH = kD / NH, QW = NH * kD;
     constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / tiles per wave
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int h = (w * CW) >> 6;
-    TileReq<256, NWV * 64> td;
-    tile_req(td, a.dqt[r], 256, row0, a.N, identity_map());
+    const int h = (w * CW) / DH;
+    TileReq<QW, NWV * 64> td;
+    tile_req(td, a.dqt[r], QW, row0, a.N, identity_map());
     FragNT<NTC, 8> fk;
     frag_load_nt(fk, a.wk[r] + (size_t)(w * CW) * kD, kD);
     FragNN<NTC, 8> fq;
     frag_load_nn(fq, a.wq[r] + w * CW, kD);
-    tile_put(td, &ds[0][0], 260, row0, a.N);
+    tile_put(td, &ds[0][0], QW + 4, row0, a.N);
     __syncthreads();
-    {   // dq[:, h*64+d] = sum_e dqt[:, h, e] Wk[h*64+d, e]
+    {   // dq[:, h*dh+d] = sum_e dqt[:, h, e] Wk[h*dh+d, e]
         f32x4 acc[NTC];
         zero_acc(acc);
-        frag_mma_nt(fk, &ds[0][h * kD], 260, acc);
+        frag_mma_nt(fk, &ds[0][h * kD], QW + 4, acc);
 #pragma unroll
         for (int t = 0; t < NTC; ++t)
 #pragma unroll
@@ -700,11 +703,11 @@ __device__ __forceinline__ void qchain_bwd_body(const QBwdArgs& a, const int r, 
     }
 }
 
-template <int NWV>
+template <int NWV, int NH = 2>
 __global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float ds[kTile][256 + 4];
+    __shared__ __attribute__((aligned(16))) float ds[kTile][NH * kD + 4];
     __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
-    qchain_bwd_body<NWV>(a, blockIdx.y, blockIdx.x * kTile, ds, qs);
+    qchain_bwd_body<NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, ds, qs);
 }
 
 // =======================================================================================
@@ -724,68 +727,70 @@ struct AttcArgs {
     const float* pe[kMaxRes];
     const float* pet[kMaxRes];
     const float* wlp[kMaxRes];
-    const float* vin[kMaxRes];   // fwd: qt, bwd: dxbar   [N,2,128]
-    float* p[kMaxRes];           // [N,2,L]   fwd: out, bwd: in
-    float* w[kMaxRes];           // [N,2,8]   fwd: w (out), bwd: du (out)
-    float* vout[kMaxRes];        // fwd: xbar, bwd: dqt   [N,2,128]
+    const float* vin[kMaxRes];   // fwd: qt, bwd: dxbar   [N,NH,128]
+    float* p[kMaxRes];           // [N,NH,L]  fwd: out, bwd: in
+    float* w[kMaxRes];           // [N,NH,8]  fwd: w (out), bwd: du (out)
+    float* vout[kMaxRes];        // fwd: xbar, bwd: dqt   [N,NH,128]
     int L[kMaxRes];
     int F;
     float scale;                 // sqrt(d_head)
 };
 
-// two simultaneous block reductions (one per head); red is 16 floats of LDS scratch
-template <bool IS_MAX>
-__device__ __forceinline__ void block_reduce2(float& v0, float& v1, float* red) {
+// NH simultaneous block reductions (one per head) over the four waves of the workgroup; red: 4 * NH floats of LDS scratch
+template <bool IS_MAX, int NH>
+__device__ __forceinline__ void block_reduce_heads(float (&v)[NH], float* red) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    v0 = IS_MAX ? wave_max(v0) : wave_sum(v0);
-    v1 = IS_MAX ? wave_max(v1) : wave_sum(v1);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) v[h] = IS_MAX ? wave_max(v[h]) : wave_sum(v[h]);
     __syncthreads();
     if (lane == 0) {
-        red[w] = v0;
-        red[4 + w] = v1;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) red[4 * h + w] = v[h];
     }
     __syncthreads();
-    if (IS_MAX) {
-        v0 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        v1 = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-    } else {
-        v0 = (red[0] + red[1]) + (red[2] + red[3]);
-        v1 = (red[4] + red[5]) + (red[6] + red[7]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float* rh = red + 4 * h;
+        v[h] = IS_MAX ? fmaxf(fmaxf(rh[0], rh[1]), fmaxf(rh[2], rh[3])) : (rh[0] + rh[1]) + (rh[2] + rh[3]);
     }
 }
 
-template <bool BWD>
+// The stand-alone form of the centre-row attention: one workgroup per sequence, vector ALUs, any bin count the LDS holds, NH heads
+// (vin / vout [N, NH, 128], p [N, NH, L], w [N, NH, 8]).  The default configuration takes the kernels of cf_attc1.h / cf_attc2.h (two
+// heads); this one runs where their LDS image does not fit and for the other head counts (1, 4).
+template <bool BWD, int NH = 2>
 __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r = blockIdx.y, n = blockIdx.x, tid = threadIdx.x;
     const int L = a.L[r], F = a.F;
-    float* vin_s = smem;              // 256
-    float* half_s = vin_s + 256;      // 256
-    float* u_s = half_s + 256;        // 16  (h*8+f)
-    float* w_s = u_s + 16;            // 16
-    float* red_s = w_s + 16;          // 16
-    float* sc_s = red_s + 16;         // 2*L  scores -> p (fwd) / p -> ds (bwd)
-    float* dp_s = sc_s + 2 * L;       // 2*L  (bwd only)
-    float* feats_s = dp_s + (BWD ? 2 * L : 0);   // L*F
+    constexpr int QW = NH * kD;
+    float* vin_s = smem;              // NH * 128
+    float* half_s = vin_s + QW;       // NH * 128
+    float* u_s = half_s + QW;         // NH * 8  (h*8+f)
+    float* w_s = u_s + NH * 8;        // NH * 8
+    float* red_s = w_s + NH * 8;      // NH * 4
+    float* sc_s = red_s + NH * 4;     // NH*L  scores -> p (fwd) / p -> ds (bwd)
+    float* dp_s = sc_s + NH * L;      // NH*L  (bwd only)
+    float* feats_s = dp_s + (BWD ? NH * L : 0);   // L*F
 
-    vin_s[tid] = a.vin[r][(size_t)n * 256 + tid];
-    if (tid < 16) {
+    for (int i = tid; i < QW; i += 256) vin_s[i] = a.vin[r][(size_t)n * QW + i];
+    if (tid < NH * 8) {
         u_s[tid] = 0.f;
         w_s[tid] = 0.f;
     }
     const float* fg = a.feats[r] + (size_t)n * L * F;
     for (int i = tid; i < L * F; i += 256) feats_s[i] = fg[i];
     if (BWD) {
-        const float* pg = a.p[r] + (size_t)n * 2 * L;
-        for (int i = tid; i < 2 * L; i += 256) sc_s[i] = pg[i];
+        const float* pg = a.p[r] + (size_t)n * NH * L;
+        for (int i = tid; i < NH * L; i += 256) sc_s[i] = pg[i];
     }
     __syncthreads();
 
     const float* wlp = a.wlp[r];
     const int grp = tid >> 4, sub = tid & 15;
-    const int gh = grp / F, gf = grp - gh * F;      // valid when grp < 2F
     // (1) u[h][f] = sum_e vin[h][e] Wlp[e][f]
-    if (grp < 2 * F) {
+    for (int gi = grp; gi < NH * F; gi += 16) {
+        const int gh = gi / F, gf = gi - gh * F;
         float s = 0.f;
         for (int e = sub; e < kD; e += 16) s = fmaf(vin_s[gh * kD + e], wlp[e * F + gf], s);
         s = group16_sum(s);
@@ -797,79 +802,78 @@ __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
     const uint8_t* mrow = a.mask[r] + (size_t)n * a.mstride[r];
     const float* pet = a.pet[r];
     for (int j = tid; j < L; j += 256) {
-        float s0 = 0.f, s1 = 0.f;
+        float sv[NH], tv[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) sv[h] = 0.f, tv[h] = 0.f;
         for (int f = 0; f < F; ++f) {
             const float fv = feats_s[j * F + f];
-            s0 = fmaf(fv, u_s[f], s0);
-            s1 = fmaf(fv, u_s[8 + f], s1);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) sv[h] = fmaf(fv, u_s[h * 8 + f], sv[h]);
         }
-        float t0 = 0.f, t1 = 0.f;
 #pragma unroll 8
         for (int e = 0; e < kD; ++e) {
             const float pv = pet[(size_t)e * L + j];
-            t0 = fmaf(pv, vin_s[e], t0);
-            t1 = fmaf(pv, vin_s[kD + e], t1);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) tv[h] = fmaf(pv, vin_s[h * kD + e], tv[h]);
         }
-        s0 += t0;
-        s1 += t1;
-        if (!BWD) {
-            s0 = s0 / a.scale;
-            s1 = s1 / a.scale;
-            if (mrow[j]) {
-                s0 = kMaskFill;
-                s1 = kMaskFill;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float sh = sv[h] + tv[h];
+            if (!BWD) {
+                sh = sh / a.scale;
+                if (mrow[j]) sh = kMaskFill;
+                sc_s[h * L + j] = sh;
+            } else {
+                dp_s[h * L + j] = sh;
             }
-            sc_s[j] = s0;
-            sc_s[L + j] = s1;
-        } else {
-            dp_s[j] = s0;
-            dp_s[L + j] = s1;
         }
     }
     __syncthreads();
 
-    // (3) softmax (fwd) / softmax backward (bwd) over the bins, both heads at once
+    // (3) softmax (fwd) / softmax backward (bwd) over the bins, all heads at once
     if (!BWD) {
-        float m0 = -INFINITY, m1 = -INFINITY;
-        for (int j = tid; j < L; j += 256) {
-            m0 = fmaxf(m0, sc_s[j]);
-            m1 = fmaxf(m1, sc_s[L + j]);
-        }
-        block_reduce2<true>(m0, m1, red_s);
-        float z0 = 0.f, z1 = 0.f;
-        for (int j = tid; j < L; j += 256) {
-            const float e0 = expf(sc_s[j] - m0), e1 = expf(sc_s[L + j] - m1);
-            sc_s[j] = e0;
-            sc_s[L + j] = e1;
-            z0 += e0;
-            z1 += e1;
-        }
-        block_reduce2<false>(z0, z1, red_s);
-        float* pg = a.p[r] + (size_t)n * 2 * L;
-        for (int j = tid; j < L; j += 256) {
-            const float p0 = sc_s[j] / z0, p1 = sc_s[L + j] / z1;
-            sc_s[j] = p0;
-            sc_s[L + j] = p1;
-            pg[j] = p0;
-            pg[L + j] = p1;
-        }
+        float m[NH], z[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) m[h] = -INFINITY, z[h] = 0.f;
+        for (int j = tid; j < L; j += 256)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) m[h] = fmaxf(m[h], sc_s[h * L + j]);
+        block_reduce_heads<true, NH>(m, red_s);
+        for (int j = tid; j < L; j += 256)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const float e = expf(sc_s[h * L + j] - m[h]);
+                sc_s[h * L + j] = e;
+                z[h] += e;
+            }
+        block_reduce_heads<false, NH>(z, red_s);
+        float* pg = a.p[r] + (size_t)n * NH * L;
+        for (int j = tid; j < L; j += 256)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const float pv = sc_s[h * L + j] / z[h];
+                sc_s[h * L + j] = pv;
+                pg[h * L + j] = pv;
+            }
     } else {
-        float d0 = 0.f, d1 = 0.f;
+        float d[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) d[h] = 0.f;
+        for (int j = tid; j < L; j += 256)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) d[h] = fmaf(sc_s[h * L + j], dp_s[h * L + j], d[h]);
+        block_reduce_heads<false, NH>(d, red_s);
         for (int j = tid; j < L; j += 256) {
-            d0 = fmaf(sc_s[j], dp_s[j], d0);
-            d1 = fmaf(sc_s[L + j], dp_s[L + j], d1);
-        }
-        block_reduce2<false>(d0, d1, red_s);
-        for (int j = tid; j < L; j += 256) {
-            const bool m = mrow[j] != 0;     // masked_fill passes no gradient
-            sc_s[j] = m ? 0.f : sc_s[j] * (dp_s[j] - d0) / a.scale;
-            sc_s[L + j] = m ? 0.f : sc_s[L + j] * (dp_s[L + j] - d1) / a.scale;
+            const bool mk = mrow[j] != 0;     // masked_fill passes no gradient
+#pragma unroll
+            for (int h = 0; h < NH; ++h) sc_s[h * L + j] = mk ? 0.f : sc_s[h * L + j] * (dp_s[h * L + j] - d[h]) / a.scale;
         }
     }
     __syncthreads();
 
     // (4) w[h][f] = sum_j sc[h][j] f_j[f]
-    if (grp < 2 * F) {
+    for (int gi = grp; gi < NH * F; gi += 16) {
+        const int gh = gi / F, gf = gi - gh * F;
         float s = 0.f;
         for (int j = sub; j < L; j += 16) s = fmaf(sc_s[gh * L + j], feats_s[j * F + gf], s);
         s = group16_sum(s);
@@ -880,30 +884,35 @@ __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
     const int Lh = (L + 1) >> 1;
     const int j0 = half * Lh, j1 = min(L, j0 + Lh);
     const float* pe = a.pe[r];
-    float c0 = 0.f, c1 = 0.f;
+    float cv[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) cv[h] = 0.f;
 #pragma unroll 4
     for (int j = j0; j < j1; ++j) {
         const float pv = pe[(size_t)j * kD + e];
-        c0 = fmaf(sc_s[j], pv, c0);
-        c1 = fmaf(sc_s[L + j], pv, c1);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) cv[h] = fmaf(sc_s[h * L + j], pv, cv[h]);
     }
     if (half == 1) {
-        half_s[e] = c0;
-        half_s[kD + e] = c1;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) half_s[h * kD + e] = cv[h];
     }
     __syncthreads();
-    if (tid < 16) a.w[r][(size_t)n * 16 + tid] = w_s[tid];
+    if (tid < NH * 8) a.w[r][(size_t)n * NH * 8 + tid] = w_s[tid];
     if (half == 0) {
-        c0 += half_s[e];
-        c1 += half_s[kD + e];
-        float x0 = 0.f, x1 = 0.f;
+        float xv[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            cv[h] += half_s[h * kD + e];
+            xv[h] = 0.f;
+        }
         for (int f = 0; f < F; ++f) {
             const float wv = wlp[e * F + f];
-            x0 = fmaf(w_s[f], wv, x0);
-            x1 = fmaf(w_s[8 + f], wv, x1);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) xv[h] = fmaf(w_s[h * 8 + f], wv, xv[h]);
         }
-        a.vout[r][(size_t)n * 256 + e] = x0 + c0;
-        a.vout[r][(size_t)n * 256 + kD + e] = x1 + c1;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) a.vout[r][(size_t)n * QW + h * kD + e] = xv[h] + cv[h];
     }
 }
 
@@ -995,21 +1004,23 @@ struct PostArgs {
 
 // NWV waves per workgroup (4 or 8): wave w owns 128 / NWV output columns of every product (DFF / NWV of the hidden layer), so with
 // eight waves two of them share a SIMD and one's operand waits hide behind the other's products; the LayerNorms run on waves 0..3.
-template <int DFF>
+template <int DFF, int NH = 2>
 struct PostFwdLds {      // LDS tiles of post_fwd_body
-    static constexpr int HW = (DFF > 256 ? DFF : 256);
+    static constexpr int HW0 = (DFF > 256 ? DFF : 256);
+    static constexpr int HW = (NH * kD > HW0 ? NH * kD : HW0);      // (the hidden tile first holds the NH x 128 attention rows)
 };
-template <bool VPROJ, int DM, int DFF, int NWV>
+template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2>
 __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, const int row0, const int N, float (*xs)[kD + 4],
-                                              float (*as_)[DM + 4], float (*ts)[kD + 4], float (*hs)[PostFwdLds<DFF>::HW + 4]) {
-    constexpr int HW = PostFwdLds<DFF>::HW;
+                                              float (*as_)[DM + 4], float (*ts)[kD + 4], float (*hs)[PostFwdLds<DFF, NH>::HW + 4]) {
+    constexpr int HW = PostFwdLds<DFF, NH>::HW;
+    constexpr int DH = kD / NH, QW = NH * kD;
     constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / column tiles per wave
     constexpr int CH = DFF / NWV, NT1 = CH / 16;          // hidden columns / tiles per wave
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     TileReq<kD, NWV * 64> tx;
-    TileReq<256, NWV * 64> th;
+    TileReq<QW, NWV * 64> th;
     tile_req(tx, a.x[r], kD, row0, N, a.xmap);
-    if (VPROJ) tile_req(th, a.ain[r], 256, row0, N, identity_map());
+    if (VPROJ) tile_req(th, a.ain[r], QW, row0, N, identity_map());
     FragNT<NTC, DM / 16> fo;
     FragNT<NTC, 8> fv;
     if (VPROJ) frag_load_nt(fv, a.wv[r] + (size_t)(w * CW) * kD, kD);
@@ -1023,7 +1034,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
     if (VPROJ) {
         tile_put(th, &hs[0][0], HW + 4, row0, N);
         __syncthreads();
-        const int h = (w * CW) >> 6;
+        const int h = (w * CW) / DH;
         f32x4 acc[NTC];
         zero_acc(acc);
         frag_mma_nt(fv, &hs[0][h * kD], HW + 4, acc);
@@ -1099,10 +1110,10 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
     __syncthreads();
     if (w < 4) ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
     if (nq) {
-        constexpr int EW = 256 / NWV, NTE = EW / 16;          // qt columns per wave (2 heads x 128)
+        constexpr int EW = QW / NWV, NTE = EW / 16;           // qt columns per wave (NH heads x 128)
         const int hq = (w * EW) >> 7, e0 = (w * EW) & 127;
-        FragNN<NTE, 4> fk;
-        frag_load_nn(fk, a.nq_wk[r] + (size_t)(hq * 64) * kD + e0, kD);
+        FragNN<NTE, DH / 16> fk;
+        frag_load_nn(fk, a.nq_wk[r] + (size_t)(hq * DH) * kD + e0, kD);
         __syncthreads();
         {   // q = out Wq^T   (ts is free: the last reader was the FFN's second product)
             f32x4 acc[NTC];
@@ -1121,7 +1132,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
         {
             f32x4 acc[NTE];
             zero_acc(acc);
-            frag_mma_nn(fk, &ts[0][hq * 64], kD + 4, acc);
+            frag_mma_nn(fk, &ts[0][hq * DH], kD + 4, acc);
             typedef typename VecN<NTE>::type vec_t;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1130,7 +1141,7 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
 #pragma unroll
                 for (int t = 0; t < NTE; ++t) v[t] = acc[t][i];
                 if (row0 + row < N)
-                    LdgN<NTE>::st(a.nq_qt[r] + (size_t)(row0 + row) * 256 + hq * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
+                    LdgN<NTE>::st(a.nq_qt[r] + (size_t)(row0 + row) * QW + hq * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
             }
         }
     }
@@ -1151,9 +1162,9 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
 
 // RT: the instantiation that hosts tiled-copy units (PostArgs::rt_units) -- a template parameter, so that the other instantiations
 // keep their code (the extra path cost k_post_fwd<true, 128, 256, 8> 2.4 us per launch when it was a run-time branch in all of them)
-template <bool VPROJ, int DM, int DFF, int NWV, bool RT = false>
+template <bool VPROJ, int DM, int DFF, int NWV, bool RT = false, int NH = 2>
 __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
-    constexpr int HW = PostFwdLds<DFF>::HW;
+    constexpr int HW = PostFwdLds<DFF, NH>::HW;
     __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
     __shared__ __attribute__((aligned(16))) float as_[kTile][DM + 4];
     __shared__ __attribute__((aligned(16))) float ts[kTile][kD + 4];
@@ -1163,7 +1174,7 @@ __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
         if (u < a.rt_n) retile_unit<NWV>(a.rt_params, a.rt_tiled, a.rt_tiledT, a.rt_units[u]);
         return;
     }
-    post_fwd_body<VPROJ, DM, DFF, NWV>(a, blockIdx.y, blockIdx.x * kTile, a.N, xs, as_, ts, hs);
+    post_fwd_body<VPROJ, DM, DFF, NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, a.N, xs, as_, ts, hs);
 }
 
 // backward of the chain.  Per tile it also emits the column sums that make up the
@@ -1193,7 +1204,7 @@ struct PostBwdArgs {
 __host__ __device__ constexpr int post_partial_width(int dff) { return 768 + dff; }
 
 // part_row: row of the partial buffer this tile's column sums go to (the tile index; the gene in the fused kernels)
-template <bool VPROJ, int DM, int DFF, int NWV>
+template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2>
 __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r, const int row0, const int N, const int part_row,
                                               float (*ds)[kD + 4], float (*xh)[kD + 4], float (*t2)[kD + 4],
                                               float (*wide)[(DFF > DM ? DFF : DM) + 4]) {
@@ -1290,15 +1301,16 @@ __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r,
             if (row0 + row < N) LdgN<NTO>::st(a.da[r] + (size_t)(row0 + row) * DM + col, *reinterpret_cast<const vec_t*>(v));
         }
     }
-    if (VPROJ) {   // dxbar[:, h, e] = sum_d da[:, h*64+d] Wv[h*64+d, e]
-        constexpr int EW = 256 / NWV, NTE = EW / 16;
+    if (VPROJ) {   // dxbar[:, h, e] = sum_d da[:, h*dh+d] Wv[h*dh+d, e]
+        constexpr int DH = kD / NH, QW = NH * kD;
+        constexpr int EW = QW / NWV, NTE = EW / 16;
         const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
-        FragNN<NTE, 4> fwv;
-        frag_load_nn(fwv, a.wv[r] + (size_t)(h * 64) * kD + e0, kD);
+        FragNN<NTE, DH / 16> fwv;
+        frag_load_nn(fwv, a.wv[r] + (size_t)(h * DH) * kD + e0, kD);
         __syncthreads();
         f32x4 acc[NTE];
         zero_acc(acc);
-        frag_mma_nn(fwv, &wide[0][h * 64], WW + 4, acc);
+        frag_mma_nn(fwv, &wide[0][h * DH], WW + 4, acc);
         typedef typename VecN<NTE>::type vec_t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1307,19 +1319,19 @@ __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r,
 #pragma unroll
             for (int t = 0; t < NTE; ++t) v[t] = acc[t][i];
             if (row0 + row < N)
-                LdgN<NTE>::st(a.dxbar[r] + (size_t)(row0 + row) * 256 + h * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
+                LdgN<NTE>::st(a.dxbar[r] + (size_t)(row0 + row) * QW + h * kD + e0 + NTE * lr, *reinterpret_cast<const vec_t*>(v));
         }
     }
 }
 
-template <bool VPROJ, int DM, int DFF, int NWV>
+template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2>
 __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
     constexpr int WW = (DFF > DM ? DFF : DM);
     __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1 -> dt1
     __shared__ __attribute__((aligned(16))) float xh[kTile][kD + 4];    // xhat2 -> xhat1
     __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2
     __shared__ __attribute__((aligned(16))) float wide[kTile][WW + 4];  // dpre1 -> da
-    post_bwd_body<VPROJ, DM, DFF, NWV>(a, blockIdx.y, blockIdx.x * kTile, a.N, blockIdx.x, ds, xh, t2, wide);
+    post_bwd_body<VPROJ, DM, DFF, NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, a.N, blockIdx.x, ds, xh, t2, wide);
 }
 
 // =======================================================================================

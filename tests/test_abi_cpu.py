@@ -67,6 +67,19 @@ def test_unsupported_configs_are_rejected_loudly():
     cfg = _cfg()
     cfg.d_head = 96
     assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) == 0
+    # head counts: Embedding / Pairwise 1, 2, 4 (d_model = 128), Regulation 4 or 8 heads with d_model 128 or 256; the rest is refused by name
+    for field, value, ok in (("embed_heads", 1, True), ("embed_heads", 4, True), ("embed_heads", 8, False), ("pair_heads", 4, True),
+                             ("pair_heads", 3, False), ("pair_dmodel", 256, False), ("reg_heads", 4, True), ("reg_heads", 2, False),
+                             ("reg_dmodel", 128, True), ("reg_dmodel", 512, False)):
+        cfg = _cfg()
+        setattr(cfg, field, value)
+        rc = _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0)
+        assert (rc == 0) == ok, (field, value)
+        if not ok:
+            assert b"n_heads in" in _lib.lib().cf_last_error()
+    cfg = _cfg()
+    cfg.embed_heads, cfg.embed_layers = 4, 2       # the all-rows Embedding path (n_layers > 1) exists for two heads only
+    assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0 and b"all-rows" in _lib.lib().cf_last_error()
 
 
 def test_model_state_dict_and_seeded_init_match_golden():

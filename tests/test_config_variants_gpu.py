@@ -4,6 +4,7 @@ an MFMA tile, and takes the unfused kernels), other depths and FFN widths, other
 all gradients against the oracle's autograd, same tolerances as the default-config tests."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import chromoformer_oracle as orc
 
@@ -20,6 +21,13 @@ VARIANTS = {
     "three_pairwise_layers": dict(pairwise_interaction=dict(n_layers=3, n_heads=2, d_model=128, d_ff=256)),
     "six_pairwise_layers": dict(pairwise_interaction=dict(n_layers=6, n_heads=2, d_model=128, d_ff=256)),
     "deep_reg": dict(regulation=dict(n_layers=8, n_heads=8, d_model=256, d_ff=256)),
+    # Embedding / Pairwise head counts other than 2 (d_head 128 / 32): the stand-alone chain kernels instantiated for that head count and
+    # the one-sequence-per-workgroup attention (k_attc)
+    "one_head": dict(embed=dict(n_layers=1, n_heads=1, d_model=128, d_ff=128), pairwise_interaction=dict(n_layers=2, n_heads=1, d_model=128, d_ff=256)),
+    "four_heads": dict(embed=dict(n_layers=1, n_heads=4, d_model=128, d_ff=128), pairwise_interaction=dict(n_layers=2, n_heads=4, d_model=128, d_ff=256)),
+    "mixed_heads": dict(embed=dict(n_layers=1, n_heads=4, d_model=128, d_ff=256), pairwise_interaction=dict(n_layers=3, n_heads=1, d_model=128, d_ff=128),
+                        regulation=dict(n_layers=2, n_heads=4, d_model=128, d_ff=256)),
+    "embed_2_pair_4_heads": dict(pairwise_interaction=dict(n_layers=2, n_heads=4, d_model=128, d_ff=256)),
     # Regulation head counts / widths other than 8 x 32: the layer-by-layer kernels (run-time heads in k_attr, both widths of the products)
     "reg_4_heads": dict(regulation=dict(n_layers=3, n_heads=4, d_model=256, d_ff=256)),
     "reg_d_model_128": dict(regulation=dict(n_layers=3, n_heads=8, d_model=128, d_ff=256)),
@@ -28,7 +36,22 @@ VARIANTS = {
     "d_head_256": dict(d_head=256),
     "other_bins": dict(binsizes=[1000, 250, 50], w_max=20000),          # L = 20 / 80 / 400 again but other PE tables ... and
     "odd_lengths": dict(binsizes=[4000, 800, 160], w_max=40000),        # L = 10 / 50 / 250: not multiples of 16 or 64
+    # L = 20 / 80 / 800: eight 800-bin regions do not fit the LDS image of the gene-batched attention kernel, every centre-row attention
+    # takes the one-sequence-per-workgroup kernel (k_attc) -- with two heads here, with four in the next
+    "long_rows": dict(binsizes=[2000, 500, 50], w_max=40000),
+    "long_rows_4_heads": dict(binsizes=[2000, 500, 50], w_max=40000, embed=dict(n_layers=1, n_heads=4, d_model=128, d_ff=128),
+                              pairwise_interaction=dict(n_layers=2, n_heads=4, d_model=128, d_ff=256)),
 }
+
+
+def _to_f64(o):
+    if torch.is_tensor(o):
+        return o.double() if o.is_floating_point() else o
+    if isinstance(o, (list, tuple)):
+        return type(o)(_to_f64(x) for x in o)
+    if isinstance(o, dict):
+        return {k: _to_f64(v) for k, v in o.items()}
+    return o
 
 
 @pytest.mark.parametrize("name", sorted(VARIANTS))
@@ -57,15 +80,29 @@ def test_forward_and_gradients_match_oracle(name, reg):
     assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
     model._publish_grads()
     named = dict(model.named_parameters())
+    off = []
     for k, v in P.items():
         if orc.never_trained(k):
             assert named[k].grad is None
             continue
         err = (named[k].grad.cpu() - v.grad).abs().max().item()
-        assert err <= GRAD_TOL * v.grad.abs().max().item() + 1e-9, (k, err, v.grad.abs().max().item())
+        if err > GRAD_TOL * v.grad.abs().max().item() + 1e-9:
+            off.append((k, err, v.grad.abs().max().item()))
+    if off:
+        # A ReLU gate within fp32 rounding of zero can be open in one implementation and shut in the other; one flipped gate is one row of
+        # an l1.weight gradient off by per cent (and everything upstream of it by ~1e-3).  Which side flipped depends on the host's BLAS:
+        # an fp64 run of the oracle decides (seen on the GPU box for "embed_2_pair_4_heads": the fp32 oracle was the one off;
+        # tools/variant_err.py prints both distances).  The HIP path has to be within the same tolerance of the fp64 gradients.
+        P64 = {k: v.detach().double().requires_grad_(True) for k, v in P.items()}
+        lo64 = orc.forward(P64, _to_f64(batch), cfg)
+        (F.mse_loss(lo64, batch["label"].view(-1, 1).double()) if reg else F.cross_entropy(lo64, batch["label"].long())).backward()      # (oracle loss_fn in fp64)
+        for k, err, _ in off:
+            ref = P64[k].grad
+            e64 = (named[k].grad.cpu().double() - ref).abs().max().item()
+            assert e64 <= GRAD_TOL * ref.abs().max().item() + 1e-9, (k, "against the fp32 oracle", err, "against the fp64 oracle", e64, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths", "d_head_96", "reg_4_heads_d_model_128"])
+@pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths", "d_head_96", "reg_4_heads_d_model_128", "mixed_heads"])
 def test_fused_optimiser_and_riders_equal_the_separate_launches(name):
     """Away from the default shapes: AdamW in the reduction epilogues, both buckets in one launch, part of the tiles riding in the trunk's
     backward launch where the fused trunk kernels exist (elsewhere the trainer falls back) -- same parameters and moments, bit for bit,
