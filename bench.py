@@ -250,8 +250,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the step as hipGraphs in the timed region (split around the event-bracketed roofline kernel: measured "
-                         "+8..12 us per step).  Default: graph replay under data parallelism (--gpus > 1: five host calls per step "
-                         "instead of ~30 matter with eight ranks driving one host), eager launches on one GPU, where the one-graph "
+                         "+8..12 us per step).  Default: graph replay under data parallelism (--gpus > 1: the host calls of a step halve -- which matters "
+                         "with eight ranks driving one host, a configuration never run; on the one-rank proxy the eager schedule is 2 %% faster, see "
+                         "`dp_path_ms_per_step`), eager launches on one GPU, where the one-graph "
                          "replay time is reported beside it as `graph_replay_ms_per_step`")
     ap.add_argument("--eager", "--no-graph", dest="graph", action="store_false", help="issue the launches of a step one by one")
     ap.add_argument("--no-cpu-baseline", action="store_true")

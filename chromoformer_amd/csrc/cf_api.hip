@@ -940,28 +940,21 @@ static size_t attr_smem(int T, int H, int DM, bool bwd) {
 constexpr int kPostWaves = CF_POST_WAVES;      // waves per workgroup of the row-tile chains (k_post_*, k_qchain_*): 4 or 8
 template <bool VPROJ, int DM>
 static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& a) {
-    if (a.rt_units) {      // the hosting instantiation (eight waves; cf_forward asks for it only then)
-        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8, true>), grid, dim3(512), 0, st, a);
-        return;
+    if constexpr (VPROJ && DM == 128) {      // the hosting instantiation (eight waves; the Embedding layer's launch asks for it, nobody else)
+        if (a.rt_units) {
+            if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8, true>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8, true>), grid, dim3(512), 0, st, a);
+            return;
+        }
     }
-    if (kPostWaves == 8) {
-        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8>), grid, dim3(512), 0, st, a);
-    } else {
-        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 4>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 4>), grid, dim3(256), 0, st, a);
-    }
+    // (kPostWaves is a compile-time switch: only the selected form is instantiated)
+    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
 }
 template <bool VPROJ, int DM>
 static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArgs& a) {
-    if (kPostWaves == 8) {
-        if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, 8>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, 8>), grid, dim3(512), 0, st, a);
-    } else {
-        if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, 4>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, 4>), grid, dim3(256), 0, st, a);
-    }
+    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
 }
 
 // The stand-alone stages of one centre-row layer for a head count other than 2 (eight-wave chain kernels, the one-sequence-per-workgroup
