@@ -2512,7 +2512,7 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t st) {
     const int mode = getenv_int("CF_ATTN_BWD_SPLIT", 0);
     const bool vec_ok = (a.ldq & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dq) & 15) == 0;      // (the dQ update is 16 bytes per lane)
     if (vec_ok && (mode < 0 || (mode == 0 && (long long)a.N * a.H >= 512))) {
-        hipLaunchKernelGGL(k_attn_bwd, dim3(a.H, a.N), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_attn_bwd<0>, dim3(a.H, a.N), dim3(256), 0, st, a);      // (<2>: next-tile register prefetch, measured slower: LAB_NOTES.md)
         LAUNCH_CHECK("k_attn_bwd");
         return 0;
     }

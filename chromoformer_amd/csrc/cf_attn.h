@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Ps[4][16 * kALd];
+    __shared__ float Kvs[kABk];      // validity of the tile's keys: travels with the tile (a global byte load at the point of use stalls the softmax)
     const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * kABq;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
     const int row_a = q0 + 16 * w + r;                  // the row this lane feeds as A operand
@@ -139,14 +140,21 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
     AttnTileRegs kr, vr;
     attn_fetch(kr, kbase, a.ldk, 0, a.Lk);
     attn_fetch(vr, vbase, a.ldv, 0, a.Lk);
+    const auto kv_fetch = [&](int k0n) {
+        const int j = k0n + (int)threadIdx.x;
+        return threadIdx.x < kABk && attn_kvalid(a, n, min(j, a.Lk - 1)) && j < a.Lk ? 1.f : 0.f;
+    };
+    float kvn = kv_fetch(0);
     for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
         __syncthreads();
         attn_put(Ks, kr);
         attn_put(Vs, vr);
+        if (threadIdx.x < kABk) Kvs[threadIdx.x] = kvn;
         __syncthreads();
         if (k0 + kABk < a.Lk) {
             attn_fetch(kr, kbase, a.ldk, k0 + kABk, a.Lk);
             attn_fetch(vr, vbase, a.ldv, k0 + kABk, a.Lk);
+            kvn = kv_fetch(k0 + kABk);
         }
         f32x4 s[4];
         zero_acc(s);
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int j = k0 + 16 * t + r;
-            const bool kvj = attn_kvalid(a, n, j);
+            const bool kvj = Kvs[16 * t + r] != 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float x = s[t][g] * a.rscale;
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_kv(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
     __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
     __shared__ __attribute__((aligned(16))) float Pt[4][16 * kALd];     // per-wave patches: p^T / ds^T [16 keys][64 rows]
+    __shared__ __attribute__((aligned(16))) float Ss[kABq * 4];         // row statistics of the query tile (as in k_attn_bwd below)
     const int n = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * kABk;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
     // this wave's 16 keys as the A operand of S^T = K Q^T and dP^T = V dO^T
@@ -282,8 +291,15 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_kv(AttnArgs a) {
             AttnTileRegs qr, gr;
             attn_fetch(qr, qbase, a.ldq, q0, a.Lq);
             attn_fetch(gr, gbase, a.ldo, q0, a.Lq);
+            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (threadIdx.x < kABq) {      // max, 1 / sum, delta, valid of row q0 + thread: the softmax below reads them from LDS
+                const int ic = min(q0 + (int)threadIdx.x, a.Lq - 1);
+                const float2 ml = ldg2(stp + 2 * ic);
+                sv = make_float4(ml.x, ml.y, ldg(dlp + ic), (a.qvalid ? a.qvalid[(size_t)n * a.Lq + ic] != 0 : true) ? 1.f : 0.f);
+            }
             attn_put(Qs, qr);
             attn_put(Gs, gr);
+            if (threadIdx.x < kABq) *reinterpret_cast<float4*>(Ss + threadIdx.x * 4) = sv;
         }
         __syncthreads();
         f32x4 st[4], dpt[4];                               // S^T, dP^T: rows = keys 4qd+g, columns = query 16t + r
@@ -296,8 +312,9 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_kv(AttnArgs a) {
         for (int t = 0; t < 4; ++t) {
             const int i = q0 + 16 * t + r;
             const bool iv = i < a.Lq;
-            const float mrow = iv ? stp[2 * i] : 0.f, linv = iv ? stp[2 * i + 1] : 0.f, dl = iv ? dlp[i] : 0.f;
-            const bool qvi = iv && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + i] != 0 : true);
+            const float4 sv = *reinterpret_cast<const float4*>(Ss + (16 * t + r) * 4);
+            const float mrow = sv.x, linv = sv.y, dl = sv.z;
+            const bool qvi = iv && sv.w != 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float p = 0.f, d = 0.f;
@@ -411,10 +428,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_q(AttnArgs a) {
 // follow each other in a fixed order: no atomics, bit-reproducible.  Two workgroups per CU: the 52 KB of LDS would allow the three the
 // other attention kernels run with, 170 registers do not (131 spilled VGPRs: backward 26.5 ms against 21.0 with two workgroups of
 // 256-register waves).  Stress configuration: backward 24.2 -> 21.0 ms (73.5 -> 84.9 TFLOP/s of algorithmic work).
+template <int PF>      // next query tile requested under the dQ^T product: 0 no, 1 the Q tile, 2 Q and dO tiles
 __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
     __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
     __shared__ __attribute__((aligned(16))) float Pt[4][16 * kALd];     // per-wave patches: p^T / ds^T [16 keys][64 rows]
+    __shared__ __attribute__((aligned(16))) float Ss[kABq * 4];         // row statistics of the query tile: max, 1 / sum, delta, valid
     const int n = blockIdx.y, h = blockIdx.x;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
     const float* qbase = a.q + (size_t)n * a.Lq * a.ldq + h * kADh;
@@ -422,6 +441,16 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
     const float* stp = a.stats + ((size_t)n * a.H + h) * a.Lq * 2;
     const float* dlp = a.delta + ((size_t)n * a.H + h) * a.Lq;
     float* dqb = a.dq + (size_t)n * a.Lq * a.ldq + h * kADh + 16 * w + 4 * qd;      // this lane's four columns
+    // the statistics of a query tile travel with it (thread i < 64: row i): the softmax of a pair reads them from LDS instead of waiting for L2
+    auto stat_fetch = [&](int q0n) {
+        const int i = q0n + (int)threadIdx.x, ic = min(i, a.Lq - 1);
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x < kABq) {
+            const float2 ml = ldg2(stp + 2 * ic);
+            sv = make_float4(ml.x, ml.y, ldg(dlp + ic), (a.qvalid ? a.qvalid[(size_t)n * a.Lq + ic] != 0 : true) ? 1.f : 0.f);
+        }
+        return sv;
+    };
     for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
         // this wave's 16 keys as the A operand of S^T = K Q^T and dP^T = V dO^T
         const int key_a = k0 + 16 * w + r;
@@ -464,8 +493,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
             AttnTileRegs qr, gr;
             attn_fetch(qr, qbase, a.ldq, 0, a.Lq);
             attn_fetch(gr, gbase, a.ldo, 0, a.Lq);
+            const float4 sv = stat_fetch(0);
             attn_put(Qs, qr);
             attn_put(Gs, gr);
+            if (threadIdx.x < kABq) *reinterpret_cast<float4*>(Ss + threadIdx.x * 4) = sv;
         }
         __syncthreads();
         for (int q0 = 0; q0 < a.Lq; q0 += kABq) {
@@ -478,8 +509,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
             for (int t = 0; t < 4; ++t) {
                 const int i = q0 + 16 * t + r;
                 const bool iv = i < a.Lq;
-                const float mrow = iv ? stp[2 * i] : 0.f, linv = iv ? stp[2 * i + 1] : 0.f, dl = iv ? dlp[i] : 0.f;
-                const bool qvi = iv && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + i] != 0 : true);
+                const float4 sv = *reinterpret_cast<const float4*>(Ss + (16 * t + r) * 4);
+                const float mrow = sv.x, linv = sv.y, dl = sv.z;
+                const bool qvi = iv && sv.w != 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float p = 0.f, d = 0.f;
@@ -507,6 +539,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
             __builtin_amdgcn_wave_barrier();
             attn_mma_nn(&Pt[w][0], Qs, dk);                   // dK += dS^T . Q
             __syncthreads();                                  // all four dS^T patches are written; nobody reads Qs / Gs any more
+            // the next query tile is requested here, behind the barrier that freed Qs / Gs, and lands under the dQ^T product
+            AttnTileRegs qr, gr;
+            const bool more = q0 + kABq < a.Lq;
+            if (PF >= 1 && more) attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
+            if (PF >= 2 && more) attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
+            float4 svn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (more) svn = stat_fetch(q0 + kABq);
             f32x4 dq[4];                                      // dQ^T: rows = head columns 16 w + 4 qd + g, columns = query row 16 t + r
             zero_acc(dq);
 #pragma unroll
@@ -526,12 +565,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
                     stg4(dqb + (size_t)row * a.ldq, v);
                 }
             }
-            if (q0 + kABq < a.Lq) {      // the next query tile
-                AttnTileRegs qr, gr;
-                attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
-                attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
+            if (more) {
+                if (PF < 1) attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
+                if (PF < 2) attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
                 attn_put(Qs, qr);
                 attn_put(Gs, gr);
+                if (threadIdx.x < kABq) *reinterpret_cast<float4*>(Ss + threadIdx.x * 4) = svn;
             }
             __syncthreads();                                  // the next tile is in LDS; every wave is done with the patches
         }
