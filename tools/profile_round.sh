@@ -42,5 +42,7 @@ timeout 200 python3 bench.py --config stress --steps 20 --warmup 3 > $OUT/bench_
 CF_TRUNK=0 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-dp-path --train-loop-steps 0 > $OUT/bench_no_trunk.json 2> /dev/null
 timeout 100 python3 tools/trunk_stamps.py > $OUT/trunk_stamps.txt 2> /dev/null
 timeout 100 python3 tools/bin_bench.py 2> /dev/null | tail -1 > $OUT/binning.json
+timeout 200 python3 tools/stress_bench.py 2> /dev/null | tail -1 > $OUT/stress_attention.json
+[ -x build/team_exchange ] && timeout 60 build/team_exchange 64 > $OUT/team_exchange.txt 2>&1
 timeout 200 python3 tools/epoch_evidence.py --bench-genes-per-s $(python3 -c "import json; print(json.load(open('$OUT/bench.json'))['train_loop']['value'])" 2> /dev/null || echo 0) > $OUT/epoch_18955.txt 2>&1
 ls -la $OUT
