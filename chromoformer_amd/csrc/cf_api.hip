@@ -223,6 +223,9 @@ struct cf_handle {
     float* tiled = nullptr;              // tiled copy of the Linear weights (forward products), same offsets
     float* tiledT = nullptr;             // tiled copy of the transposed Regulation weights (backward products), same offsets
     bool reg8 = false;                   // Regulation stack on the 512-thread kernels of cf_reg8.h
+    bool reg_team = false;               // ... its forward on teams of four 256-thread workgroups (cf_regq.h; CF_REG_TEAM=1)
+    float* team_slots = nullptr;
+    int* team_cnt = nullptr;
     // Embedding stack over ALL promoter bins (cf_embed_full.h + the dense transformer layer): used by the model path when
     // embed.n_layers > 1 and by cf_embed_full; device buffers outside the arena, allocated on first need
     struct EmbedDense {
@@ -455,6 +458,8 @@ static void plan_workspace(cf_handle* h) {
     h->loss_part = h->ws_get("H.loss_part", MB + 1);      // (per 16-gene tile; per gene in the generic-width head)
     h->head_cnt = reinterpret_cast<int*>(h->ws_get("H.cnt", MB + 1));      // arrivals per gene + genes done (cf_head_ride.h); zero between launches
     h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 64);      // shader-clock stamps (uint64) of the fused Regulation kernels
+    h->team_slots = h->ws_get("R.team_slots", regq_slot_floats((int)MB * c.n_res));      // (cf_regq.h; the arena is zeroed at cf_create: the counters start at 0)
+    h->team_cnt = reinterpret_cast<int*>(h->ws_get("R.team_cnt", (size_t)MB * c.n_res * kTqCnt));
 }
 
 // ------------------------------------------------------------------------------------
@@ -855,6 +860,20 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             if (e1 != hipSuccess || e2 != hipSuccess) h->reg_fused = false;
         }
         if (!h->reg_fused) h->reg8 = false;
+        // the team forward (cf_regq.h): default Regulation shape with d_ff = 256, and a device on which workgroup i of a launch runs on
+        // XCD i mod 8 -- the four members of a team then share an L2, which is what makes their plain-store / sc1-load exchange coherent
+        if (h->reg8 && c.reg_dff == 256 && getenv_int("CF_REG_TEAM", 0) != 0) {
+            unsigned* probe = nullptr;
+            unsigned host[64];
+            bool ok = hipMalloc(&probe, sizeof host) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(k_xcc_probe, dim3(64), dim3(64), 0, 0, probe);
+                ok = hipMemcpy(host, probe, sizeof host, hipMemcpyDeviceToHost) == hipSuccess;
+                for (int i = 0; ok && i < 64; ++i) ok = host[i] == (unsigned)(i & 7);
+                (void)hipFree(probe);
+            }
+            h->reg_team = ok;
+        }
     }
     {   // gene-batched attention kernel when its LDS image (8 regions of features + 16 score rows) fits
         size_t need = 0;
@@ -1110,7 +1129,8 @@ static int check_batch(const cf_handle* h, const cf_batch* b) {
 // Launch of a fused Regulation kernel.  Under capture, if it is the kernel selected with cf_timing_select, the
 // capture is split around it: the launch is remembered instead of recorded and cf_graph_launch issues it eagerly,
 // between two HIP events, between the two graph pieces.
-static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid, size_t smem, RegArgs& ra, hipStream_t st) {
+static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid, size_t smem, RegArgs& ra, hipStream_t st, int threads = 0) {
+    const dim3 block(threads ? threads : (h->reg8 ? 512 : 256));
     if (h->capturing && h->timed == name && !h->cap.has_hole) {
         hipGraph_t g = nullptr;
         HIP_TRY(hipStreamEndCapture(st, &g));
@@ -1120,7 +1140,7 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
         h->cap.has_hole = true;
         h->cap.hole.func = fn;
         h->cap.hole.grid = grid;
-        h->cap.hole.block = dim3(h->reg8 ? 512 : 256);
+        h->cap.hole.block = block;
         h->cap.hole.smem = smem;
         h->cap.hole.args = ra;
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
@@ -1129,7 +1149,7 @@ static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid,
     }
     void* kargs[] = {&ra};
     h->time_mark(name, st);
-    HIP_TRY(hipLaunchKernel(fn, grid, dim3(h->reg8 ? 512 : 256), kargs, smem, st));
+    HIP_TRY(hipLaunchKernel(fn, grid, block, kargs, smem, st));
     h->time_mark(name, st);
     LAUNCH_CHECK(name);
     return 0;
@@ -1448,8 +1468,13 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
         memset(&ra.head, 0, sizeof ra.head);
         if (ride) ra.head = *ride;
-        if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T, h->reg8, save != 0), dim3(8 * ((B * nres + 7) / 8)),
-                       h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), ra, st))
+        ra.team_slots = h->team_slots;
+        ra.team_cnt = h->team_cnt;
+        if (h->reg_team) {      // four 256-thread workgroups per (gene, resolution), 8 workgroup ids apart (cf_regq.h)
+            const void* fn = save != 0 ? (const void*)k_regq_fwd<true> : (const void*)k_regq_fwd<false>;
+            if (launch_reg(h, "k_reg_fwd", fn, dim3(32 * ((B * nres + 7) / 8)), regq_fwd_smem(), ra, st, 256)) return -1;
+        } else if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T, h->reg8, save != 0), dim3(8 * ((B * nres + 7) / 8)),
+                              h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), ra, st))
             return -1;
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
@@ -1545,7 +1570,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
 // default head width; CF_HEAD_RIDE=0 at cf_create switches it off: A/B runs, cross-checks.)
 extern "C" int cf_head_rides(cf_handle* h) {
     if (!h) return 0;
-    return h->reg_fused && h->reg8 && h->cfg.n_res == kMaxRes && h->cfg.d_head == kD && h->head_ride ? 1 : 0;
+    return h->reg_fused && h->reg8 && !h->reg_team && h->cfg.n_res == kMaxRes && h->cfg.d_head == kD && h->head_ride ? 1 : 0;
 }
 // cf_forward(save_for_backward = 2) for a training step whose labels are known at forward time: where cf_head_rides(h), the
 // prediction head -- forward, loss, its backward down to the gradient of token 0 of every Regulation output -- runs at the tail of the

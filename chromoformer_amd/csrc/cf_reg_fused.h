@@ -25,6 +25,8 @@ struct RegArgs {
     int save;
     unsigned long long* tdbg;        // optional: shader-clock stamps of workgroup (0,0), 16 per layer
     HeadRide head;                   // forward (cf_reg8.h): the gene's prediction head at the tail of its last workgroup (cf_head_ride.h)
+    float* team_slots;               // cf_regq.h: exchange slots of the four-workgroup teams, [units][2][4][16 x 128]
+    int* team_cnt;                   //            arrival / departure counters, [units][32]
 };
 #define CF_STAMP(slot)                                                                                 \
     do {                                                                                               \

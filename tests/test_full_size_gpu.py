@@ -78,7 +78,8 @@ def test_bsz64_forward_loss_and_all_gradients_match_the_oracle(case):
     assert n == 334
 
 
-@pytest.mark.parametrize("env", [{"CF_ATTC1": "0"}, {"CF_REG8": "0"}, {"CF_HEAD_RIDE": "0"}], ids=["attc1_vs_attc2", "reg8_vs_reg4", "head_ride_vs_head_launch"])
+@pytest.mark.parametrize("env", [{"CF_ATTC1": "0"}, {"CF_REG8": "0"}, {"CF_HEAD_RIDE": "0"}, {"CF_REG_TEAM": "1"}],
+                         ids=["attc1_vs_attc2", "reg8_vs_reg4", "head_ride_vs_head_launch", "reg8_vs_team_forward"])
 def test_bsz64_independent_kernel_implementations_agree(case, env):
     batch, P = case
     logits, loss, grads = _model_run({}, batch, P)
