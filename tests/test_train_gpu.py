@@ -57,3 +57,30 @@ def test_training_run_matches_reference_checkpoint(tmp_path, reg):
     from chromoformer_amd import ChromoformerClassifier, ChromoformerRegressor
     m = (ChromoformerRegressor if reg else ChromoformerClassifier)()
     m.load_state_dict(c["net"])
+
+
+def test_an_edited_config_trains(tmp_path):
+    """configs/default.yaml:14-31 with other head counts / Regulation width (the shapes of tests/test_config_variants_gpu.py, checked there against the oracle)
+    through the training entrypoint: constructs, trains, validates, saves a checkpoint of the edited shapes that loads back."""
+    from chromoformer_amd import train, ChromoformerClassifier
+    meta = make_dataset(str(tmp_path / "npy"), n_genes=48, seed=2024)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "chromoformer_amd", "configs", "default.yaml")))
+    cfg["bsz"], cfg["num_epoch"] = 8, 2
+    cfg["embed"]["n_heads"] = 4
+    cfg["pairwise_interaction"]["n_heads"] = 1
+    cfg["regulation"].update(n_heads=4, d_model=128, n_layers=3)
+    cfg_path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    out = str(tmp_path / "ck.pt")
+    assert train.main(["-o", out, "-c", cfg_path, "--exp-id", "edited", "-m", meta, "-d", str(tmp_path / "npy"), "--fold", "0",
+                       "--binsizes", "2000", "500", "100"]) == 0
+    c = torch.load(out, map_location="cpu", weights_only=False)
+    net = c["net"]
+    assert net["regulation.2000.transformer.layers.0.self_att.att.weight"].shape == (512, 128)
+    assert net["regulation.2000.transformer.layers.0.self_att.gamma_f"].shape == (4,)
+    assert net["embed.100.transformer.layers.0.self_att.gamma_f"].shape == (4,)
+    assert "regulation.2000.transformer.layers.3.ff.l1.weight" not in net
+    assert np.isfinite(float(c["last_val_loss"])) and all(torch.isfinite(v).all() for v in net.values())
+    m = ChromoformerClassifier(cfg["n_feats"] if "n_feats" in cfg else 7, cfg["embed"]["d_model"], cfg.get("d_head", 128), cfg["embed"], cfg["pairwise_interaction"],
+                               cfg["regulation"], binsizes=[2000, 500, 100], i_max=cfg.get("i_max", 8), w_max=cfg.get("w_max", 40000))
+    m.load_state_dict(net)
