@@ -92,6 +92,9 @@ SYMBOLS = {
     "cf_head_rides": (C.c_int, [C.c_void_p]),
     "cf_kernel_flops": (C.c_double, [C.c_void_p, C.c_char_p, C.c_int]),
     "cf_cu_count": (C.c_int, [C.c_void_p]),
+    "cf_keep_tiled": (C.c_int, [C.c_void_p, C.c_int]),
+    "cf_params_changed": (C.c_int, [C.c_void_p]),
+    "cf_retile_early": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cf_capture_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cf_capture_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "cf_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

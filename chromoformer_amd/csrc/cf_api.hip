@@ -223,6 +223,9 @@ struct cf_handle {
     float* tiled = nullptr;              // tiled copy of the Linear weights (forward products), same offsets
     float* tiledT = nullptr;             // tiled copy of the transposed Regulation weights (backward products), same offsets
     bool reg8 = false;                   // Regulation stack on the 512-thread kernels of cf_reg8.h
+    bool keep_tiled_ok = false;          // (build_tables: the reduction tiles cover every tensor of that group)
+    bool keep_tiled = false;             // cf_keep_tiled: the fused optimiser keeps the Embedding + Pairwise tiled copies fresh, forward passes do not re-tile them
+    bool tiled_pe_fresh = false;         // ... and they ARE fresh (cleared by whatever else writes parameters: cf_bind, cf_params_changed, the separate AdamW launches)
     bool reg_team = false;               // ... its forward on teams of four 256-thread workgroups (cf_regq.h; CF_REG_TEAM=1)
     float* team_slots = nullptr;
     int* team_cnt = nullptr;
@@ -484,6 +487,7 @@ static void push_wg(std::vector<WgTile>& out, const WgJob& j) {
             t.Kk = j.Kk;
             t.n0 = n0;
             t.k0 = k0;
+            t.toff = -1;
             out.push_back(t);
         }
 }
@@ -707,6 +711,31 @@ static int build_tables(cf_handle* h) {
     h->n_lp = (int)lpj.size();
     HIP_TRY(hipMalloc(&h->lp_jobs, lpj.size() * sizeof(LpJob)));
     HIP_TRY(hipMemcpy(h->lp_jobs, lpj.data(), lpj.size() * sizeof(LpJob), hipMemcpyHostToDevice));
+    // Embedding + Pairwise tiles whose tensor has a tiled copy: where the tensor starts in the flat buffers and which of its rows the tile's row 0 is
+    // (AdamFuse::tiled: the optimiser epilogue writes the stepped elements into the tiled copy as well)
+    for (WgTile& t : wg) {
+        const long long e0 = t.C - h->grads;
+        for (const PDesc& p : h->table) {
+            if (e0 < p.offset || e0 >= p.offset + p.numel) continue;
+            const bool tiled_copy = p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable;
+            if (tiled_copy && t.ldc == p.shape[1] && (e0 - p.offset) % p.shape[1] == 0) {
+                t.toff = p.offset;
+                t.trow0 = (int)((e0 - p.offset) / p.shape[1]);
+            }
+            break;
+        }
+    }
+    {   // ... and every tensor the forward pass re-tiles up front must be covered completely, or the mode is not offered (cf_keep_tiled)
+        h->keep_tiled_ok = !h->embed_dense;
+        for (const PDesc& p : h->table) {
+            const bool is_late = p.name.rfind("regulation.", 0) == 0 || p.name.rfind("fc_head.", 0) == 0;
+            if (is_late || !(p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable)) continue;
+            long long covered = 0;
+            for (const WgTile& t : wg)
+                if (t.toff == p.offset) covered += (long long)std::min(64, t.Nn - t.n0) * std::min(kWgTk, t.Kk - t.k0);
+            if (covered != p.numel) h->keep_tiled_ok = false;
+        }
+    }
     h->n_wg_r = (int)wgR.size();
     h->n_cs_r = (int)csR.size();
     wg.insert(wg.begin(), wgR.begin(), wgR.end());      // table layout: [Regulation + head | Embedding + Pairwise]
@@ -929,6 +958,7 @@ extern "C" void cf_destroy(cf_handle* h) {
 static int build_trunk_table(cf_handle* h);      // (behind the centre-row parameter helpers below)
 extern "C" int cf_bind(cf_handle* h, float* params, float* grads, float* exp_avg, float* exp_avg_sq) {
     if (!h || !params) return fail("cf_bind: null handle / params");
+    h->tiled_pe_fresh = false;
     h->params = params;
     h->grads = grads;
     h->m = exp_avg;
@@ -1197,6 +1227,16 @@ static void head_fwd_args(const cf_handle* h, int B, float* logits_user, HeadFwd
 // forward
 // ------------------------------------------------------------------------------------
 static int gather_launch(const GatherArgs& ga, int n, hipStream_t st);      // (with the gather entry points below)
+// the tiled copies of the Embedding + Pairwise weights, now (cf_keep_tiled: whenever somebody other than the fused optimiser has written them)
+static int retile_early(cf_handle* h, hipStream_t st) {
+    if (h->n_retile_early > 0) {
+        hipLaunchKernelGGL(k_retile, dim3(h->n_retile_early), dim3(256), 0, st, (const float*)h->params, h->tiled, h->reg8 ? h->tiledT : (float*)nullptr,
+                           (const RetileUnit*)h->retile_units);
+        LAUNCH_CHECK("k_retile");
+    }
+    h->tiled_pe_fresh = true;
+    return 0;
+}
 static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int save, void* stream, const HeadRide* ride) {
     if (check_batch(h, bt)) return -1;
     hipStream_t st = (hipStream_t)stream;
@@ -1221,17 +1261,22 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             a.L[r] = c.n_bins[r];
         }
         a.F = F;
-        const int n_now = defer ? h->n_retile_early : h->n_retile;
+        // cf_keep_tiled: the Embedding + Pairwise units (the leading ones) are kept fresh by the optimiser epilogue; if something else has
+        // written parameters since (cf_params_changed, cf_bind, a separate AdamW launch) they are re-tiled here, once, in a launch of their own
+        if (h->keep_tiled && !h->tiled_pe_fresh && retile_early(h, st)) return -1;
+        const int u0 = h->keep_tiled ? h->n_retile_early : 0;
+        const int n_now = (defer ? h->n_retile_early : h->n_retile) - u0;
+        const RetileUnit* units = (const RetileUnit*)h->retile_units + u0;
         const bool with_gather = h->pend_gather && trunk && h->pend_ga.B == B;
         if (h->pend_gather && !with_gather && gather_launch(h->pend_ga, h->pend_ga_n, st)) return -1;      // (launches of their own, as cf_gather_batch)
         if (with_gather) {      // the step's batch gather in the same launch (cf_gather_batch_fwd); the trunk's forward launch advances the cursor
             hipLaunchKernelGGL(k_prologue_gather, dim3(n_now + B * h->pend_ga_n), dim3(256), 0, st, (const float*)h->params, h->tiled,
-                               h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, n_now, h->pend_ga);
+                               h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, h->pend_ga);
             LAUNCH_CHECK("k_prologue_gather");
-        } else {
+        } else if (n_now + (trunk ? 0 : B * nres) > 0) {      // (nothing to re-tile and nothing to gather: no launch)
             // (the fused trunk computes the Embedding input row itself: no x0 workgroups then)
             hipLaunchKernelGGL(k_fwd_prologue, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
-                               h->reg8 ? h->tiledT : (float*)nullptr, (const RetileUnit*)h->retile_units, n_now, a, B);
+                               h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
             LAUNCH_CHECK("k_fwd_prologue");
         }
         h->pend_gather = false;
@@ -2185,6 +2230,7 @@ extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float bet
     long long lo, n4;
     int grid;
     if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy) || adam_range(h, buckets, lo, n4, grid)) return -1;
+    if (buckets & CF_BUCKET_PE) h->tiled_pe_fresh = false;      // (this launch steps the parameters only, not their tiled copies)
     h->time_mark("k_adamw", (hipStream_t)stream);
     hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
                        h->v + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps);
@@ -2201,6 +2247,7 @@ extern "C" int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, flo
     if (B < 1 || B > h->cfg.max_batch) return fail("cf_reduce_adamw_part: bad batch size %d", B);
     if (reduce_buckets != CF_BUCKET_PE && reduce_buckets != CF_BUCKET_REG) return fail("cf_reduce_adamw_part: exactly one reduction bucket");
     if (adam_buckets & reduce_buckets) return fail("cf_reduce_adamw_part: the optimiser range overlaps the bucket under reduction");
+    if (adam_buckets & CF_BUCKET_PE) h->tiled_pe_fresh = false;
     AdamHyper hy;
     long long lo, n4;
     int agrid;
@@ -2247,10 +2294,14 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
         wn -= h->rider.done;
         h->rider.done = 0;
     }
-    AdamFuse o{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0};
+    // cf_keep_tiled: the Embedding + Pairwise bucket's tiles write the tiled copies of the weights they step (their next reader is the next
+    // forward pass, which then skips the re-tiling of those tensors)
+    AdamFuse o{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0,
+               h->keep_tiled && pe ? h->tiled : nullptr};
     hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
                        h->xcd_reduce_opt, o);
     LAUNCH_CHECK("k_reduce_opt");
+    if (pe) h->tiled_pe_fresh = h->keep_tiled;      // (every tensor of that bucket with a tiled copy has just been rewritten in both forms -- or in one only)
     h->n_bwd += (int)(g_launches - launches0);
     return 0;
 }
@@ -2265,7 +2316,7 @@ extern "C" int cf_rider_arm(cf_handle* h, float lr, float beta1, float beta2, fl
     if (h->rider.done) return fail("cf_rider_arm: the riders of step %lld have not been followed by cf_reduce_opt_part", h->rider.step);
     AdamHyper hy;
     if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy)) return -1;
-    h->rider.o = AdamFuse{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0};
+    h->rider.o = AdamFuse{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0, nullptr};
     h->rider.max_tiles = std::max(0, max_tiles);
     h->rider.step = step;
     h->rider.armed = max_tiles > 0;      // (max_tiles <= 0: disarms; the checks above tell a caller whether riders are available at all)
@@ -2286,6 +2337,7 @@ extern "C" int cf_adamw_step_dev(cf_handle* h, int buckets, void* stream) {
     long long lo, n4;
     int grid;
     if (adam_range(h, buckets, lo, n4, grid)) return -1;
+    if (buckets & CF_BUCKET_PE) h->tiled_pe_fresh = false;
     h->time_mark("k_adamw", (hipStream_t)stream);
     hipLaunchKernelGGL(k_adamw_dev, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
                        h->v + lo, n4, (const AdamHyper*)h->hyper);
@@ -2308,6 +2360,30 @@ extern "C" int cf_stream_wait(cf_handle* h, void* waiter, void* signaller) {
     HIP_TRY(hipEventRecord(e, (hipStream_t)signaller));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)waiter, e, 0));
     return 0;
+}
+// The fused optimiser (cf_reduce_opt_part over the Embedding + Pairwise bucket) can keep the tiled copies of that bucket's weights fresh: its
+// epilogue writes every stepped element in both layouts, and forward passes then skip the re-tiling of those tensors -- the launch in front
+// of a training step disappears (or carries only the batch gather).  The caller's side of the contract: whoever else writes parameters --
+// a checkpoint load, an in-place edit, another optimiser -- says so with cf_params_changed before the next forward pass (the Python layer
+// compares the version counter of its flat parameter tensor; the library's own separate AdamW launches and cf_bind clear the flag
+// themselves); the next forward pass then re-tiles once, in a launch of its own.  Not offered (-1) where the reduction tiles do not cover those
+// tensors (the all-rows Embedding path).
+extern "C" int cf_keep_tiled(cf_handle* h, int on) {
+    if (!h) return fail("null handle");
+    if (on && !h->keep_tiled_ok) return fail("cf_keep_tiled: not available for this configuration (gradient buffer not bound, or the all-rows Embedding path)");
+    h->keep_tiled = on != 0;
+    h->tiled_pe_fresh = false;
+    return 0;
+}
+extern "C" int cf_params_changed(cf_handle* h) {
+    if (!h) return fail("null handle");
+    h->tiled_pe_fresh = false;
+    return 0;
+}
+// the re-tiling a forward pass would do on finding the flag cleared, now (before a hipGraph that was captured without it is replayed)
+extern "C" int cf_retile_early(cf_handle* h, void* stream) {
+    if (!h || !h->params) return fail("cf_retile_early: no parameters bound");
+    return retile_early(h, (hipStream_t)stream);
 }
 extern "C" int cf_adamw_step(cf_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, long long step,
                              void* stream) {

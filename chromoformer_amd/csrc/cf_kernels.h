@@ -1701,6 +1701,8 @@ struct AdamFuse {
     const float* gbase;      // flat gradient buffer: a tile's output pointer minus this is the element's offset in all four
     float decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps;
     int keep_grads;          // also store the gradient (callers that read it back)
+    float* tiled;            // optional: the tiled weight copies (same flat offsets as p); tiles that carry a tensor offset (WgTile::toff >= 0) write
+                             // the updated elements there too, in fragment order -- the next forward pass then has nothing to re-tile (cf_keep_tiled)
 };
 __device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, const AdamFuse& o) {
 #pragma clang fp contract(off)      // every product and sum rounded on its own, wherever this is inlined: the stand-alone and the fused form agree bit for bit
@@ -1722,6 +1724,8 @@ struct WgTile {
     float* C;
     int ldc, Nn, Kk;
     int n0, k0;
+    long long toff;       // flat offset of the tensor C lies in when that tensor has a tiled copy kept fresh by the optimiser epilogue, else -1
+    int trow0, pad_;      // row of the tensor C's row 0 is
 };
 // four consecutive floats of a row, zero beyond `ncols`; 16-byte load when the address allows it
 __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col, int ncols, bool vec_ok) {
@@ -1899,6 +1903,10 @@ __device__ __forceinline__ void wgrad_tile_impl(const WgTile& t, int batch, cons
                     if (CF_OPT_NT) stg4_nt(o->m + off, mm[i]); else stg4(o->m + off, mm[i]);
                     if (CF_OPT_NT) stg4_nt(o->v + off, vv[i]); else stg4(o->v + off, vv[i]);
                     if (o->keep_grads) stg4(cp, g4);
+                    if (o->tiled && t.toff >= 0) {      // the same four elements in the tiled copy: block (row / 16, k / 16), lane slot (k % 16 / 4, row % 16)
+                        const int ra = t.trow0 + row, k = kc + 64 * h;
+                        stg4(o->tiled + t.toff + ((size_t)(ra >> 4) * (t.ldc >> 4) + (k >> 4)) * 256 + (((k & 15) >> 2) * 16 + (ra & 15)) * 4, pp[i]);
+                    }
                 } else {
                     stg4(cp, g4);
                 }

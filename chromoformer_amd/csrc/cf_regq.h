@@ -22,6 +22,9 @@
 #ifndef CF_TQ_PRE
 #define CF_TQ_PRE 3
 #endif
+#ifndef CF_TQ_SLEEP
+#define CF_TQ_SLEEP 2
+#endif
 namespace cf {
 
 constexpr int kTqLA = 64 + 4;                                   // row stride of the member's 64-column tiles
@@ -52,7 +55,7 @@ __device__ __forceinline__ void team_arrive(int* cnt) {
 }
 __device__ __forceinline__ void team_wait(int* cnt, int target) {
     if (threadIdx.x == 0)
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(CF_TQ_SLEEP);
     __syncthreads();
 }
 

@@ -179,7 +179,8 @@ class Trainer:
 
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
-                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None, rider_tiles=None):
+                 overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None, rider_tiles=None,
+                 keep_tiled=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -256,6 +257,13 @@ class Trainer:
         # riders fit on the CUs the trunk's n_res x B one-per-CU workgroups leave idle: sized from the device's CU count (256 on an
         # MI355X; a partition or another part has fewer / more), none when the trunk alone fills the device
         self._n_cu = int(self._L.cf_cu_count(model._handle)) or 256
+        # ... and the fused optimiser keeps the tiled copies of the Embedding + Pairwise weights fresh (its epilogue writes every stepped
+        # element in both layouts): no re-tiling launch in front of a step -- 6 -> 5 launches where no batch gather shares that launch.
+        # keep_tiled=False / CF_KEEP_TILED=0: every forward pass re-tiles (model.keep_tiled has the contract).
+        if keep_tiled is None:
+            import os
+            keep_tiled = os.environ.get("CF_KEEP_TILED", "1") != "0"
+        self.keep_tiled = model.keep_tiled(True) if (keep_tiled and self.fuse_opt) else (model.keep_tiled(False) and False)
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 
@@ -358,6 +366,7 @@ class Trainer:
     def _step(self, slot):
         m, L = self.model, self._L
         st = self._stream()
+        m._sync_tiled(st)          # (keep_tiled: parameters written through torch since the last step are re-tiled here, also in front of a graph replay)
         feed = getattr(slot, "feed", None)
         if feed is not None:
             if feed.taken >= feed.n_batches:           # the device-side bound would skip the gather; refuse on the host, loudly
@@ -468,6 +477,7 @@ class Trainer:
     def evaluate(self, slot):
         m = self.model
         with torch.cuda.stream(self.stream):
+            m._sync_tiled(self._stream())
             _lib.check(self._L.cf_forward(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), 0, self._stream()), "cf_forward")
         return slot.logits
 
@@ -488,6 +498,7 @@ class Trainer:
         # task: the gather would copy 4-byte labels out of an 8-byte column)
         with_labels = bool(getattr(store, "regression", m.n_out == 1)) == (m.n_out == 1)
         with torch.cuda.stream(self.stream):
+            m._sync_tiled(self._stream())
             order = torch.arange(n, dtype=torch.int32, device=m._device)
             n_full = n // bsz
             for B, lo, nb in ((bsz, 0, n_full), (n - n_full * bsz, n_full * bsz, 1)):

@@ -260,10 +260,41 @@ class ChromoformerBase(nn.Module):
                           d["interaction_masks"], d["interaction_freq"])
 
     # ----------------------------------------------------------------- forward / backward
+    # ----------------------------------------------------------------- tiled weight copies kept fresh by the fused optimiser (cf_keep_tiled)
+    def keep_tiled(self, on=True):
+        """The fused optimiser writes the tiled copies of the Embedding + Pairwise weights it steps, forward passes stop re-tiling them
+        (Trainer: no launch in front of a training step).  Whatever else writes parameters THROUGH TORCH -- load_state_dict, an optimiser,
+        an in-place op on a parameter -- is noticed by the version counters (_sync_tiled, in front of every forward pass); an edit through
+        `.data` or a raw pointer is not: call params_changed() after it.  Returns whether the library offers the mode for this model."""
+        ok = _lib.lib().cf_keep_tiled(self._handle, 1 if on else 0) == 0
+        self._keep_tiled = bool(on) and ok
+        self._pver = None
+        return self._keep_tiled
+
+    def params_changed(self):
+        if self._handle is not None:
+            _lib.check(_lib.lib().cf_params_changed(self._handle), "cf_params_changed")
+        self._pver = None
+
+    def _sync_tiled(self, st):
+        """In front of every forward pass of a model in keep_tiled mode: have parameters been written through torch since the library last
+        saw them?  (sum of the version counters of the ~370 parameters: ~20 us of host time.)  If so the tiled copies are rebuilt at once, on
+        the stream the pass will run on -- also in front of a hipGraph that was captured without the re-tiling."""
+        if not getattr(self, "_keep_tiled", False):
+            return
+        if getattr(self, "_plist", None) is None:
+            self._plist = [p for _, p in self.named_parameters()]
+        ver = sum(p._version for p in self._plist)
+        if ver != self._pver:
+            _lib.check(_lib.lib().cf_params_changed(self._handle), "cf_params_changed")
+            _lib.check(_lib.lib().cf_retile_early(self._handle, st), "cf_retile_early")
+            self._pver = ver
+
     def _run_forward(self, bs, save):
         """save: False / 0 = inference, True / 1 = keep activations, 2 = as 1 with the head left to the cf_backward that follows."""
         out = torch.empty(bs.B, self.n_out, device=self._device)
         st = torch.cuda.current_stream(self._device).cuda_stream
+        self._sync_tiled(st)
         _lib.check(_lib.lib().cf_forward(self._handle, C.byref(bs), out.data_ptr(), int(save), st), "cf_forward")
         return out
 
@@ -310,6 +341,7 @@ class ChromoformerBase(nn.Module):
         # head forward + loss + head backward at the tail of the Regulation forward launch where the library can (cf_forward_train),
         # else as one launch inside the cf_backward below; logits / loss are filled by whichever runs
         logits = torch.empty(bs.B, self.n_out, device=self._device)
+        self._sync_tiled(st)
         _lib.check(_lib.lib().cf_forward_train(self._handle, C.byref(bs), logits.data_ptr(), labels.data_ptr(), float(loss_scale),
                                                self._loss_buf.data_ptr(), st), "cf_forward_train")
         _lib.check(_lib.lib().cf_backward(self._handle, C.byref(bs), labels.data_ptr(), float(loss_scale),

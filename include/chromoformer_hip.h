@@ -387,6 +387,16 @@ int cf_op_attention_bwd(const cf_attn_shape* shape, const float* q, const float*
                         const float* o, const float* stats, const float* d_o, float* dq, float* dk, float* dv,
                         float* delta_ws, void* stream);
 
+/* Round 4.  The fused optimiser (cf_reduce_opt_part over CF_BUCKET_PE) keeps the tiled copies of the Embedding + Pairwise weights fresh:
+ * its epilogue writes every stepped element in both layouts and forward passes skip the re-tiling of those tensors (no launch in front of
+ * a training step, or one that only gathers the batch).  Contract: whoever else writes parameters calls cf_params_changed before the next
+ * forward pass, which then re-tiles once (cf_retile_early does it at once, e.g. before replaying a hipGraph captured without it).  cf_bind
+ * and the library's separate AdamW launches clear the flag themselves.  cf_keep_tiled(h, 1) returns -1 where the reduction tiles do not
+ * cover those tensors (embed n_layers > 1, no gradient buffer bound).  No reference counterpart (train.py:194 steps torch parameters). */
+int cf_keep_tiled(cf_handle* h, int on);
+int cf_params_changed(cf_handle* h);
+int cf_retile_early(cf_handle* h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,3 +152,55 @@ def test_riders_must_be_followed_by_the_fused_reduction_of_the_same_step():
     torch.cuda.synchronize()
     sd = model.state_dict()
     assert all(torch.isfinite(v).all() for v in sd.values())
+
+
+def test_tiled_copies_kept_by_the_optimiser_survive_outside_writes():
+    """Trainer(keep_tiled=True), the default: the fused optimiser writes the tiled copies of the Embedding + Pairwise weights and forward passes stop
+    re-tiling them (one launch less per step).  Parameters written through torch between two steps (an in-place op, load_state_dict) are noticed
+    by the version counters; an edit through `.data` needs model.params_changed().  Same bits as a trainer that re-tiles in every forward pass."""
+    import ctypes as C
+    from chromoformer_amd import ChromoformerClassifier, _lib
+    from chromoformer_amd.engine import Trainer
+
+    def run(keep, graph):
+        model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+        tr = Trainer(model, lr=1e-3, keep_tiled=keep, use_graph=graph)
+        assert tr.keep_tiled == keep
+        slots = [tr.stage(orc.synthetic_batch(B, seed=7 + i, regime="realistic")) for i in range(2)]
+        named = dict(model.named_parameters())
+        losses, counts = [], []
+        for i in range(7):
+            torch.cuda.synchronize()      # (the edits below run on torch's default stream, the steps on the trainer's)
+            if i == 2:      # an in-place op on an Embedding and on a Pairwise weight
+                with torch.no_grad():
+                    named["embed.100.transformer.layers.0.self_att.att.weight"].mul_(1.25)
+                    named["pairwise_interaction.500.transformer.layers.1.ff.l1.weight"].add_(0.01)
+            if i == 4:      # a checkpoint load
+                sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+                sd["pairwise_interaction.2000.lin_proj_p.weight"] = sd["pairwise_interaction.2000.lin_proj_p.weight"] * 0.5
+                model.load_state_dict(sd)
+            if i == 5:      # behind torch's back: the caller has to say so
+                named["embed.2000.transformer.layers.0.ff.l2.weight"].data.mul_(0.9)
+                model.params_changed()
+            torch.cuda.synchronize()
+            _, loss = tr.step(slots[i % 2])
+            with torch.cuda.stream(tr.stream):
+                losses.append(loss.clone())
+            nf, nb, no = C.c_int(), C.c_int(), C.c_int()
+            _lib.check(_lib.lib().cf_launch_counts(model._handle, C.byref(nf), C.byref(nb), C.byref(no)), "cf_launch_counts")
+            counts.append(nf.value)
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        logits = tr.evaluate(slots[0])
+        tr.stream.synchronize()      # (evaluate runs on the trainer's stream)
+        return sd, [float(x) for x in losses], counts, logits.cpu().clone()
+
+    ref, ref_loss, ref_counts, ref_logits = run(False, False)
+    for graph in (False, True):
+        got, loss, counts, logits = run(True, graph)
+        assert loss == ref_loss, (graph, loss, ref_loss)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (graph, k)
+        assert torch.equal(logits, ref_logits)
+        if not graph:      # forward launches of an eager step: prologue + trunk + Regulation against trunk + Regulation
+            assert ref_counts[1] == counts[1] + 1, (ref_counts, counts)
