@@ -102,8 +102,9 @@ def train_loop_rate(model, lr, steps, store_genes, regime, dev):
     el = time.perf_counter() - t0
     return {"value": round(BSZ * done / el, 1), "unit": "genes/s", "ms_per_step": round(1e3 * el / done, 4), "steps": done,
             "store_genes": store_genes, "host_calls_per_step": ((4 if trainer.rider_tiles else 2) if trainer.fuse_one else 4) if trainer.fuse_opt else 3,
-            "what": "chromoformer_amd.train.train_epoch over a resident synthetic split: batch gather (in the forward prologue launch) + cf_record_step inside "
-                    "the step graph, running metrics (train.py:205-232) on every 10-step window"}
+            "what": "chromoformer_amd.train.train_epoch over a resident synthetic split: the batch of step k + 1 gathered behind the tiles of step k's "
+                    "reduction launch (cf_gather_batch_next; the first batch of an epoch by a launch of its own), the step log written by the trunk's backward "
+                    "launch (cf_record_step_bwd), running metrics (train.py:205-232) on every 10-step window"}
 
 
 def val_auroc_run(n_genes=256, epochs=3):

@@ -119,6 +119,8 @@ SYMBOLS = {
     "cf_embed_full": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.POINTER(C.c_void_p), C.c_void_p]),
     "cf_gather_batch": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
     "cf_gather_batch_fwd": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
+    "cf_gather_batch_next": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
+    "cf_gather_batch_only": (C.c_int, [C.c_void_p, C.POINTER(cf_store), C.c_void_p, C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_void_p]),
     "cf_record_step_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_record_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cf_op_dense_layer_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),

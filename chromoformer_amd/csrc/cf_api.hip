@@ -253,6 +253,10 @@ struct cf_handle {
     bool head_loss_due = false;                // ... and the mean loss is still to be summed (by the Regulation backward launch)
     bool pend_record = false;                  // cf_record_step_bwd: the step log rides in the trunk's backward launch
     RecordArgs pend_rec;
+    bool pend_gnext = false;                   // cf_gather_batch_next: the NEXT step's gather rides in this step's reduction launch (cf_reduce_opt_part)
+    GatherArgs pend_gn;
+    int pend_gn_n = 0;
+    int* adv_next = nullptr;                   // a batch gathered without advancing the cursor: the next forward pass advances it (trunk launch)
     bool pend_gather = false;                  // cf_gather_batch_fwd: the gather of the step shares a launch with the next forward's prologue
     GatherArgs pend_ga;
     int pend_ga_n = 0;
@@ -1264,6 +1268,12 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         // cf_keep_tiled: the Embedding + Pairwise units (the leading ones) are kept fresh by the optimiser epilogue; if something else has
         // written parameters since (cf_params_changed, cf_bind, a separate AdamW launch) they are re-tiled here, once, in a launch of their own
         if (h->keep_tiled && !h->tiled_pe_fresh && retile_early(h, st)) return -1;
+        if (h->pend_gnext) {      // (a cf_gather_batch_next that found no reduction launch to ride in: a launch of its own, here)
+            hipLaunchKernelGGL(k_gather_batch, dim3(h->pend_gn.B, h->pend_gn_n), dim3(256), 0, st, h->pend_gn);
+            LAUNCH_CHECK("k_gather_batch");
+            h->adv_next = h->pend_gn.cursor;
+            h->pend_gnext = false;
+        }
         const int u0 = h->keep_tiled ? h->n_retile_early : 0;
         const int n_now = (defer ? h->n_retile_early : h->n_retile) - u0;
         const RetileUnit* units = (const RetileUnit*)h->retile_units + u0;
@@ -1281,6 +1291,14 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         }
         h->pend_gather = false;
         if (with_gather) adv_cursor = h->pend_ga.cursor;
+        else if (h->adv_next) {      // the batch is in place already (cf_gather_batch_only / cf_gather_batch_next): only the cursor moves on
+            if (trunk) adv_cursor = h->adv_next;
+            else {
+                hipLaunchKernelGGL(k_gather_advance, dim3(1), dim3(1), 0, st, h->adv_next);
+                LAUNCH_CHECK("k_gather_advance");
+            }
+        }
+        h->adv_next = nullptr;
     }
     if (trunk) {
         TrunkArgs ta;
@@ -2121,7 +2139,10 @@ extern "C" int cf_graph_launch(cf_handle* h, int graph_id, void* stream) {
     if (!h || graph_id < 0 || graph_id >= (int)h->replays.size()) return fail("cf_graph_launch: bad graph id %d", graph_id);
     cf_handle::Replay& rp = h->replays[graph_id];
     hipStream_t st = (hipStream_t)stream;
-    if (rp.n_fwd >= 0) h->n_fwd = rp.n_fwd;
+    if (rp.n_fwd >= 0) {
+        h->n_fwd = rp.n_fwd;
+        h->adv_next = nullptr;      // (a replayed forward pass moves the cursor on by itself if it was captured that way)
+    }
     if (rp.starts_bwd) h->n_bwd = h->n_opt = 0;
     h->n_bwd += rp.n_bwd;
     HIP_TRY(hipGraphLaunch(rp.first, st));
@@ -2298,8 +2319,15 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
     // forward pass, which then skips the re-tiling of those tensors)
     AdamFuse o{h->params, h->m, h->v, h->grads, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, keep_grads ? 1 : 0,
                h->keep_tiled && pe ? h->tiled : nullptr};
-    hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
-                       h->xcd_reduce_opt, o);
+    if (h->pend_gnext) {      // the next step's batch gather behind the tiles of this launch (cf_gather_batch_next)
+        hipLaunchKernelGGL(k_reduce_opt_gather, dim3(xcd_grid(wn) + cn + h->pend_gn.B * h->pend_gn_n), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn,
+                           (const CsTile*)h->cs_tiles + c0, cn, B, h->xcd_reduce_opt, o, h->pend_gn);
+        h->adv_next = h->pend_gn.cursor;
+        h->pend_gnext = false;
+    } else {
+        hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
+                           h->xcd_reduce_opt, o);
+    }
     LAUNCH_CHECK("k_reduce_opt");
     if (pe) h->tiled_pe_fresh = h->keep_tiled;      // (every tensor of that bucket with a tiled copy has just been rewritten in both forms -- or in one only)
     h->n_bwd += (int)(g_launches - launches0);
@@ -2475,6 +2503,31 @@ extern "C" int cf_gather_batch_fwd(cf_handle* h, const cf_store* st_, const int*
     if (gather_args(h, st_, order, cursor, dst, labels_dst, h->pend_ga, n)) return -1;
     h->pend_ga_n = n;
     h->pend_gather = true;
+    return 0;
+}
+
+// The batch of the NEXT step, gathered while this step ends: nothing is launched here; the cf_reduce_opt_part that follows on the same stream
+// carries the copy blocks behind its tiles (nothing in that launch reads the batch buffers, and every kernel of this step that does has
+// finished), and the cursor -- which the gather reads, so it cannot move in the same launch -- is advanced by the trunk's forward launch
+// of the next cf_forward / cf_forward_train.  A step of the training loop then has no launch in front of it.  cf_gather_batch_only is the
+// same for the first step of an epoch: the copy as a launch of its own, now, the cursor left to the forward pass that follows.
+extern "C" int cf_gather_batch_next(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst,
+                                    void* stream) {
+    (void)stream;
+    int n;
+    if (gather_args(h, st_, order, cursor, dst, labels_dst, h->pend_gn, n)) return -1;
+    h->pend_gn_n = n;
+    h->pend_gnext = true;
+    return 0;
+}
+extern "C" int cf_gather_batch_only(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst,
+                                    void* stream) {
+    GatherArgs ga;
+    int n;
+    if (gather_args(h, st_, order, cursor, dst, labels_dst, ga, n)) return -1;
+    hipLaunchKernelGGL(k_gather_batch, dim3(ga.B, n), dim3(256), 0, (hipStream_t)stream, ga);
+    LAUNCH_CHECK("k_gather_batch");
+    h->adv_next = cursor;
     return 0;
 }
 

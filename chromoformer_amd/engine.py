@@ -110,6 +110,7 @@ class EpochFeed:
         self.cursor = torch.zeros(4, dtype=torch.int32, device=dev)          # [next batch, batches uploaded, error flags, reserved]
         self._cursor_host = torch.zeros(4, dtype=torch.int32).pin_memory()
         self.taken = 0                                                        # steps issued since begin_epoch (host-side guard)
+        self.pregathered = False                                              # the next step's batch is in the slot already (Trainer._pregather)
         # the step logs live in pinned HOST memory (device-addressable): cf_record_step writes a KB per step straight into
         # it, the loop reads it once an event says the window is complete -- no device-to-host copy, which would queue
         # behind the replayed graphs (1.6 ms per copy on a busy GPU)
@@ -139,6 +140,7 @@ class EpochFeed:
                 self.order[:n].copy_(self._order_host[:n], non_blocking=True)
             self.cursor.copy_(self._cursor_host, non_blocking=True)
         self.n_batches, self.taken = len(batches), 0
+        self.pregathered = False
         if flags:
             raise RuntimeError("EpochFeed: the previous epoch set error flags %d on the device (1: a step past the epoch, "
                                "2: a gene index outside the store)" % flags)
@@ -156,6 +158,7 @@ class EpochFeed:
         """Back to the first batch of the uploaded epoch (the eager validation pass before a capture consumed one)."""
         self.cursor[0] = 0                                 # (on the current stream: the caller synchronises before capturing)
         self.taken = 0
+        self.pregathered = False
 
     def window(self, lo, hi):
         """(logits [n, n_out], labels [n], losses [hi - lo]) of steps lo .. hi - 1 of the epoch, on the host (the caller has
@@ -291,9 +294,9 @@ class Trainer:
     def _reduce(self, slot, st, buckets):
         _lib.check(self._L.cf_backward_reduce_part(self.model._handle, slot.B, buckets, st), "cf_backward_reduce_part")
 
-    def _seq_early(self, slot, st, reduce=True):     # [batch gather,] forward, loss, head + Regulation backward, [step log,] Regulation + head gradient bucket
+    def _seq_early(self, slot, st, reduce=True, gather=True):     # [batch gather,] forward, loss, head + Regulation backward, [step log,] Regulation + head gradient bucket
         m, L = self.model, self._L
-        feed = getattr(slot, "feed", None)
+        feed = getattr(slot, "feed", None) if gather else None      # (gather=False: the batch is in place already, see _pregather)
         if feed is not None:
             # (shares a launch with the prologue of the forward below: cf_gather_batch_fwd)
             _lib.check(L.cf_gather_batch_fwd(m._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(),
@@ -371,6 +374,12 @@ class Trainer:
         if feed is not None:
             if feed.taken >= feed.n_batches:           # the device-side bound would skip the gather; refuse on the host, loudly
                 raise RuntimeError("Trainer.step: the feed's epoch of %d batches is exhausted (call begin_epoch)" % feed.n_batches)
+        # Fused single-GPU step fed from an EpochFeed: the batch of step k + 1 is gathered inside step k's last launch (cf_gather_batch_next,
+        # behind the reduction tiles), the first batch of an epoch by a launch of its own (cf_gather_batch_only): no launch in front of a step.
+        pre = feed is not None and self.fuse_opt and self.fuse_one
+        gargs = None
+        if pre:
+            gargs = (m._handle, C.byref(feed.struct), feed.order.data_ptr(), feed.cursor.data_ptr(), C.byref(slot.struct), slot.label.data_ptr(), st)
         if self.use_graph and slot.graph is None:
             self._seq_all(slot, st, opt=False)         # eager once (validates the arguments before anything is captured)
             if getattr(slot, "feed", None) is not None:
@@ -378,9 +387,12 @@ class Trainer:
             torch.cuda.synchronize()
             first = self._seq_early if self.dp else (self._seq_main if self.merge_opt else (lambda s_, t_: self._seq_all(s_, t_, opt=self.opt_in_graph)))
             if self.fuse_opt and self.fuse_one and self.rider_tiles == 0:
-                first = lambda s_, t_: (self._seq_early(s_, t_, reduce=False), self._part(s_, t_, 4))
+                first = lambda s_, t_: (self._seq_early(s_, t_, reduce=False, gather=not pre), self._part(s_, t_, 4))
             elif self.fuse_opt:
-                first = lambda s_, t_: self._seq_early(s_, t_, reduce=False)
+                first = lambda s_, t_: self._seq_early(s_, t_, reduce=False, gather=not pre)
+            if pre:      # (the captured trunk launch advances the cursor because a gathered batch is waiting at capture time)
+                _lib.check(L.cf_gather_batch_only(*gargs), "cf_gather_batch_only")
+                feed.pregathered = True
             slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
         if feed is not None:
             feed.taken += 1
@@ -389,10 +401,16 @@ class Trainer:
             m._step += 1
             _lib.check(L.cf_adamw_set(m._handle, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step, st), "cf_adamw_set")
         if self.fuse_opt:
+            if pre and not feed.pregathered:           # first step of an epoch
+                _lib.check(L.cf_gather_batch_only(*gargs), "cf_gather_batch_only")
             if self.use_graph:
                 self._launch(slot.graph["first"], st)
             else:
-                self._seq_early(slot, st, reduce=False)
+                self._seq_early(slot, st, reduce=False, gather=not pre)
+            if pre:                                    # the next step's batch rides in this step's reduction launch
+                feed.pregathered = feed.taken < feed.n_batches
+                if feed.pregathered:
+                    _lib.check(L.cf_gather_batch_next(*gargs), "cf_gather_batch_next")
             m._step += 1
             hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
             kg = 1 if self.keep_grads else 0

@@ -393,6 +393,11 @@ int cf_op_attention_bwd(const cf_attn_shape* shape, const float* q, const float*
  * forward pass, which then re-tiles once (cf_retile_early does it at once, e.g. before replaying a hipGraph captured without it).  cf_bind
  * and the library's separate AdamW launches clear the flag themselves.  cf_keep_tiled(h, 1) returns -1 where the reduction tiles do not
  * cover those tensors (embed n_layers > 1, no gradient buffer bound).  No reference counterpart (train.py:194 steps torch parameters). */
+/* cf_gather_batch for a training loop without a launch in front of a step: cf_gather_batch_next stores its arguments and the cf_reduce_opt_part
+ * that follows carries the copy of the NEXT step's batch behind its tiles; cf_gather_batch_only copies now (the first step of an epoch).  In
+ * both cases the cursor is advanced by the forward pass that follows (its trunk launch).  Replaces train.py:137-140, 171-177 as cf_gather_batch does. */
+int cf_gather_batch_next(cf_handle* h, const cf_store* store, const int* order, int* cursor, const cf_batch* dst, void* labels_dst, void* stream);
+int cf_gather_batch_only(cf_handle* h, const cf_store* store, const int* order, int* cursor, const cf_batch* dst, void* labels_dst, void* stream);
 int cf_keep_tiled(cf_handle* h, int on);
 int cf_params_changed(cf_handle* h);
 int cf_retile_early(cf_handle* h, void* stream);
