@@ -893,8 +893,8 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             if (e1 != hipSuccess || e2 != hipSuccess) h->reg_fused = false;
         }
         if (!h->reg_fused) h->reg8 = false;
-        // the team forward (cf_regq.h): default Regulation shape with d_ff = 256, and a device on which workgroup i of a launch runs on
-        // XCD i mod 8 -- the four members of a team then share an L2, which is what makes their plain-store / sc1-load exchange coherent
+        // the team forward (cf_regq.h): default Regulation shape with d_ff = 256, and a device on which the workgroups of a launch go round-robin
+        // over the 8 XCDs -- the four members of a team, 8 ids apart, then share an L2, which is what makes their plain-store / sc1-load exchange coherent
         if (h->reg8 && c.reg_dff == 256 && getenv_int("CF_REG_TEAM", 0) != 0) {
             unsigned* probe = nullptr;
             unsigned host[64];
@@ -902,7 +902,8 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             if (ok) {
                 hipLaunchKernelGGL(k_xcc_probe, dim3(64), dim3(64), 0, 0, probe);
                 ok = hipMemcpy(host, probe, sizeof host, hipMemcpyDeviceToHost) == hipSuccess;
-                for (int i = 0; ok && i < 64; ++i) ok = host[i] == (unsigned)(i & 7);
+                // (round-robin from wherever the dispatcher stands: what a team needs is that ids 8 apart share an XCD)
+                for (int i = 0; ok && i < 64; ++i) ok = host[i] == ((host[0] + (unsigned)i) & 7);
                 (void)hipFree(probe);
             }
             h->reg_team = ok;
