@@ -223,6 +223,7 @@ struct cf_handle {
     float* tiled = nullptr;              // tiled copy of the Linear weights (forward products), same offsets
     float* tiledT = nullptr;             // tiled copy of the transposed Regulation weights (backward products), same offsets
     bool reg8 = false;                   // Regulation stack on the 512-thread kernels of cf_reg8.h
+    bool reg_row0 = true;                // ... whose last layer computes only what token 0 of its output needs (CF_REG_ROW0=0: all rows, the cross-check)
     bool keep_tiled_ok = false;          // (build_tables: the reduction tiles cover every tensor of that group)
     bool keep_tiled = false;             // cf_keep_tiled: the fused optimiser keeps the Embedding + Pairwise tiled copies fresh, forward passes do not re-tile them
     bool tiled_pe_fresh = false;         // ... and they ARE fresh (cleared by whatever else writes parameters: cf_bind, cf_params_changed, the separate AdamW launches)
@@ -258,6 +259,8 @@ struct cf_handle {
     int pend_gn_n = 0;
     int* adv_next = nullptr;                   // a batch gathered without advancing the cursor: the next forward pass advances it (trunk launch)
     bool pend_gather = false;                  // cf_gather_batch_fwd: the gather of the step shares a launch with the next forward's prologue
+    const void* pend_key = nullptr;            // the batch (its first feature array) the pending gather / cursor advance above belongs to: a forward
+                                               // pass over ANOTHER batch (validation between two steps of a fed epoch) must not consume them
     GatherArgs pend_ga;
     int pend_ga_n = 0;
     bool head_ride = true;                     // CF_HEAD_RIDE=0 (read at cf_create): the head stays a launch of its own (k_head_train)
@@ -882,6 +885,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         const int T = c.i_max + 1;
         h->reg8 = T <= kTile;                  // 512-thread kernels (cf_reg8.h); CF_REG8=0 selects the 256-thread ones (A/B runs)
         if (const char* e = getenv("CF_REG8")) h->reg8 = h->reg8 && atoi(e) != 0;
+        h->reg_row0 = getenv_int("CF_REG_ROW0", 1) != 0;
         const size_t need = h->reg8 ? std::max(reg8_fwd_smem(c.reg_dff), reg8_bwd_smem(c.reg_dff)) : std::max(reg_fwd_smem(T), reg_bwd_smem(T));
         h->reg_fused = T <= kTile && need <= 160 * 1024 && c.reg_heads == kRH && c.reg_dmodel == kRDm;
         if (h->reg_fused) {
@@ -1275,11 +1279,16 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             h->adv_next = h->pend_gn.cursor;
             h->pend_gnext = false;
         }
+        // The pre-gathered feed's pending state belongs to ONE batch: only the forward pass over that batch takes the gather into its
+        // launch / moves the cursor on.  A pass over another batch (Trainer.evaluate_store or model(...) between two steps of a fed epoch)
+        // leaves it for the step it was queued for -- consumed here it advanced the cursor a second time under graph replay (the
+        // captured trunk launch advances it by itself) and the epoch silently skipped a batch.
+        const bool mine = !h->pend_key || h->pend_key == (const void*)bt->promoter_feats[0];
         const int u0 = h->keep_tiled ? h->n_retile_early : 0;
         const int n_now = (defer ? h->n_retile_early : h->n_retile) - u0;
         const RetileUnit* units = (const RetileUnit*)h->retile_units + u0;
-        const bool with_gather = h->pend_gather && trunk && h->pend_ga.B == B;
-        if (h->pend_gather && !with_gather && gather_launch(h->pend_ga, h->pend_ga_n, st)) return -1;      // (launches of their own, as cf_gather_batch)
+        const bool with_gather = mine && h->pend_gather && trunk && h->pend_ga.B == B;
+        if (mine && h->pend_gather && !with_gather && gather_launch(h->pend_ga, h->pend_ga_n, st)) return -1;      // (launches of their own, as cf_gather_batch)
         if (with_gather) {      // the step's batch gather in the same launch (cf_gather_batch_fwd); the trunk's forward launch advances the cursor
             hipLaunchKernelGGL(k_prologue_gather, dim3(n_now + B * h->pend_ga_n), dim3(256), 0, st, (const float*)h->params, h->tiled,
                                h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, h->pend_ga);
@@ -1290,16 +1299,19 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
                                h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
             LAUNCH_CHECK("k_fwd_prologue");
         }
-        h->pend_gather = false;
+        if (mine) h->pend_gather = false;
         if (with_gather) adv_cursor = h->pend_ga.cursor;
-        else if (h->adv_next) {      // the batch is in place already (cf_gather_batch_only / cf_gather_batch_next): only the cursor moves on
+        else if (mine && h->adv_next) {      // the batch is in place already (cf_gather_batch_only / cf_gather_batch_next): only the cursor moves on
             if (trunk) adv_cursor = h->adv_next;
             else {
                 hipLaunchKernelGGL(k_gather_advance, dim3(1), dim3(1), 0, st, h->adv_next);
                 LAUNCH_CHECK("k_gather_advance");
             }
         }
-        h->adv_next = nullptr;
+        if (mine) {
+            h->adv_next = nullptr;
+            h->pend_key = nullptr;
+        }
     }
     if (trunk) {
         TrunkArgs ta;
@@ -1534,6 +1546,7 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         if (ride) ra.head = *ride;
         ra.team_slots = h->team_slots;
         ra.team_cnt = h->team_cnt;
+        ra.row0_last = h->reg_row0 ? 1 : 0;
         if (h->reg_team) {      // four 256-thread workgroups per (gene, resolution), 8 workgroup ids apart (cf_regq.h)
             const void* fn = save != 0 ? (const void*)k_regq_fwd<true> : (const void*)k_regq_fwd<false>;
             if (launch_reg(h, "k_reg_fwd", fn, dim3(32 * ((B * nres + 7) / 8)), regq_fwd_smem(), ra, st, 256)) return -1;
@@ -1742,6 +1755,9 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             if (loss_out) ra.head.loss_user = loss_out;
             h->head_loss_due = false;
         }
+        ra.team_slots = nullptr;
+        ra.team_cnt = nullptr;
+        ra.row0_last = h->reg_row0 ? 1 : 0;
         if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T, h->reg8), dim3(8 * ((B * nres + 7) / 8)),
                        h->reg8 ? reg8_bwd_smem(c.reg_dff) : reg_bwd_smem(T), ra, st))
             return -1;
@@ -2143,6 +2159,7 @@ extern "C" int cf_graph_launch(cf_handle* h, int graph_id, void* stream) {
     if (rp.n_fwd >= 0) {
         h->n_fwd = rp.n_fwd;
         h->adv_next = nullptr;      // (a replayed forward pass moves the cursor on by itself if it was captured that way)
+        h->pend_key = nullptr;
     }
     if (rp.starts_bwd) h->n_bwd = h->n_opt = 0;
     h->n_bwd += rp.n_bwd;
@@ -2193,8 +2210,15 @@ extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
     const double RDm = c.reg_dmodel;
     const double lin_fwd = 2.0 * T * (kD * 4.0 * RDm + RDm * (double)kD + kD * dff + dff * kD);        // q|k|v|g, out-proj, FFN
     const double att_fwd = 2.0 * T * T * RDm * 2.0;                                                    // q k^T and p v
-    if (k == "k_reg_fwd") return (lin_fwd + att_fwd) * c.reg_layers * c.n_res * B;
-    if (k == "k_reg_bwd") return (lin_fwd + 2.0 * T * T * RDm * 5.0) * c.reg_layers * c.n_res * B;     // dX products + p v, dp, dq, dk, dv
+    // With the last layer reduced to what token 0 of its output needs (cf_reg8.h, b_run_row0) that layer's algorithmic work is smaller and is
+    // counted as such: keys / values (forward) and the k, v quarters of the input-gradient product (backward) over all T rows, everything else
+    // -- q, gate, out-projection, FFN, the attention products -- for ONE row.
+    const bool row0 = h->reg_fused && h->reg8 && !h->reg_team && h->reg_row0;
+    const double full_layers = c.reg_layers - (row0 ? 1 : 0);
+    const double lin_last = 2.0 * (T * kD * 2.0 * RDm + kD * 2.0 * RDm + RDm * (double)kD + kD * dff + dff * kD);
+    if (k == "k_reg_fwd") return ((lin_fwd + att_fwd) * full_layers + (row0 ? lin_last + 2.0 * T * RDm * 2.0 : 0.0)) * c.n_res * B;
+    if (k == "k_reg_bwd")                                                                              // dX products + p v, dp, dq, dk, dv
+        return ((lin_fwd + 2.0 * T * T * RDm * 5.0) * full_layers + (row0 ? lin_last + 2.0 * T * RDm * 5.0 : 0.0)) * c.n_res * B;
     if (k == "k_trunk_fwd" || k == "k_trunk_bwd") {
         // The centre-row trunk of one (gene, resolution): ONE Embedding row and S = i_max Pairwise rows per layer.  Per row and layer the
         // 128-wide products q = x Wq^T, qt[h] = q[h] Wk[h], a[h] = xbar[h] Wv[h]^T, a Wo^T (4 x 128 x 128 MACs), the FFN (2 x 128 x d_ff) and the
@@ -2504,6 +2528,7 @@ extern "C" int cf_gather_batch_fwd(cf_handle* h, const cf_store* st_, const int*
     if (gather_args(h, st_, order, cursor, dst, labels_dst, h->pend_ga, n)) return -1;
     h->pend_ga_n = n;
     h->pend_gather = true;
+    h->pend_key = dst->promoter_feats[0];
     return 0;
 }
 
@@ -2519,6 +2544,7 @@ extern "C" int cf_gather_batch_next(cf_handle* h, const cf_store* st_, const int
     if (gather_args(h, st_, order, cursor, dst, labels_dst, h->pend_gn, n)) return -1;
     h->pend_gn_n = n;
     h->pend_gnext = true;
+    h->pend_key = dst->promoter_feats[0];
     return 0;
 }
 extern "C" int cf_gather_batch_only(cf_handle* h, const cf_store* st_, const int* order, int* cursor, const cf_batch* dst, void* labels_dst,
@@ -2529,6 +2555,7 @@ extern "C" int cf_gather_batch_only(cf_handle* h, const cf_store* st_, const int
     hipLaunchKernelGGL(k_gather_batch, dim3(ga.B, n), dim3(256), 0, (hipStream_t)stream, ga);
     LAUNCH_CHECK("k_gather_batch");
     h->adv_next = cursor;
+    h->pend_key = dst->promoter_feats[0];
     return 0;
 }
 

@@ -194,6 +194,79 @@ __device__ __forceinline__ void b_run(BBuf<NU, R>& b, const float* base, unsigne
     }
 }
 
+// ---- The LAST layer (RegArgs::row0_last).  The head reads token 0 of the stack's output and nothing else (net.py:375-376), so in the
+// last layer only the keys and values need all T rows: its query, gate, out-projection, FFN and both LayerNorms are needed for row 0
+// alone, and in the backward pass every gradient above the attention has one live row.  A 16-row MFMA tile costs the same for one row
+// as for sixteen; on the vector ALUs a one-row product is 4 FMAs per 1 KB weight block and lane: lane (r, q) of a tiled block holds
+// W[n0 + r][16 kb + 4 q ..], so y[n0 + r] = sum over the blocks of the lane's 4-term dot products, summed over the four lanes r, r + 16,
+// r + 32, r + 48 at the end.  Same operand stream, same ring, same epilogues (the result goes into row 0 of an otherwise zero
+// accumulator tile): ~330 of a wave's ~470 MFMAs of that layer disappear in either direction, its 0.9 MB weight stream stays.
+// Exact: what is dropped is never read (forward) or multiplied by an exact zero (backward).
+__device__ __forceinline__ float dot4(const float4& w, const float4& x, float acc) {
+    acc = fmaf(w.x, x.x, acc);
+    acc = fmaf(w.y, x.y, acc);
+    acc = fmaf(w.z, x.z, acc);
+    return fmaf(w.w, x.w, acc);
+}
+__device__ __forceinline__ float quarters_sum(float v) {      // over the lanes r, r + 16, r + 32, r + 48
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ f32x4 row0_acc(float v) {      // accumulator layout: lane (r, q = 0), register 0 = row 0, column r
+    f32x4 c = {(threadIdx.x & 48) == 0 ? v : 0.f, 0.f, 0.f, 0.f};
+    return c;
+}
+// b_run for ONE live row: a0 = row 0 of the A tile + 4 q.  Result in acc[0] (TWO: acc[0], acc[1] = the two column tiles), the rest zero.
+template <int PRE, bool TWO, int NACC, int NU, int R, class IDX, class CO = NoCo>
+__device__ __forceinline__ void b_run_row0(BBuf<NU, R>& b, const float* base, unsigned vb, IDX idx, const float* a0, f32x4 (&acc)[NACC], CO co = CO()) {
+    static_assert(PRE <= R && (PRE == NU || PRE < R), "ring too small for the prefetch distance");
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        if (u + PRE < NU) {
+            b.s[(u + PRE) % R][0] = ldg_blk(base, vb, idx(u + PRE, 0));
+            b.s[(u + PRE) % R][1] = ldg_blk(base, vb, idx(u + PRE, 1));
+        }
+        co(u);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 x0 = lds4(a0 + (TWO ? u : 2 * u) * 16);
+        p0 = dot4(b.s[u % R][0], x0, p0);
+        p1 = dot4(b.s[u % R][1], TWO ? x0 : lds4(a0 + (2 * u + 1) * 16), p1);
+    }
+    zero_acc(acc);
+    if (TWO) {
+        acc[0] = row0_acc(quarters_sum(p0));
+        acc[1] = row0_acc(quarters_sum(p1));
+    } else {
+        acc[0] = row0_acc(quarters_sum(p0 + p1));
+    }
+}
+// The K = 1024 input-gradient product of the last layer: d(q | k | v | gate) has all rows in its k and v quarters (units 8 .. 23: matrix
+// cores) and row 0 only in its q and gate quarters (units 0 .. 7, 24 .. 31: vector ALUs).  ap = A tile + r * lda + 4 q, a0 = row 0 + 4 q.
+template <int PRE, int NU, int R, class IDX>
+__device__ __forceinline__ void b_run_kv_rows(BBuf<NU, R>& b, const float* base, unsigned vb, IDX idx, const float* ap, const float* a0, f32x4 (&acc)[4]) {
+    static_assert(NU == 32 && PRE < R, "q | k | v | gate: eight units each");
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        if (u + PRE < NU) {
+            b.s[(u + PRE) % R][0] = ldg_blk(base, vb, idx(u + PRE, 0));
+            b.s[(u + PRE) % R][1] = ldg_blk(base, vb, idx(u + PRE, 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u < 8 || u >= 24) {
+            p0 = dot4(b.s[u % R][0], lds4(a0 + (2 * u) * 16), p0);
+            p1 = dot4(b.s[u % R][1], lds4(a0 + (2 * u + 1) * 16), p1);
+        } else {
+            const int k = (u & 1) * 2;
+            mma_unit(lds4(ap + (2 * u) * 16), lds4(ap + (2 * u + 1) * 16), b.s[u % R][0], b.s[u % R][1], acc[k], acc[k + 1]);
+        }
+    }
+    const float v = quarters_sum(p0 + p1);
+    if ((threadIdx.x & 48) == 0) acc[0][0] += v;
+}
+
 // LayerNorm backward of the 16-row tile, 16 lanes per row (waves 0..3), xhat / rstd / gamma of the lane in registers:
 // dst = rstd * (a - mean(a) - xhat * mean(a * xhat)),  a = dy * g
 __device__ __forceinline__ void ln_bwd_tile16_r(const float* src, float* dst, int ld, float4 x0, float4 x1, float4 g0, float4 g1, float rs,
@@ -285,7 +358,10 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
     BBuf<32, 8> rq;
     b_issue<0, kQPre>(rq, load_layer(tab).watt_t + wq, wl, qidx);
     __syncthreads();
-    for (int l = 0; l < a.n_layers; ++l) {
+    // (the layer as a generic lambda instantiated twice -- all rows / the last layer's row 0 -- instead of run-time branches in one body:
+    // with both forms alive in one loop body the 241-register kernel spilled 46 VGPRs)
+    auto layer = [&](auto r0_c, const int l) __attribute__((always_inline)) {
+        constexpr bool r0 = decltype(r0_c)::value;      // the last layer: row 0 only (see b_run_row0)
         const RegLayerDev P = load_layer(tab + l);      // by value: the pointers live in SGPRs
         CF_STAMP8(0);
         const float gam = ldg(P.gamma + w);
@@ -305,6 +381,7 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         const float* ap = xs + oALD;
         float4 an = lds4(ap);
         f32x4 pacc[2];
+        float pr0 = 0.f, pr1 = 0.f;
         auto units = [&](auto u0_c, auto u1_c) {
             constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
 #pragma unroll
@@ -315,12 +392,26 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                 }
                 if (u >= 24) b_issue1(bwo, P.wo_t + wo16, wl, idx_one, u - 24);      // out-projection weights, spread over the gate chunk
                 __builtin_amdgcn_sched_barrier(0);
-                if ((u & 7) == 0) zero_acc(pacc);
+                if ((u & 7) == 0) {
+                    zero_acc(pacc);
+                    pr0 = pr1 = 0.f;
+                }
                 const float4 av = an;
                 an = lds4(ap + ((u + 1) & 7) * 16);
-                mma_unit(av, av, rq.s[u % 8][0], rq.s[u % 8][1], pacc[0], pacc[1]);
+                const bool one = r0 && ((u >> 3) == 0 || (u >> 3) == 3);      // q / gate of the last layer: row 0 on the vector ALUs
+                if (one) {
+                    const float4 x0 = lds4(xs + lq * 4 + (u & 7) * 16);
+                    pr0 = dot4(rq.s[u % 8][0], x0, pr0);
+                    pr1 = dot4(rq.s[u % 8][1], x0, pr1);
+                } else {
+                    mma_unit(av, av, rq.s[u % 8][0], rq.s[u % 8][1], pacc[0], pacc[1]);
+                }
                 if ((u & 7) == 7) {
                     const int c = u >> 3;
+                    if (one) {
+                        pacc[0] = row0_acc(quarters_sum(pr0));
+                        pacc[1] = row0_acc(quarters_sum(pr1));
+                    }
 #ifdef CF_STAMP_CHUNKS      // (tools/reg_stamps.py: ends of the q, k, v chunks)
                     if (c < 3) CF_STAMP8(9 + c);
 #endif
@@ -411,14 +502,18 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         {
             f32x4 acc[2];
             zero_acc(acc);
-            b_run<8, false, 2>(bwo, P.wo_t + wo16, wl, idx_one, as_ + oALW, acc, [&](int u) {      // FFN weights 1, one unit per unit
+            const auto co_w1 = [&](int u) {      // FFN weights 1, one unit per unit
                 if (u < NU1) {
                     if (DFF == 256)
                         b_issue1(bw1, P.w1_t + w1o, wl, idx_two, u);
                     else
                         b_issue1(bw1, P.w1_t + w1o, wl, idx_one, u);
                 }
-            });
+            };
+            if (r0)
+                b_run_row0<8, false, 2>(bwo, P.wo_t + wo16, wl, idx_one, as_ + lq * 4, acc, co_w1);
+            else
+                b_run<8, false, 2>(bwo, P.wo_t + wo16, wl, idx_one, as_ + oALW, acc, co_w1);
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) ts[oDLD + ii * LD] = (acc[0][ii] + acc[1][ii]) + bov + xs[oDLD + ii * LD];
         }
@@ -436,7 +531,10 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
             f32x4 acc[2];
             zero_acc(acc);
             if (DFF == 256) {
-                b_run<NU1, true, 2>(bw1, P.w1_t + w1o, wl, idx_two, ts + oALD, acc, co_w2);
+                if (r0)
+                    b_run_row0<NU1, true, 2>(bw1, P.w1_t + w1o, wl, idx_two, ts + lq * 4, acc, co_w2);
+                else
+                    b_run<NU1, true, 2>(bw1, P.w1_t + w1o, wl, idx_two, ts + oALD, acc, co_w2);
                 float* hp = lane_at(sbase(hg, 0), zH);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -449,7 +547,10 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
                     }
                 }
             } else {
-                b_run<NU1, false, 2>(bw1, P.w1_t + w1o, wl, idx_one, ts + oALD, acc, co_w2);
+                if (r0)
+                    b_run_row0<NU1, false, 2>(bw1, P.w1_t + w1o, wl, idx_one, ts + lq * 4, acc, co_w2);
+                else
+                    b_run<NU1, false, 2>(bw1, P.w1_t + w1o, wl, idx_one, ts + oALD, acc, co_w2);
                 if (NU2 > NU1) b_issue<NU1, NU2>(bw2, P.w2_t + w2o, wl, idx_one);
                 float* hp = lane_at(sbase(hg, 0), zH);
                 float hv[4];
@@ -469,9 +570,13 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
             zero_acc(acc);
             const bool more = l + 1 < a.n_layers;
             const float* nq = load_layer(tab + (more ? l + 1 : l)).watt_t + wq;
-            b_run<NU2, false, 2>(bw2, P.w2_t + w2o, wl, idx_one, hs + oALH, acc, [&](int u) {      // next layer's projection ring
+            const auto co_nq = [&](int u) {      // next layer's projection ring
                 if (u < kQPre && more) b_issue1(rq, nq, wl, qidx, u);
-            });
+            };
+            if (r0)
+                b_run_row0<NU2, false, 2>(bw2, P.w2_t + w2o, wl, idx_one, hs + lq * 4, acc, co_nq);
+            else
+                b_run<NU2, false, 2>(bw2, P.w2_t + w2o, wl, idx_one, hs + oALH, acc, co_nq);
             if (kQPre > NU2 && more) b_issue<NU2, kQPre>(rq, nq, wl, qidx);
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) xs[oDLD + ii * LD] = (acc[0][ii] + acc[1][ii]) + b2v + ts[oDLD + ii * LD];
@@ -481,7 +586,10 @@ __global__ __launch_bounds__(512) void k_reg8_fwd(RegArgs a) {
         if (w < 4) ln_fwd_tile16<(CF_SAVE_NT & 4) != 0>(xs, LD, ln2, row0, T, SAVE ? P.xh2 : nullptr, P.rs2, P.xout);
         CF_STAMP8(8);
         __syncthreads();
-    }
+    };
+    const int n_full = a.n_layers - (a.row0_last ? 1 : 0);
+    for (int l = 0; l < n_full; ++l) layer(std::false_type{}, l);
+    if (a.row0_last) layer(std::true_type{}, n_full);
     // the prediction head of the gene, forward + loss + backward, by the last of its resolutions' workgroups to get here (cf_head_ride.h);
     // row 0 of xs is the stack's output for token 0, everything behind it in the LDS is free
     if (SAVE && a.head.on) head_ride_tail(a.head, g, r, a.B, T, a.n_res, xs, load_layer(tab).xin + (size_t)row0 * kD, as_);
@@ -511,10 +619,11 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
     const float scale = sqrtf((float)kRDh);
     {
         const float* d0 = load_layer(tab + a.n_layers - 1).dxout + (size_t)row0 * kD;
+        const int Tin = a.row0_last ? 1 : T;      // (only token 0 of the stack's output has a gradient, see b_run_row0)
         for (int i = tid; i < kTile * (kD / 4); i += 512) {
             const int row = i >> 5, c4 = i & 31;
             float4 t = f4z();
-            if (row < T) t = ldg4(d0 + row * kD + c4 * 4);
+            if (row < Tin) t = ldg4(d0 + row * kD + c4 * 4);
             *reinterpret_cast<float4*>(ds + row * LD + c4 * 4) = t;
         }
         for (int i = tid; i < kTile * kQkLd; i += 512) dqk[i] = 0.f;      // rows >= T stay zero (MFMA operand)
@@ -574,7 +683,8 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
     };
     request_ln2(load_layer(tab + a.n_layers - 1));
     __syncthreads();
-    for (int l = a.n_layers - 1; l >= 0; --l) {
+    auto layer = [&](auto r0_c, const int l) __attribute__((always_inline)) {
+        constexpr bool r0 = decltype(r0_c)::value;      // the last layer: one live row above the attention (see b_run_row0)
         const RegLayerDev P = load_layer(tab + l);
         CF_STAMP8(0);
         // ---- LayerNorm 2 backward (waves 0..3) first, then everybody's requests for the next phase
@@ -597,7 +707,10 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             f32x4 acc[2];
             zero_acc(acc);
             if (DFF == 256) {
-                b_run<NUA, true, 2>(bA, P.w2_tt + wAo, wl, idx_two, t2 + oALD, acc, co_B);
+                if (r0)
+                    b_run_row0<NUA, true, 2>(bA, P.w2_tt + wAo, wl, idx_two, t2 + lq * 4, acc, co_B);
+                else
+                    b_run<NUA, true, 2>(bA, P.w2_tt + wAo, wl, idx_two, t2 + oALD, acc, co_B);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -608,7 +721,10 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
                     }
                 }
             } else {
-                b_run<NUA, false, 2>(bA, P.w2_tt + wAo, wl, idx_one, t2 + oALD, acc, co_B);
+                if (r0)
+                    b_run_row0<NUA, false, 2>(bA, P.w2_tt + wAo, wl, idx_one, t2 + lq * 4, acc, co_B);
+                else
+                    b_run<NUA, false, 2>(bA, P.w2_tt + wAo, wl, idx_one, t2 + oALD, acc, co_B);
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const float vv = hm[0][ii] > 0.f ? acc[0][ii] + acc[1][ii] : 0.f;
@@ -635,7 +751,11 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         {
             f32x4 acc[2];
             zero_acc(acc);
-            b_run<NUB, false, 2>(bB, P.w1_tt + wBo, wl, idx_one, wide + oALH, acc, [&](int u) { b_issue1(bC, P.wo_tt + wCo, wl, idx_two, u); });
+            const auto co_C = [&](int u) { b_issue1(bC, P.wo_tt + wCo, wl, idx_two, u); };
+            if (r0)
+                b_run_row0<NUB, false, 2>(bB, P.w1_tt + wBo, wl, idx_one, wide + lq * 4, acc, co_C);
+            else
+                b_run<NUB, false, 2>(bB, P.w1_tt + wBo, wl, idx_one, wide + oALH, acc, co_C);
             if (NUB < 8) b_issue<NUB, 8>(bC, P.wo_tt + wCo, wl, idx_two);
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
@@ -680,9 +800,13 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         {
             f32x4 da[2];
             zero_acc(da);
-            b_run<8, true, 2>(bC, P.wo_tt + wCo, wl, idx_two, ds + oALD, da, [&](int u) {
+            const auto co_D = [&](int u) {
                 if (u < 7) b_issue1(bD, P.watt_tt + wDo, wl, idx_one, u);
-            });
+            };
+            if (r0)
+                b_run_row0<8, true, 2>(bC, P.wo_tt + wCo, wl, idx_two, ds + lq * 4, da, co_D);
+            else
+                b_run<8, true, 2>(bC, P.wo_tt + wCo, wl, idx_two, ds + oALD, da, co_D);
             float* dg = P.dqkvg + row0 * kRW + w * 32;
             f32x4 dov[2];      // do = da . sigmoid(gate): D layout = B operand of dv
 #pragma unroll
@@ -750,7 +874,10 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         {
             f32x4 acc[4];
             zero_acc(acc);
-            b_run<7, false, 4>(bD, P.watt_tt + wDo, wl, idx_one, dqk + oAQ, acc);
+            if (r0)
+                b_run_kv_rows<7>(bD, P.watt_tt + wDo, wl, idx_one, dqk + oAQ, dqk + lq * 4, acc);
+            else
+                b_run<7, false, 4>(bD, P.watt_tt + wDo, wl, idx_one, dqk + oAQ, acc);
 
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
@@ -761,7 +888,9 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         }
         CF_STAMP8(6);
         __syncthreads();
-    }
+    };
+    if (a.row0_last) layer(std::true_type{}, a.n_layers - 1);
+    for (int l = a.n_layers - 1 - (a.row0_last ? 1 : 0); l >= 0; --l) layer(std::false_type{}, l);
     if (ride_loss) head_ride_loss(a.head, a.B, ride_l);
 }
 

@@ -27,6 +27,7 @@ struct RegArgs {
     HeadRide head;                   // forward (cf_reg8.h): the gene's prediction head at the tail of its last workgroup (cf_head_ride.h)
     float* team_slots;               // cf_regq.h: exchange slots of the four-workgroup teams, [units][2][4][16 x 128]
     int* team_cnt;                   //            arrival / departure counters, [units][32]
+    int row0_last;                   // cf_reg8.h: only token 0 of the LAST layer's output is consumed (net.py:375): that layer computes row 0 only
 };
 #define CF_STAMP(slot)                                                                                 \
     do {                                                                                               \

@@ -115,3 +115,41 @@ def test_feed_steps_equal_staged_steps_and_log_every_step():
     assert torch.equal(torch.cat([w[2] for w in windows]), torch.cat(losses[:10]))
     want = torch.cat([store.label[torch.tensor(b, device=store.label.device)].cpu() for b in batches[:10]])
     assert torch.equal(torch.cat([w[1] for w in windows]), want)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_a_forward_pass_between_two_fed_steps_does_not_move_the_feed(use_graph):
+    """The pre-gathered feed keeps 'a batch is waiting, the next trunk launch advances the cursor' on the handle.  A forward pass over
+    ANOTHER batch in between (validation mid-epoch through the public Trainer API) must leave that state to the step it was queued
+    for: consumed there, the replayed step graph advanced the cursor a second time and the epoch silently skipped a batch."""
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import EpochFeed, Trainer
+    from chromoformer_amd.synth import synthetic_store
+    dev = torch.device("cuda", 0)
+    store = synthetic_store(120, dev, seed=5, regime="realistic")
+    val = synthetic_store(24, dev, seed=6, regime="realistic")
+    rng = np.random.default_rng(3)
+    batches = [rng.choice(len(store), size=8, replace=False).tolist() for _ in range(6)]
+
+    def run(interleave):
+        model = ChromoformerClassifier(seed=42, max_batch=8).cuda(0)
+        trainer = Trainer(model, lr=3e-5, use_graph=use_graph)
+        feed = EpochFeed(model, store, 8)
+        feed.begin_epoch(batches, trainer.stream)
+        outs = []
+        for k in range(len(batches)):
+            lo, ls = trainer.step(feed.slot)
+            trainer.stream.synchronize()
+            outs.append((lo.cpu().clone(), ls.cpu().clone()))
+            if interleave and k in (1, 2, 4):
+                trainer.evaluate_store(val, 8)
+        torch.cuda.synchronize()
+        assert feed.check() == 0 and int(feed.cursor[0].item()) == len(batches)
+        return outs, {k: v.clone() for k, v in model.state_dict().items()}
+
+    plain, sd0 = run(False)
+    mixed, sd1 = run(True)
+    for (a, b), (c, d) in zip(plain, mixed):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
