@@ -390,9 +390,10 @@ def main():
                        "adamw": "in the epilogue of the gradient reductions (cf_reduce_opt_part)" if trainer.fuse_opt else "own launches"},
             "roofline": roof,
             # BASELINE.json's north_star asks for ">= 60 % HBM utilisation in the attention kernels": no kernel of this step is HBM-bound -- the centre-row
-            # attention reads its 7-mark features once (the only HBM stream, 6.5-10 % of HBM bandwidth while it runs) and is bound by the matrix pipe of
+            # attention reads its 7-mark features once (the only HBM stream, 7-10.6 % of HBM bandwidth while it runs) and is bound by the matrix pipe of
             # its CU and by a chain of dependent phases (DESIGN.md sections 2, 4, 9); the bound of every kernel reported here is the f32 MFMA peak
-            "attention_hbm_note": "centre-row attention is MFMA / latency-bound, not HBM-bound: 6.5-10 % of HBM bandwidth (profiles/r02c_attc2_bandwidth.csv); "
+            "attention_hbm_note": "centre-row attention is MFMA / latency-bound, not HBM-bound: 7-10.6 % of HBM bandwidth measured on the current kernels run as "
+                                  "launches of their own (CF_TRUNK=0; tools/attc_bandwidth.sh -> profiles/r05b_attc_bandwidth.csv: PMC bytes / duration per launch); "
                                   "the HBM-bound kernel of the path is the binning of raw signals (profiles/*_binning.json: 70 % of 8 TB/s)",
             "loss": round(float(trainer.last_loss()), 6),
         }

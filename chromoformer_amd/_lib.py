@@ -171,6 +171,16 @@ def lib():
             raise RuntimeError(
                 "libchromoformer_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "there is no CPU / PyTorch fallback for the Chromoformer hot path" % LIB_PATH)
+        # the library on disk must be the one the current environment asks for: an A/B build (CF_HIPCC_FLAGS) left behind by an experiment is
+        # refused instead of silently used by every later run that does not call build()
+        flags = " ".join(os.environ.get("CF_HIPCC_FLAGS", "").split())
+        try:
+            built_with = open(FLAGS_PATH).read().strip()
+        except OSError:
+            built_with = ""      # (a library without the sidecar was built by build() before the sidecar existed, or by hand: plain flags)
+        if built_with != flags:
+            raise RuntimeError("libchromoformer_hip.so was built with CF_HIPCC_FLAGS='%s' but this process runs with '%s': rebuild "
+                               "(`python -c 'import __graft_entry__ as g; g.build()'`) or set the variable to match" % (built_with, flags))
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -30,8 +30,8 @@ struct HeadRide {
     int* cnt;                    // [B] arrivals per gene (zeroed by workgroup 0 of the forward launch at its start)
 };
 
-// Start of the Regulation forward launch, workgroup 0: nobody has arrived yet.  (Every workgroup of the launch is resident from the
-// start -- one per CU -- and reaches its tail ~100 us later.)
+// Start of the Regulation forward launch, workgroup 0: a repair, not a protocol step -- every gene's last arriver rewinds the gene's counter
+// itself (head_ride_tail), so the counters ARE zero here unless a launch was aborted.  (An arrival needs the whole stack: ~100 us later.)
 __device__ __forceinline__ void head_ride_begin(const HeadRide& hd, const int B) {
     for (int i = threadIdx.x; i < B; i += blockDim.x) __hip_atomic_store(hd.cnt + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -71,15 +71,28 @@ __device__ __forceinline__ void head_ride_tail(const HeadRide& hd, const int g, 
     // the operand streams of both products are requested before anybody knows who will need them: the loser of the count returns
     // a microsecond later without having waited for them, the winner finds them there
     if (tid < kD) __hip_atomic_store(hd.hin + (size_t)g * K + r * kD + tid, xs0[tid] + ldg(xin0 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::: "memory");                          // (the store stays in front of the loads: the counted wait below relies on it)
+    // The chunk must have reached the coherence point before the workgroup counts itself in.  Nothing else of this wave is in flight here (the
+    // last layer's operand rings have drained), so a full wait costs the write-through latency of this one store and depends on nothing the
+    // compiler may do to the loads behind it (round 4 waited with vmcnt(24) for "everything but the 24 operand loads requested after the
+    // store": right for the code the compiler emitted then, silently wrong if it ever splits, merges or hoists one of them).
+#ifndef CF_HEAD_RIDE_COUNTED_WAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NtW<kD, K> w1t;
+    nt_request(w1t, hd.w1_t);
+#else
+    asm volatile("" ::: "memory");
     NtW<kD, K> w1t;
     nt_request(w1t, hd.w1_t);
     static_assert(NtW<kD, K>::TW * NtW<kD, K>::KB == 24, "loads of the operand stream behind the store");
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // this wave's share of the chunk has been acknowledged; the 24 operand loads stay in flight
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+#endif
     __syncthreads();
     if (tid == 0) *flag = __hip_atomic_fetch_add(hd.cnt + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*flag != n_res - 1) return;
+    // the last arriver is the only workgroup that still looks at the gene's counter: it puts it back to zero for the next launch itself.  (The
+    // zero fill at the start of the launch, head_ride_begin, stays as the repair after an aborted launch; nothing depends on its timing.)
+    if (tid == 0) __hip_atomic_store(hd.cnt + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- the gene's last workgroup: forward
     if (tid < K) hs[tid] = __hip_atomic_load(hd.hin + (size_t)g * K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int n = nt_row<kD, K>(0);

@@ -83,6 +83,17 @@ class Slot:
             put(self.cf[r], d["pcre_feats"][b])
             pm, cm = d["promoter_pad_masks"][b], d["pcre_pad_masks"][b]
             if pm.dim() == 5:
+                if model._kws[0]["n_layers"] > 1:
+                    # A slot keeps the CENTRE query row of a pad mask.  That is all a one-layer Embedding reads (net.py:59); with more layers
+                    # every row of the promoter mask is read (modules.py:71-73), and the all-rows path rebuilds it from the centre row as
+                    # not(valid x valid) -- the dataset's form (data.py:156-161).  Any other [L, L] mask would be silently replaced: refuse it
+                    # here by name; model(...) / model.pack_batch(...) hand the library the full tensor and take any bool mask.
+                    full = pm[:, 0, 0].to(torch.bool)
+                    valid = ~full[:, L // 2, :]
+                    if not torch.equal(full, ~(valid[:, :, None] & valid[:, None, :])):
+                        raise ValueError("Slot.fill: promoter_pad_masks[%d] is not of the dataset's form not(valid x valid) with a valid centre bin; a "
+                                         "slot keeps only the centre row, which does not determine such a mask for embed.n_layers = %d > 1 "
+                                         "(use model(...) / model.pack_batch(...), which pass the full [B, 1, L, L] mask)" % (b, model._kws[0]["n_layers"]))
                 pm, cm = pm[:, 0, 0, L // 2, :], cm[:, :, 0, L // 2, :]
             put(self.pm[r], pm)
             put(self.cm[r], cm)
@@ -369,6 +380,12 @@ class Trainer:
     def _step(self, slot):
         m, L = self.model, self._L
         st = self._stream()
+        # keep_tiled is a mode of the MODEL, the captured graphs are this Trainer's: another Trainer on the same model may have switched the
+        # mode since (its constructor does).  A graph captured with the mode on holds no Embedding + Pairwise re-tiling and would replay on
+        # stale tiled weights once the optimiser stops writing them -- so the mode this Trainer was built (and captured) with is put back
+        # in front of every step; switching it drops the version stamp, and _sync_tiled below rebuilds the copies once.
+        if bool(getattr(m, "_keep_tiled", False)) != bool(self.keep_tiled):
+            m.keep_tiled(self.keep_tiled)
         m._sync_tiled(st)          # (keep_tiled: parameters written through torch since the last step are re-tiled here, also in front of a graph replay)
         feed = getattr(slot, "feed", None)
         if feed is not None:

@@ -114,3 +114,48 @@ def test_full_promoter_embedding_of_the_default_model(compact):
             full, centre = orc.embed_forward(P, "embed.%d." % b, cfg, batch["promoter_feats"][b], batch["promoter_pad_masks"][b])
             assert got[b].shape == full.shape
             assert (got[b].cpu() - full).abs().max() < 2e-5, b
+
+
+def test_arbitrary_bool_masks_through_two_embedding_layers():
+    """modules.py:71-73 takes ANY bool mask (the reference's own smoke block feeds `randn(...).bool()`-style ones, net.py:431-568).  With
+    embed.n_layers = 2 every row of the promoter mask is read: model(...) hands the library the full [B, 1, L, L] tensor and matches the
+    oracle (forward 1e-4, gradients 1e-3); a Slot, which keeps only the centre row, refuses such a mask by name instead of replacing it."""
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    model = ChromoformerClassifier(embed_kws=CFG2["embed"], seed=42, max_batch=4).cuda(0)
+    P = _perturb(orc.init_params(CFG2, 42, False), 5)
+    model.load_state_dict(P)
+    batch = orc.synthetic_batch(4, seed=33, regime="realistic")
+    g = torch.Generator().manual_seed(9)
+    for b in batch["promoter_pad_masks"]:      # unstructured masks, ~30 % of the entries set, one query row fully masked
+        m = torch.rand(batch["promoter_pad_masks"][b].shape, generator=g) < 0.3
+        m[1, 0, 0, 3, :] = True
+        batch["promoter_pad_masks"][b] = m
+        c = torch.rand(batch["pcre_pad_masks"][b].shape, generator=g) < 0.3
+        batch["pcre_pad_masks"][b] = c
+    for t in P.values():
+        t.requires_grad_(True)
+    ref = orc.forward(P, batch, CFG2)
+    loss_ref = orc.loss_fn(ref, batch["label"], False)
+    loss_ref.backward()
+    with torch.no_grad():
+        out = _call(model, batch).cpu()
+    assert (out - ref.detach()).abs().max() < 1e-4
+    logits, loss = model.forward_backward(model.pack_batch(batch), batch["label"])
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4
+    model._publish_grads()
+    named = dict(model.named_parameters())
+    n = 0
+    for k, v in P.items():
+        if v.grad is None:
+            continue
+        got = named[k].grad.cpu()
+        assert (got - v.grad).abs().max() <= 1e-3 * max(v.grad.abs().max().item(), 1e-6), k
+        n += 1
+    assert n > 300
+    with pytest.raises(ValueError, match="not of the dataset's form"):
+        Trainer(model, lr=3e-5).stage(batch)
+    # ... while the dataset's structured masks go through a slot as before
+    ok = orc.synthetic_batch(4, seed=33, regime="realistic")
+    Trainer(model, lr=3e-5).stage(ok)

@@ -204,3 +204,42 @@ def test_tiled_copies_kept_by_the_optimiser_survive_outside_writes():
         assert torch.equal(logits, ref_logits)
         if not graph:      # forward launches of an eager step: prologue + trunk + Regulation against trunk + Regulation
             assert ref_counts[1] == counts[1] + 1, (ref_counts, counts)
+
+
+def test_two_trainers_with_different_tiling_modes_on_one_model():
+    """keep_tiled is a mode of the model, the captured step graphs belong to a Trainer.  A second Trainer built with the mode off (bench.py's
+    data-parallel proxy does that on the shared model) must not leave the first one replaying graphs that hold no re-tiling while the
+    optimiser has stopped writing the tiled copies: every Trainer puts its own mode back in front of a step.  Same bits as one Trainer alone."""
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    batches = [orc.synthetic_batch(B, seed=11 + i, regime="realistic") for i in range(2)]
+
+    def run(interleave):
+        model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+        t1 = Trainer(model, lr=1e-3, use_graph=True)
+        s1 = [t1.stage(b) for b in batches]
+        losses = []
+        def step(tr, sl):
+            _, loss = tr.step(sl)
+            tr.stream.synchronize()      # (the step runs on the trainer's own non-blocking stream)
+            losses.append(float(loss))
+
+        for i in range(3):
+            step(t1, s1[i % 2])
+        if interleave:
+            t2 = Trainer(model, lr=1e-3, use_graph=True, keep_tiled=False)      # switches the model's mode off
+            assert t1.keep_tiled and not t2.keep_tiled
+        else:
+            t2 = t1
+        s2 = [t2.stage(b) for b in batches] if interleave else s1
+        for i in range(3, 9):
+            tr, sl = (t2, s2) if i % 2 else (t1, s1)
+            step(tr, sl[i % 2])
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    l0, sd0 = run(False)
+    l1, sd1 = run(True)
+    assert l0 == l1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
