@@ -6,6 +6,10 @@
 //
 // One workgroup per 16 genes.  The head is a few MFLOP: what matters is that it is two launches instead of nine.
 #pragma once
+// (the head kernels keep the plain thread index: with the opaque one of cf_kernels.h -- CF_TID_OPAQUE, there for the fused trunk -- k_head_bwd
+// went from 174 registers to 256 with 16 spilled)
+#pragma push_macro("threadIdx")
+#undef threadIdx
 
 namespace cf {
 
@@ -363,3 +367,4 @@ __global__ __launch_bounds__(256) void k_head_gen_bwd(HeadGenArgs a) {
 }
 
 }  // namespace cf
+#pragma pop_macro("threadIdx")

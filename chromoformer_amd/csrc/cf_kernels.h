@@ -21,6 +21,30 @@
 #define CF_TRUNK_NT 0
 #endif
 
+// Every read of threadIdx.x is OPAQUE to the optimiser (CF_TID_OPAQUE=0: the plain builtin).  The fused trunk kernels run ~20 phase bodies one
+// behind the other in straight-line code; each body starts from `tid = threadIdx.x` and derives its lane / row / column offsets from it.
+// Left alone the compiler recognises that tid >> 3, tid << 5, (tid & 63) * 16 ... of phase 17 were already computed in phase 2, keeps them
+// alive through the 244-register attention bodies in between and SPILLS them there (k_trunk_bwd: 71 spilled VGPRs, every one of them a
+// shift of the thread index; tools/kernel_resources.sh).  Read through an empty `asm volatile` the thread index of one phase has nothing in
+// common with that of the next: each phase recomputes its three or four shifts and nothing lives across a phase boundary.
+#ifndef CF_TID_OPAQUE
+#define CF_TID_OPAQUE 1
+#endif
+#if CF_TID_OPAQUE
+namespace cf {
+struct TidProxy {
+    struct X {
+        __device__ __forceinline__ operator unsigned() const {
+            unsigned t = __builtin_amdgcn_workitem_id_x();
+            asm volatile("" : "+v"(t));
+            return t;
+        }
+    } x;
+};
+}  // namespace cf
+#define threadIdx (cf::TidProxy{})
+#endif
+
 namespace cf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
