@@ -227,9 +227,6 @@ struct cf_handle {
     bool keep_tiled_ok = false;          // (build_tables: the reduction tiles cover every tensor of that group)
     bool keep_tiled = false;             // cf_keep_tiled: the fused optimiser keeps the Embedding + Pairwise tiled copies fresh, forward passes do not re-tile them
     bool tiled_pe_fresh = false;         // ... and they ARE fresh (cleared by whatever else writes parameters: cf_bind, cf_params_changed, the separate AdamW launches)
-    bool reg_team = false;               // ... its forward on teams of four 256-thread workgroups (cf_regq.h; CF_REG_TEAM=1)
-    float* team_slots = nullptr;
-    int* team_cnt = nullptr;
     // Embedding stack over ALL promoter bins (cf_embed_full.h + the dense transformer layer): used by the model path when
     // embed.n_layers > 1 and by cf_embed_full; device buffers outside the arena, allocated on first need
     struct EmbedDense {
@@ -468,8 +465,6 @@ static void plan_workspace(cf_handle* h) {
     h->loss_part = h->ws_get("H.loss_part", MB + 1);      // (per 16-gene tile; per gene in the generic-width head)
     h->head_cnt = reinterpret_cast<int*>(h->ws_get("H.cnt", MB + 1));      // arrivals per gene + genes done (cf_head_ride.h); zero between launches
     h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 64);      // shader-clock stamps (uint64) of the fused Regulation kernels
-    h->team_slots = h->ws_get("R.team_slots", regq_slot_floats((int)MB * c.n_res));      // (cf_regq.h; the arena is zeroed at cf_create: the counters start at 0)
-    h->team_cnt = reinterpret_cast<int*>(h->ws_get("R.team_cnt", (size_t)MB * c.n_res * kTqCnt));
 }
 
 // ------------------------------------------------------------------------------------
@@ -540,23 +535,13 @@ static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const C
     push_wg(out, wg1(b.dt2, kD, b.hdn, dff, rpg, h->G_(ff_pre + "l2.weight"), dff, kD, dff));
 }
 
-// the fused Regulation kernels are instantiated for the default token count (T = 9, loops over tokens
-// unrolled) and once with a run-time T
-static const void* reg_kernel(bool bwd, int dff, int T, bool reg8, bool save = true) {
-    if (reg8) {
-        if (!bwd) {
-            if (save) return dff == 128 ? (const void*)k_reg8_fwd<128, true> : (const void*)k_reg8_fwd<256, true>;
-            return dff == 128 ? (const void*)k_reg8_fwd<128, false> : (const void*)k_reg8_fwd<256, false>;
-        }
-        return dff == 128 ? (const void*)k_reg8_bwd<128> : (const void*)k_reg8_bwd<256>;
-    }
-    const bool t9 = T == 9;
+// the fused Regulation kernels (cf_reg8.h): forward with / without the activation saves, backward; per FFN width
+static const void* reg_kernel(bool bwd, int dff, bool save = true) {
     if (!bwd) {
-        if (dff == 128) return t9 ? (const void*)k_reg_fwd<128, 9> : (const void*)k_reg_fwd<128, 0>;
-        return t9 ? (const void*)k_reg_fwd<256, 9> : (const void*)k_reg_fwd<256, 0>;
+        if (save) return dff == 128 ? (const void*)k_reg8_fwd<128, true> : (const void*)k_reg8_fwd<256, true>;
+        return dff == 128 ? (const void*)k_reg8_fwd<128, false> : (const void*)k_reg8_fwd<256, false>;
     }
-    if (dff == 128) return t9 ? (const void*)k_reg_bwd<128, 9> : (const void*)k_reg_bwd<128, 0>;
-    return t9 ? (const void*)k_reg_bwd<256, 9> : (const void*)k_reg_bwd<256, 0>;
+    return dff == 128 ? (const void*)k_reg8_bwd<128> : (const void*)k_reg8_bwd<256>;
 }
 
 static int build_reg_table(cf_handle* h) {
@@ -693,16 +678,6 @@ static int build_tables(cf_handle* h) {
                 push_cs(csR, b.dy1, kD, kD, T, 1, h->G_(ap + "ln.weight"), b.xh1);
                 push_cs(csR, b.dy1, kD, kD, T, 1, h->G_(ap + "ln.bias"));
                 push_cs(csR, b.dt1, kD, kD, T, 1, h->G_(ap + "ff.bias"));
-            } else if (h->reg_fused) {       // one partial row per gene instead of per 16-row tile
-                const int pw = post_partial_width(dff);
-                const std::string ap = lp + "self_att.", fp = lp + "ff.";
-                push_cs(csR, b.partial + 0, pw, kD, 1, 1, h->G_(fp + "ln.weight"));
-                push_cs(csR, b.partial + 128, pw, kD, 1, 1, h->G_(fp + "ln.bias"));
-                push_cs(csR, b.partial + 256, pw, kD, 1, 1, h->G_(fp + "l2.bias"));
-                push_cs(csR, b.partial + 384, pw, dff, 1, 1, h->G_(fp + "l1.bias"));
-                push_cs(csR, b.partial + 384 + dff, pw, kD, 1, 1, h->G_(ap + "ln.weight"));
-                push_cs(csR, b.partial + 512 + dff, pw, kD, 1, 1, h->G_(ap + "ln.bias"));
-                push_cs(csR, b.partial + 640 + dff, pw, kD, 1, 1, h->G_(ap + "ff.bias"));
             } else {
                 push_post_cs(csR, h, b.partial, dff, T, lp + "self_att.", lp + "ff.");
             }
@@ -883,35 +858,19 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     const cf_config& c = h->cfg;
     {   // the fused Regulation kernels need up to ~150 KB of dynamic LDS
         const int T = c.i_max + 1;
-        h->reg8 = T <= kTile;                  // 512-thread kernels (cf_reg8.h); CF_REG8=0 selects the 256-thread ones (A/B runs)
-        if (const char* e = getenv("CF_REG8")) h->reg8 = h->reg8 && atoi(e) != 0;
+        // 512-thread kernels (cf_reg8.h) for the default head count / width and T <= 16 tokens; CF_REG_FUSED=0 runs the stack layer by layer
+        // on the stand-alone kernels instead (k_attr + the row-tile chains: what every other shape runs) -- the cross-check implementation
         h->reg_row0 = getenv_int("CF_REG_ROW0", 1) != 0;
-        const size_t need = h->reg8 ? std::max(reg8_fwd_smem(c.reg_dff), reg8_bwd_smem(c.reg_dff)) : std::max(reg_fwd_smem(T), reg_bwd_smem(T));
-        h->reg_fused = T <= kTile && need <= 160 * 1024 && c.reg_heads == kRH && c.reg_dmodel == kRDm;
+        const size_t need = std::max(reg8_fwd_smem(c.reg_dff), reg8_bwd_smem(c.reg_dff));
+        h->reg_fused = T <= kTile && need <= 160 * 1024 && c.reg_heads == kRH && c.reg_dmodel == kRDm && getenv_int("CF_REG_FUSED", 1) != 0;
         if (h->reg_fused) {
-            const size_t sf = h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), sb = h->reg8 ? reg8_bwd_smem(c.reg_dff) : reg_bwd_smem(T);
-            hipError_t e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, T, h->reg8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
-            if (h->reg8 && e1 == hipSuccess)
-                e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, T, true, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
-            hipError_t e2 = hipFuncSetAttribute(reg_kernel(true, c.reg_dff, T, h->reg8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb);
+            const size_t sf = reg8_fwd_smem(c.reg_dff), sb = reg8_bwd_smem(c.reg_dff);
+            hipError_t e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
+            if (e1 == hipSuccess) e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
+            hipError_t e2 = hipFuncSetAttribute(reg_kernel(true, c.reg_dff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb);
             if (e1 != hipSuccess || e2 != hipSuccess) h->reg_fused = false;
         }
-        if (!h->reg_fused) h->reg8 = false;
-        // the team forward (cf_regq.h): default Regulation shape with d_ff = 256, and a device on which the workgroups of a launch go round-robin
-        // over the 8 XCDs -- the four members of a team, 8 ids apart, then share an L2, which is what makes their plain-store / sc1-load exchange coherent
-        if (h->reg8 && c.reg_dff == 256 && getenv_int("CF_REG_TEAM", 0) != 0) {
-            unsigned* probe = nullptr;
-            unsigned host[64];
-            bool ok = hipMalloc(&probe, sizeof host) == hipSuccess;
-            if (ok) {
-                hipLaunchKernelGGL(k_xcc_probe, dim3(64), dim3(64), 0, 0, probe);
-                ok = hipMemcpy(host, probe, sizeof host, hipMemcpyDeviceToHost) == hipSuccess;
-                // (round-robin from wherever the dispatcher stands: what a team needs is that ids 8 apart share an XCD)
-                for (int i = 0; ok && i < 64; ++i) ok = host[i] == ((host[0] + (unsigned)i) & 7);
-                (void)hipFree(probe);
-            }
-            h->reg_team = ok;
-        }
+        h->reg8 = h->reg_fused;
     }
     {   // gene-batched attention kernel when its LDS image (8 regions of features + 16 score rows) fits
         size_t need = 0;
@@ -1168,8 +1127,8 @@ static int check_batch(const cf_handle* h, const cf_batch* b) {
 // Launch of a fused Regulation kernel.  Under capture, if it is the kernel selected with cf_timing_select, the
 // capture is split around it: the launch is remembered instead of recorded and cf_graph_launch issues it eagerly,
 // between two HIP events, between the two graph pieces.
-static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid, size_t smem, RegArgs& ra, hipStream_t st, int threads = 0) {
-    const dim3 block(threads ? threads : (h->reg8 ? 512 : 256));
+static int launch_reg(cf_handle* h, const char* name, const void* fn, dim3 grid, size_t smem, RegArgs& ra, hipStream_t st) {
+    const dim3 block(512);
     if (h->capturing && h->timed == name && !h->cap.has_hole) {
         hipGraph_t g = nullptr;
         HIP_TRY(hipStreamEndCapture(st, &g));
@@ -1544,15 +1503,8 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         ra.tdbg = getenv("CF_STAMP") ? reinterpret_cast<unsigned long long*>(h->tdbg) : nullptr;
         memset(&ra.head, 0, sizeof ra.head);
         if (ride) ra.head = *ride;
-        ra.team_slots = h->team_slots;
-        ra.team_cnt = h->team_cnt;
         ra.row0_last = h->reg_row0 ? 1 : 0;
-        if (h->reg_team) {      // four 256-thread workgroups per (gene, resolution), 8 workgroup ids apart (cf_regq.h)
-            const void* fn = save != 0 ? (const void*)k_regq_fwd<true> : (const void*)k_regq_fwd<false>;
-            if (launch_reg(h, "k_reg_fwd", fn, dim3(32 * ((B * nres + 7) / 8)), regq_fwd_smem(), ra, st, 256)) return -1;
-        } else if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, T, h->reg8, save != 0), dim3(8 * ((B * nres + 7) / 8)),
-                              h->reg8 ? reg8_fwd_smem(c.reg_dff) : reg_fwd_smem(T), ra, st))
-            return -1;
+        if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, save != 0), dim3(8 * ((B * nres + 7) / 8)), reg8_fwd_smem(c.reg_dff), ra, st)) return -1;
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
         LinArgs la;
@@ -1647,7 +1599,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
 // default head width; CF_HEAD_RIDE=0 at cf_create switches it off: A/B runs, cross-checks.)
 extern "C" int cf_head_rides(cf_handle* h) {
     if (!h) return 0;
-    return h->reg_fused && h->reg8 && !h->reg_team && h->cfg.n_res == kMaxRes && h->cfg.d_head == kD && h->head_ride ? 1 : 0;
+    return h->reg_fused && h->cfg.n_res == kMaxRes && h->cfg.d_head == kD && h->head_ride ? 1 : 0;
 }
 // cf_forward(save_for_backward = 2) for a training step whose labels are known at forward time: where cf_head_rides(h), the
 // prediction head -- forward, loss, its backward down to the gradient of token 0 of every Regulation output -- runs at the tail of the
@@ -1755,12 +1707,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             if (loss_out) ra.head.loss_user = loss_out;
             h->head_loss_due = false;
         }
-        ra.team_slots = nullptr;
-        ra.team_cnt = nullptr;
         ra.row0_last = h->reg_row0 ? 1 : 0;
-        if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff, T, h->reg8), dim3(8 * ((B * nres + 7) / 8)),
-                       h->reg8 ? reg8_bwd_smem(c.reg_dff) : reg_bwd_smem(T), ra, st))
-            return -1;
+        if (launch_reg(h, "k_reg_bwd", reg_kernel(true, c.reg_dff), dim3(8 * ((B * nres + 7) / 8)), reg8_bwd_smem(c.reg_dff), ra, st)) return -1;
     }
     for (int l = ((h->reg_fused || !(parts & 2)) ? -1 : c.reg_layers - 1); l >= 0; --l) {   // Regulation, unfused fallback
         PostBwdArgs pb;
@@ -2213,7 +2161,7 @@ extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
     // With the last layer reduced to what token 0 of its output needs (cf_reg8.h, b_run_row0) that layer's algorithmic work is smaller and is
     // counted as such: keys / values (forward) and the k, v quarters of the input-gradient product (backward) over all T rows, everything else
     // -- q, gate, out-projection, FFN, the attention products -- for ONE row.
-    const bool row0 = h->reg_fused && h->reg8 && !h->reg_team && h->reg_row0;
+    const bool row0 = h->reg_fused && h->reg_row0;
     const double full_layers = c.reg_layers - (row0 ? 1 : 0);
     const double lin_last = 2.0 * (T * kD * 2.0 * RDm + kD * 2.0 * RDm + RDm * (double)kD + kD * dff + dff * kD);
     if (k == "k_reg_fwd") return ((lin_fwd + att_fwd) * full_layers + (row0 ? lin_last + 2.0 * T * RDm * 2.0 : 0.0)) * c.n_res * B;
@@ -2694,7 +2642,7 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t st) {
     const int mode = getenv_int("CF_ATTN_BWD_SPLIT", 0);
     const bool vec_ok = (a.ldq & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dq) & 15) == 0;      // (the dQ update is 16 bytes per lane)
     if (vec_ok && (mode < 0 || (mode == 0 && (long long)a.N * a.H >= 512))) {
-        hipLaunchKernelGGL(k_attn_bwd<0>, dim3(a.H, a.N), dim3(256), 0, st, a);      // (<2>: next-tile register prefetch, measured slower: LAB_NOTES.md)
+        hipLaunchKernelGGL(k_attn_bwd, dim3(a.H, a.N), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_attn_bwd");
         return 0;
     }

@@ -425,11 +425,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_q(AttnArgs a) {
 // result in the accumulator layout is, per query row, FOUR CONSECUTIVE head columns: the update of dQ in global memory is one 16-byte
 // load and one 16-byte store per lane and 16-row block.  dQ is complete only after the last key tile: every pair adds to the rows in
 // global memory (the first key tile stores without reading).  One workgroup per (sequence, head) owns those rows and the key tiles
-// follow each other in a fixed order: no atomics, bit-reproducible.  Two workgroups per CU: the 52 KB of LDS would allow the three the
-// other attention kernels run with, 170 registers do not (131 spilled VGPRs: backward 26.5 ms against 21.0 with two workgroups of
-// 256-register waves).  Stress configuration: backward 24.2 -> 21.0 ms (73.5 -> 84.9 TFLOP/s of algorithmic work).
-template <int PF>      // next query tile requested under the dQ^T product: 0 no, 1 the Q tile, 2 Q and dO tiles
-__global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
+// follow each other in a fixed order: no atomics, bit-reproducible.  THREE workgroups per CU since round 5 (52 KB of LDS each; 166
+// registers): in round 4 the kernel needed 256 registers at two per CU and spilled 131 at three -- most of that was thread-index
+// arithmetic kept alive across the loops (cf_kernels.h, CF_TID_OPAQUE) and 64-bit per-lane base addresses (now scalar base + 32-bit lane
+// offset).  Stress configuration: backward 24.2 (split kernels) -> 21.0 (one pass) -> 19.4 (statistics in LDS) -> 18.2 ms (three per CU):
+// 73.5 -> 98 TFLOP/s of algorithmic work.
+__global__ __launch_bounds__(256, 3) void k_attn_bwd(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
     __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
     __shared__ __attribute__((aligned(16))) float Pt[4][16 * kALd];     // per-wave patches: p^T / ds^T [16 keys][64 rows]
@@ -455,13 +456,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
         // this wave's 16 keys as the A operand of S^T = K Q^T and dP^T = V dO^T
         const int key_a = k0 + 16 * w + r;
         float4 kf[4], vf[4];
-        {
-            const float* kp = a.k + ((size_t)n * a.Lk + min(key_a, a.Lk - 1)) * a.ldk + h * kADh;
-            const float* vp = a.v + ((size_t)n * a.Lk + min(key_a, a.Lk - 1)) * a.ldv + h * kADh;
+        {   // (scalar base of the (sequence, head) + 32-bit lane offset: as 64-bit per-lane addresses these bases were the kernel's only spills)
+            const float* kp = lane_at(sbase(a.k + (size_t)n * a.Lk * a.ldk + h * kADh, 0), (unsigned)(min(key_a, a.Lk - 1) * a.ldk + 4 * qd) * 4u);
+            const float* vp = lane_at(sbase(a.v + (size_t)n * a.Lk * a.ldv + h * kADh, 0), (unsigned)(min(key_a, a.Lk - 1) * a.ldv + 4 * qd) * 4u);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                kf[u] = key_a < a.Lk ? ldg4(kp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
-                vf[u] = key_a < a.Lk ? ldg4(vp + 16 * u + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+                kf[u] = key_a < a.Lk ? ldg4(kp + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                vf[u] = key_a < a.Lk ? ldg4(vp + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         // column 16 w + r of the K tile as the A operand of dQ^T = K^T dS^T: kt[u] = K[keys k0 + 16 u + 4 qd .. + 3][that column]
@@ -539,11 +540,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
             __builtin_amdgcn_wave_barrier();
             attn_mma_nn(&Pt[w][0], Qs, dk);                   // dK += dS^T . Q
             __syncthreads();                                  // all four dS^T patches are written; nobody reads Qs / Gs any more
-            // the next query tile is requested here, behind the barrier that freed Qs / Gs, and lands under the dQ^T product
             AttnTileRegs qr, gr;
             const bool more = q0 + kABq < a.Lq;
-            if (PF >= 1 && more) attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
-            if (PF >= 2 && more) attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
             float4 svn = make_float4(0.f, 0.f, 0.f, 0.f);
             if (more) svn = stat_fetch(q0 + kABq);
             f32x4 dq[4];                                      // dQ^T: rows = head columns 16 w + 4 qd + g, columns = query row 16 t + r
@@ -565,9 +563,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd(AttnArgs a) {
                     stg4(dqb + (size_t)row * a.ldq, v);
                 }
             }
-            if (more) {
-                if (PF < 1) attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
-                if (PF < 2) attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
+            if (more) {      // (a register prefetch of the next tile under the dQ^T product lost in rounds 4 and 5: 19.1 against 18.2 ms)
+                attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
+                attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
                 attn_put(Qs, qr);
                 attn_put(Gs, gr);
                 if (threadIdx.x < kABq) *reinterpret_cast<float4*>(Ss + threadIdx.x * 4) = svn;

@@ -2360,7 +2360,6 @@ __global__ __launch_bounds__(256) void k_dense_cs_tables(DenseCsTab a) {
 #include "cf_head_ride.h"
 #include "cf_reg_fused.h"
 #include "cf_reg8.h"
-#include "cf_regq.h"
 #include "cf_attc2.h"
 #include "cf_attc1.h"
 #include "cf_gather.h"

@@ -5,7 +5,7 @@ Small-batch tests run the centre-row attention with one region per workgroup (k_
 idle; at bsz 64 the Pairwise launches take the eight-regions-per-workgroup MFMA kernel (k_attc2<., 8>), the Regulation kernels
 run 192 workgroups and the weight-gradient tables are fully populated.  The oracle's forward + autograd of one 64-gene batch
 takes a few seconds on the host.  Switches (environment, read when a model is constructed): CF_ATTC1=0 puts the one-region
-launches back on the MFMA kernel, CF_REG8=0 selects the 256-thread Regulation kernels of round 1, CF_HEAD_RIDE=0 the prediction head as a launch of its own (matrix cores, 16 genes per
+launches back on the MFMA kernel, CF_REG_FUSED=0 runs the Regulation stack layer by layer on the stand-alone kernels instead of the fused 512-thread ones, CF_HEAD_RIDE=0 the prediction head as a launch of its own (matrix cores, 16 genes per
 workgroup) instead of at the tail of the Regulation forward launch (vector ALUs, one gene per workgroup), CF_REG_ROW0=0 the last Regulation
 layer over all T rows instead of the one row the head consumes (cf_reg8.h, b_run_row0) -- different code, same math."""
 import os
@@ -79,8 +79,8 @@ def test_bsz64_forward_loss_and_all_gradients_match_the_oracle(case):
     assert n == 334
 
 
-@pytest.mark.parametrize("env", [{"CF_ATTC1": "0"}, {"CF_REG8": "0"}, {"CF_HEAD_RIDE": "0"}, {"CF_REG_TEAM": "1"}, {"CF_REG_ROW0": "0"}],
-                         ids=["attc1_vs_attc2", "reg8_vs_reg4", "head_ride_vs_head_launch", "reg8_vs_team_forward", "last_layer_row0_vs_all_rows"])
+@pytest.mark.parametrize("env", [{"CF_ATTC1": "0"}, {"CF_REG_FUSED": "0"}, {"CF_HEAD_RIDE": "0"}, {"CF_REG_ROW0": "0"}],
+                         ids=["attc1_vs_attc2", "fused_regulation_vs_layer_by_layer", "head_ride_vs_head_launch", "last_layer_row0_vs_all_rows"])
 def test_bsz64_independent_kernel_implementations_agree(case, env):
     batch, P = case
     logits, loss, grads = _model_run({}, batch, P)
