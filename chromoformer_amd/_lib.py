@@ -15,6 +15,8 @@ FLAGS_PATH = LIB_PATH + ".flags"       # the CF_HIPCC_FLAGS the library was buil
 CSRC = os.path.join(_HERE, "csrc")
 MAX_RES = 3
 BUCKET_REG, BUCKET_PE = 1, 2
+BUCKET_REG_HI, BUCKET_REG_LO = 4, 8      # the Regulation bucket in halves (cf_reg_halves): upper layers + head, lower layers
+PART_REG_HI, PART_REG_LO = 8, 16        # cf_backward_part: the Regulation backward as two launches
 
 
 class cf_config(C.Structure):
@@ -81,6 +83,7 @@ SYMBOLS = {
     "cf_backward": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cf_backward_chain": (C.c_int, [C.c_void_p, C.POINTER(cf_batch), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "cf_backward_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "cf_reg_halves": (C.c_int, [C.c_void_p]),
     "cf_grad_bucket": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "cf_backward_reduce_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cf_adamw_step_part": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_int, C.c_void_p]),

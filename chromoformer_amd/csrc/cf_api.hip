@@ -181,15 +181,26 @@ static int build_layout(const cf_config& c, std::vector<PDesc>& v, cf_layout& la
     add(v, "fc_head.2.weight", c.n_out, c.d_head, true);
     add(v, "fc_head.2.bias", c.n_out, 0, true);
 
+    // Offsets: trainable tensors first -- Embedding, Pairwise (state_dict order), then the Regulation layers BELOW reg_layers / 2 of every
+    // resolution, then the layers from there up, then fc_head (three adjacent gradient buckets: cf_grad_bucket) --, never-trained ones behind.
+    // The TABLE stays in state_dict order; only where a tensor lies in the flat buffers follows the order its gradient becomes complete in.
+    const auto group = [&](const PDesc& p) {
+        if (!p.trainable) return 4;
+        if (p.name.rfind("fc_head.", 0) == 0) return 3;
+        if (p.name.rfind("regulation.", 0) != 0) return 0;
+        const size_t at = p.name.find(".transformer.layers.");
+        const int l = at == std::string::npos ? 0 : atoi(p.name.c_str() + at + 20);
+        return l < c.reg_layers / 2 ? 1 : 2;
+    };
     long long off = 0, elems = 0;
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 5; ++pass) {
         for (auto& p : v) {
-            if (p.trainable != (pass == 0)) continue;
+            if (group(p) != pass) continue;
             p.offset = off;
             off += (p.numel + 3) / 4 * 4;     // 16-byte aligned tensors
             elems += p.numel;
         }
-        if (pass == 0) lay.n_active = off;
+        if (pass == 3) lay.n_active = off;
     }
     lay.n_tensors = (int)v.size();
     lay.n_total = off;
@@ -293,6 +304,8 @@ struct cf_handle {
     int xcd_map = 1;                          // XCD-aware placement of the Regulation workgroups (CF_XCD_MAP=0 turns it off)
     int n_wg_r = 0, n_cs_r = 0;               // leading entries of wg_tiles / cs_tiles that belong to the Regulation + head bucket
     long long bucket_split = 0;               // flat offset of the first Regulation parameter (bucket boundary)
+    long long bucket_split_hi = 0;            // ... of the first parameter of the upper Regulation layers (CF_BUCKET_REG_HI = [this, n_active))
+    int n_wg_hi = 0, n_cs_hi = 0;             // tiles of CF_BUCKET_REG_HI at the front of the tables
     float *featc[kMaxRes], *ex0[kMaxRes], *edx0[kMaxRes], *edout[kMaxRes];
     CentreBuf E[kMaxRes];
     float *xp0[kMaxRes], *dxp0[kMaxRes], *resid[kMaxRes];
@@ -609,8 +622,8 @@ static int build_tables(cf_handle* h) {
     const int S = c.i_max, T = S + 1, F = c.n_feats;
     // two gradient buckets: `wg` / `cs` take Embedding + Pairwise (ready after the whole backward chain), `wgR` / `csR`
     // the Regulation stacks and the head (ready after k_reg_bwd, i.e. before Pairwise + Embedding backward starts)
-    std::vector<WgTile> wg, wgR;
-    std::vector<CsTile> cs, csR;
+    std::vector<WgTile> wg, wgHi, wgLo;
+    std::vector<CsTile> cs, csHi, csLo;
     std::vector<LpJob> lpj;
     for (int r = 0; r < c.n_res; ++r) {
         const int bs = c.binsizes[r];
@@ -660,7 +673,9 @@ static int build_tables(cf_handle* h) {
                 else push_post_cs(cs, h, b.partial, c.pair_dff, S, lp + "self_att.", lp + "ff.");
             }
         }
-        for (int l = 0; l < c.reg_layers; ++l) {   // Regulation
+        for (int l = 0; l < c.reg_layers; ++l) {   // Regulation: the upper half of the stack (complete first in the backward pass) and the lower one
+            std::vector<WgTile>& wgR = l >= c.reg_layers / 2 ? wgHi : wgLo;
+            std::vector<CsTile>& csR = l >= c.reg_layers / 2 ? csHi : csLo;
             const std::string lp = fmt("regulation.%d.transformer.layers.%d.", bs, l);
             const RegBuf& b = h->R[r][l];
             const int dff = c.reg_dff;
@@ -684,10 +699,10 @@ static int build_tables(cf_handle* h) {
             push_cs(csR, b.dgam, c.reg_heads, c.reg_heads, 1, 1, h->G_(lp + "self_att.gamma_f"));
         }
     }
-    push_wg(wgR, wg1(h->dh1, c.d_head, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, c.d_head, 3 * kD));
-    push_wg(wgR, wg1(h->dlogits, c.n_out, h->h1, c.d_head, 1, h->G_("fc_head.2.weight"), c.d_head, c.n_out, c.d_head));
-    push_cs(csR, h->dh1, c.d_head, c.d_head, 1, 1, h->G_("fc_head.0.bias"));
-    push_cs(csR, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
+    push_wg(wgHi, wg1(h->dh1, c.d_head, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, c.d_head, 3 * kD));
+    push_wg(wgHi, wg1(h->dlogits, c.n_out, h->h1, c.d_head, 1, h->G_("fc_head.2.weight"), c.d_head, c.n_out, c.d_head));
+    push_cs(csHi, h->dh1, c.d_head, c.d_head, 1, 1, h->G_("fc_head.0.bias"));
+    push_cs(csHi, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
 
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
     h->n_lp = (int)lpj.size();
@@ -718,10 +733,14 @@ static int build_tables(cf_handle* h) {
             if (covered != p.numel) h->keep_tiled_ok = false;
         }
     }
-    h->n_wg_r = (int)wgR.size();
-    h->n_cs_r = (int)csR.size();
-    wg.insert(wg.begin(), wgR.begin(), wgR.end());      // table layout: [Regulation + head | Embedding + Pairwise]
-    cs.insert(cs.begin(), csR.begin(), csR.end());
+    h->n_wg_hi = (int)wgHi.size();
+    h->n_cs_hi = (int)csHi.size();
+    h->n_wg_r = (int)(wgHi.size() + wgLo.size());
+    h->n_cs_r = (int)(csHi.size() + csLo.size());
+    wg.insert(wg.begin(), wgLo.begin(), wgLo.end());      // table layout: [upper Regulation layers + head | lower Regulation layers | Embedding + Pairwise]
+    wg.insert(wg.begin(), wgHi.begin(), wgHi.end());
+    cs.insert(cs.begin(), csLo.begin(), csLo.end());
+    cs.insert(cs.begin(), csHi.begin(), csHi.end());
     h->wg_flops_per_gene = 0.0;
     for (const WgTile& t : wg) {
         if (t.n0 || t.k0) continue;      // count each job once
@@ -801,6 +820,12 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
             return fail("cf_create: parameter layout does not split into [embed, pairwise | regulation, head] ranges");
         }
         h->bucket_split = split;
+        h->bucket_split_hi = h->lay.n_active;
+        for (const PDesc& p : h->table) {
+            if (!p.trainable || p.name.rfind("regulation.", 0) != 0) continue;
+            const size_t at = p.name.find(".transformer.layers.");
+            if (at != std::string::npos && atoi(p.name.c_str() + at + 20) >= h->cfg.reg_layers / 2) h->bucket_split_hi = std::min(h->bucket_split_hi, p.offset);
+        }
     }
     {
         // units of the Embedding + Pairwise weights first (needed by the first kernels of a forward pass), Regulation + head behind
@@ -1504,6 +1529,8 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         memset(&ra.head, 0, sizeof ra.head);
         if (ride) ra.head = *ride;
         ra.row0_last = h->reg_row0 ? 1 : 0;
+        ra.l_top = c.reg_layers - 1;
+        ra.l_bot = 0;
         if (launch_reg(h, "k_reg_fwd", reg_kernel(false, c.reg_dff, save != 0), dim3(8 * ((B * nres + 7) / 8)), reg8_fwd_smem(c.reg_dff), ra, st)) return -1;
     }
     for (int l = 0; l < (h->reg_fused ? 0 : c.reg_layers); ++l) {   // Regulation layers, unfused fallback (T > 11)
@@ -1689,8 +1716,17 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             LAUNCH_CHECK("k_head_bwd");
         }
     }
-    if ((parts & 2) && h->reg_fused) {
+    if ((parts & (CF_PART_REG_HI | CF_PART_REG_LO)) && !(parts & 2)) {      // the Regulation backward in halves (data-parallel schedule, cf_reg_halves)
+        if (!cf_reg_halves(h)) return fail("cf_backward_part: this model's Regulation backward does not come in halves (cf_reg_halves)");
+        if ((parts & (CF_PART_REG_HI | CF_PART_REG_LO)) == (CF_PART_REG_HI | CF_PART_REG_LO)) parts |= 2;
+    }
+    if ((parts & (2 | CF_PART_REG_HI | CF_PART_REG_LO)) && h->reg_fused) {
+        const int half = c.reg_layers / 2;
+        const int l_top = (parts & 2) || (parts & CF_PART_REG_HI) ? c.reg_layers - 1 : half - 1;
+        const int l_bot = (parts & 2) || (parts & CF_PART_REG_LO) ? 0 : half;
         RegArgs ra;
+        ra.l_top = l_top;
+        ra.l_bot = l_bot;
         ra.tab = h->reg_tab;
         ra.n_layers = c.reg_layers;
         ra.T = T;
@@ -1976,10 +2012,23 @@ static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUC
         hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
         LAUNCH_CHECK("k_wgrad_lp");
     }
-    for (int bk = 0; bk < 2; ++bk) {
-        if (!(buckets & (bk == 0 ? CF_BUCKET_REG : CF_BUCKET_PE))) continue;
-        const int w0 = bk == 0 ? 0 : h->n_wg_r, wn = bk == 0 ? h->n_wg_r : h->n_wg - h->n_wg_r;
-        const int c0 = bk == 0 ? 0 : h->n_cs_r, cn = bk == 0 ? h->n_cs_r : h->n_cs - h->n_cs_r;
+    if (buckets & CF_BUCKET_REG) buckets |= CF_BUCKET_REG_HI | CF_BUCKET_REG_LO;
+    if ((buckets & (CF_BUCKET_REG_HI | CF_BUCKET_REG_LO)) == (CF_BUCKET_REG_HI | CF_BUCKET_REG_LO)) buckets |= CF_BUCKET_REG;
+    for (int bk = 0; bk < 4; ++bk) {      // the whole Regulation + head bucket (one launch), else its halves; Embedding + Pairwise
+        int w0, wn, c0, cn;
+        if (bk == 0) {
+            if (!(buckets & CF_BUCKET_REG)) continue;
+            w0 = 0, wn = h->n_wg_r, c0 = 0, cn = h->n_cs_r;
+        } else if (bk == 1) {
+            if ((buckets & CF_BUCKET_REG) || !(buckets & CF_BUCKET_REG_HI)) continue;
+            w0 = 0, wn = h->n_wg_hi, c0 = 0, cn = h->n_cs_hi;
+        } else if (bk == 2) {
+            if ((buckets & CF_BUCKET_REG) || !(buckets & CF_BUCKET_REG_LO)) continue;
+            w0 = h->n_wg_hi, wn = h->n_wg_r - h->n_wg_hi, c0 = h->n_cs_hi, cn = h->n_cs_r - h->n_cs_hi;
+        } else {
+            if (!(buckets & CF_BUCKET_PE)) continue;
+            w0 = h->n_wg_r, wn = h->n_wg - h->n_wg_r, c0 = h->n_cs_r, cn = h->n_cs - h->n_cs_r;
+        }
         if (!kMergeReduce || h->timed == "k_wgrad" || h->timed == "k_colsum") {      // timed separately
             h->time_mark("k_wgrad", st);
             hipLaunchKernelGGL(k_wgrad, dim3(xcd_grid(wn)), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, B, h->xcd_reduce);
@@ -2037,7 +2086,9 @@ extern "C" int cf_backward_reduce(cf_handle* h, int B, void* stream) {
 extern "C" int cf_backward_reduce_part(cf_handle* h, int B, int buckets, void* stream) {
     if (!h || !h->grads) return fail("cf_backward_reduce_part: no gradient buffer bound");
     if (B < 1 || B > h->cfg.max_batch) return fail("cf_backward_reduce_part: bad batch size %d", B);
-    if (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE)) return fail("cf_backward_reduce_part: bad bucket mask %d", buckets);
+    if (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE | CF_BUCKET_REG_HI | CF_BUCKET_REG_LO)) return fail("cf_backward_reduce_part: bad bucket mask %d", buckets);
+    if ((buckets & (CF_BUCKET_REG_HI | CF_BUCKET_REG_LO)) && !(buckets & CF_BUCKET_REG) && !cf_reg_halves(h))
+        return fail("cf_backward_reduce_part: this model's Regulation bucket does not come in halves (cf_reg_halves)");
     const long long launches0 = g_launches;
     const int rc = reduce_impl(h, B, (hipStream_t)stream, buckets);
     h->n_bwd += (int)(g_launches - launches0);
@@ -2045,6 +2096,7 @@ extern "C" int cf_backward_reduce_part(cf_handle* h, int B, int buckets, void* s
     return rc;
 }
 
+extern "C" int cf_reg_halves(cf_handle* h) { return h && h->reg_fused && h->cfg.reg_layers >= 2 ? h->cfg.reg_layers / 2 : 0; }
 extern "C" int cf_grad_bucket(cf_handle* h, int bucket, long long* offset, long long* numel) {
     if (!h || !offset || !numel) return fail("cf_grad_bucket: null argument");
     if (bucket == CF_BUCKET_PE) {
@@ -2053,8 +2105,14 @@ extern "C" int cf_grad_bucket(cf_handle* h, int bucket, long long* offset, long 
     } else if (bucket == CF_BUCKET_REG) {
         *offset = h->bucket_split;
         *numel = h->lay.n_active - h->bucket_split;
+    } else if (bucket == CF_BUCKET_REG_HI) {
+        *offset = h->bucket_split_hi;
+        *numel = h->lay.n_active - h->bucket_split_hi;
+    } else if (bucket == CF_BUCKET_REG_LO) {
+        *offset = h->bucket_split;
+        *numel = h->bucket_split_hi - h->bucket_split;
     } else {
-        return fail("cf_grad_bucket: bucket must be CF_BUCKET_REG or CF_BUCKET_PE");
+        return fail("cf_grad_bucket: bucket must be CF_BUCKET_PE, CF_BUCKET_REG, CF_BUCKET_REG_HI or CF_BUCKET_REG_LO");
     }
     return 0;
 }
@@ -2211,9 +2269,13 @@ static int adam_hyper(cf_handle* h, float lr, float beta1, float beta2, float ep
 // the buckets are adjacent ranges of the flat buffers: [0, split) = Embedding + Pairwise, [split, n_active) = Regulation + head;
 // every tensor starts 16-byte aligned, so both bounds are multiples of 4
 static int adam_range(cf_handle* h, int buckets, long long& lo, long long& n4, int& grid) {
-    if (!buckets || (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE))) return fail("cf_adamw_step_part: bad bucket mask %d", buckets);
-    lo = (buckets & CF_BUCKET_PE) ? 0 : h->bucket_split;
-    const long long hi = (buckets & CF_BUCKET_REG) ? h->lay.n_active : h->bucket_split;
+    if (!buckets || (buckets & ~(CF_BUCKET_REG | CF_BUCKET_PE | CF_BUCKET_REG_HI | CF_BUCKET_REG_LO))) return fail("cf_adamw_step_part: bad bucket mask %d", buckets);
+    if (buckets & CF_BUCKET_REG) buckets |= CF_BUCKET_REG_HI | CF_BUCKET_REG_LO;
+    // the buckets lie [PE | REG_LO | REG_HI]: the mask must name an adjacent run of them
+    const bool pe = buckets & CF_BUCKET_PE, lo_ = buckets & CF_BUCKET_REG_LO, hi_ = buckets & CF_BUCKET_REG_HI;
+    if (pe && hi_ && !lo_) return fail("cf_adamw_step_part: the buckets of mask %d are not adjacent in the flat buffers", buckets);
+    lo = pe ? 0 : (lo_ ? h->bucket_split : h->bucket_split_hi);
+    const long long hi = hi_ ? h->lay.n_active : (lo_ ? h->bucket_split_hi : h->bucket_split);
     n4 = (hi - lo) / 4;
     grid = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
     return 0;

@@ -30,11 +30,12 @@ struct HeadRide {
     int* cnt;                    // [B] arrivals per gene (zeroed by workgroup 0 of the forward launch at its start)
 };
 
-// Start of the Regulation forward launch, workgroup 0: a repair, not a protocol step -- every gene's last arriver rewinds the gene's counter
-// itself (head_ride_tail), so the counters ARE zero here unless a launch was aborted.  (An arrival needs the whole stack: ~100 us later.)
-__device__ __forceinline__ void head_ride_begin(const HeadRide& hd, const int B) {
-    for (int i = threadIdx.x; i < B; i += blockDim.x) __hip_atomic_store(hd.cnt + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// The per-gene arrival counters are MONOTONIC (round 5): a launch adds n_res to each, the workgroup that reads a value congruent to n_res - 1
+// runs the gene's head -- nobody ever writes a counter but the arrivals themselves.  (Round 4 had workgroup 0 zero them at the start of the
+// launch, "100 us before anybody arrives", and this round first let the last arriver rewind its counter: with two processes on one device --
+// the two-rank tests -- a gene's head was skipped about once in ten runs, stale logits and all; with CF_HEAD_RIDE=0 never.  Zeroed at cf_create;
+// 2^32 is not a multiple of 3, so a counter is good for 1.4e9 launches.)
+__device__ __forceinline__ void head_ride_begin(const HeadRide&, const int) {}
 // The Regulation BACKWARD launch, one wave of workgroup 0: the mean loss of the batch, summed in gene order (the genes' losses were
 // written by whichever workgroup ran each gene's head; a launch boundary lies in between).  The first 64 values are requested at the
 // start of the launch (head_ride_loss_request) and added at its end: as the first thing the wave does, the cold loads held its whole
@@ -89,10 +90,7 @@ __device__ __forceinline__ void head_ride_tail(const HeadRide& hd, const int g, 
     __syncthreads();
     if (tid == 0) *flag = __hip_atomic_fetch_add(hd.cnt + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*flag != n_res - 1) return;
-    // the last arriver is the only workgroup that still looks at the gene's counter: it puts it back to zero for the next launch itself.  (The
-    // zero fill at the start of the launch, head_ride_begin, stays as the repair after an aborted launch; nothing depends on its timing.)
-    if (tid == 0) __hip_atomic_store(hd.cnt + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)*flag % (unsigned)n_res != (unsigned)n_res - 1u) return;
     // ---- the gene's last workgroup: forward
     if (tid < K) hs[tid] = __hip_atomic_load(hd.hin + (size_t)g * K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int n = nt_row<kD, K>(0);

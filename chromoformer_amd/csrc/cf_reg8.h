@@ -617,9 +617,10 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
     float* dss = dos + 16 * 36;                          //               ds      [16][20]
     const RegLayerDev* tab = a.tab + (size_t)r * a.n_layers;
     const float scale = sqrtf((float)kRDh);
+    const bool from_top = a.l_top + 1 == a.n_layers;      // (a launch over the lower layers starts from what the one above it stored as d(layer input))
     {
-        const float* d0 = load_layer(tab + a.n_layers - 1).dxout + (size_t)row0 * kD;
-        const int Tin = a.row0_last ? 1 : T;      // (only token 0 of the stack's output has a gradient, see b_run_row0)
+        const float* d0 = load_layer(tab + a.l_top).dxout + (size_t)row0 * kD;
+        const int Tin = a.row0_last && from_top ? 1 : T;      // (only token 0 of the stack's output has a gradient, see b_run_row0)
         for (int i = tid; i < kTile * (kD / 4); i += 512) {
             const int row = i >> 5, c4 = i & 31;
             float4 t = f4z();
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
             }
         }
     };
-    request_ln2(load_layer(tab + a.n_layers - 1));
+    request_ln2(load_layer(tab + a.l_top));
     __syncthreads();
     auto layer = [&](auto r0_c, const int l) __attribute__((always_inline)) {
         constexpr bool r0 = decltype(r0_c)::value;      // the last layer: one live row above the attention (see b_run_row0)
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         CF_STAMP8(5);
         __syncthreads();
         // ---- d(layer input) = dt1 + d(q|k|v|gate) Watt   (K = 1024: 32 units, four accumulators)
-        if (l > 0) request_ln2(load_layer(tab + l - 1));
+        if (l > a.l_bot) request_ln2(load_layer(tab + l - 1));
         {
             f32x4 acc[4];
             zero_acc(acc);
@@ -889,8 +890,9 @@ __global__ __launch_bounds__(512) void k_reg8_bwd(RegArgs a) {
         CF_STAMP8(6);
         __syncthreads();
     };
-    if (a.row0_last) layer(std::true_type{}, a.n_layers - 1);
-    for (int l = a.n_layers - 1 - (a.row0_last ? 1 : 0); l >= 0; --l) layer(std::false_type{}, l);
+    const bool top_row0 = a.row0_last && from_top;
+    if (top_row0) layer(std::true_type{}, a.l_top);
+    for (int l = a.l_top - (top_row0 ? 1 : 0); l >= a.l_bot; --l) layer(std::false_type{}, l);
     if (ride_loss) head_ride_loss(a.head, a.B, ride_l);
 }
 

@@ -25,6 +25,8 @@ struct RegArgs {
     unsigned long long* tdbg;        // optional: shader-clock stamps of workgroup (0,0), 16 per layer
     HeadRide head;                   // forward (cf_reg8.h): the gene's prediction head at the tail of its last workgroup (cf_head_ride.h)
     int row0_last;                   // cf_reg8.h: only token 0 of the LAST layer's output is consumed (net.py:375): that layer computes row 0 only
+    int l_top, l_bot;                // backward: the launch walks layers l_top down to l_bot (the whole stack: n_layers - 1 .. 0; the data-parallel step
+                                     // runs the upper and the lower half as two launches, so that the upper half's gradients can be on the wire earlier)
 };
 
 constexpr int kQkLd = kRW + 4;

@@ -194,7 +194,7 @@ class Trainer:
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
                  overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None, rider_tiles=None,
-                 keep_tiled=None):
+                 keep_tiled=None, dp_halves=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -216,8 +216,19 @@ class Trainer:
         torch.cuda.synchronize(model._device)      # parameter upload / buffer fills of the model ran on the default stream
         # four events, created once: a fresh torch.cuda.Event per step is a hipEventCreate on the critical path of the host loop
         self._ev_fork, self._ev_join, self._ev_late, self._ev_done = (torch.cuda.Event() for _ in range(4))
+        # Data parallel, round 5: the Regulation + head bucket goes on the wire in two HALVES.  Its all-reduce (16.6 MB, ~0.17 ms per-link
+        # bound on eight ranks) is the critical path of the step; as one piece it starts behind the whole Regulation backward and the
+        # reduction of 1,008 tiles (~180 us after that launch began).  With the backward as two launches -- upper half of the layers, then
+        # the lower half -- the upper half's + the head's tiles are reduced and sent while the lower half still runs (~90 us earlier),
+        # the lower half's follow under the Pairwise + Embedding backward.  Same gradients, same bits (tests/test_engine_gpu.py);
+        # dp_halves=False / CF_DP_HALVES=0: the two-bucket schedule of rounds 2-4.
+        if dp_halves is None:
+            import os
+            dp_halves = os.environ.get("CF_DP_HALVES", "1") != "0"
+        self.halves = bool(dp_halves) and self.dp and not opt_in_graph and int(self._L.cf_reg_halves(model._handle)) > 0
+        self._ev_mid = torch.cuda.Event()
         self._buckets = {}
-        for b in (_lib.BUCKET_REG, _lib.BUCKET_PE):
+        for b in (_lib.BUCKET_REG, _lib.BUCKET_PE) + ((_lib.BUCKET_REG_HI, _lib.BUCKET_REG_LO) if self.halves else ()):
             off, n = C.c_longlong(), C.c_longlong()
             _lib.check(self._L.cf_grad_bucket(model._handle, b, C.byref(off), C.byref(n)), "cf_grad_bucket")
             self._buckets[b] = model._gflat[off.value: off.value + n.value]
@@ -316,9 +327,17 @@ class Trainer:
         # (cf_head_rides), else left to cf_backward_part, where the three are one launch; part 1 below is a no-op in the first case
         _lib.check(L.cf_forward_train(m._handle, C.byref(slot.struct), slot.logits.data_ptr(), slot.label.data_ptr(), 1.0 / self.world,
                                       slot.loss.data_ptr(), st), "cf_forward_train")
+        if self.halves:      # data parallel: head + upper half of the Regulation layers, and their gradient bucket
+            self._part(slot, st, 1 | _lib.PART_REG_HI)
+            self._reduce(slot, st, _lib.BUCKET_REG_HI)
+            return
         self._part(slot, st, 3)
         if reduce:
             self._reduce(slot, st, _lib.BUCKET_REG)
+
+    def _seq_mid(self, slot, st):       # data parallel in halves: lower half of the Regulation layers and their gradient bucket
+        self._part(slot, st, _lib.PART_REG_LO)
+        self._reduce(slot, st, _lib.BUCKET_REG_LO)
 
     def _seq_main(self, slot, st):      # single GPU, merged optimiser: everything up to the Pairwise + Embedding backward (its bucket is reduced beside AdamW)
         if self.overlap_reduce:
@@ -347,6 +366,8 @@ class Trainer:
         on the side stream under the Pairwise + Embedding backward -- an HBM stream next to latency-bound kernels."""
         side = self.side.cuda_stream
         self._seq_early(slot, st)
+        if self.halves:
+            self._seq_mid(slot, st)
         if opt:
             if self.overlap_opt:
                 self._wait(side, st)
@@ -410,7 +431,8 @@ class Trainer:
             if pre:      # (the captured trunk launch advances the cursor because a gathered batch is waiting at capture time)
                 _lib.check(L.cf_gather_batch_only(*gargs), "cf_gather_batch_only")
                 feed.pregathered = True
-            slot.graph = {"first": self._capture(first, slot, st), "late": self._capture(self._seq_late, slot, st) if self.dp else None}
+            slot.graph = {"first": self._capture(first, slot, st), "mid": self._capture(self._seq_mid, slot, st) if self.halves else None,
+                          "late": self._capture(self._seq_late, slot, st) if self.dp else None}
         if feed is not None:
             feed.taken += 1
         oig = self.opt_in_graph
@@ -465,23 +487,38 @@ class Trainer:
                 self._launch(slot.graph["first"], st)
             else:
                 self._seq_early(slot, st)
-            def early_allreduce():      # the early bucket is complete: all-reduce it on the side stream
-                self._ev_fork.record(self.stream)
+            def early_allreduce(bucket=_lib.BUCKET_REG, ev=None, last=True):      # an early bucket is complete: all-reduce it on the side stream
+                ev = ev or self._ev_fork
+                ev.record(self.stream)
                 with torch.cuda.stream(self.side):
-                    self.side.wait_event(self._ev_fork)
-                    torch.distributed.all_reduce(self._buckets[_lib.BUCKET_REG], group=self.pg)     # SUM; dloss carries 1/world
-                    if self.overlap_opt:
-                        self._opt(_lib.BUCKET_REG, self.side.cuda_stream)
-                    self._ev_join.record(self.side)
+                    self.side.wait_event(ev)
+                    torch.distributed.all_reduce(self._buckets[bucket], group=self.pg)     # SUM; dloss carries 1/world
+                    if last:
+                        if self.overlap_opt:
+                            self._opt(_lib.BUCKET_REG, self.side.cuda_stream)
+                        self._ev_join.record(self.side)
 
-            if self.overlap_allreduce:
+            if self.halves:             # the upper half + head are on the wire while the lower half's backward runs
+                if self.overlap_allreduce:
+                    early_allreduce(_lib.BUCKET_REG_HI, self._ev_fork, last=False)
+                if self.use_graph:
+                    self._launch(slot.graph["mid"], st)
+                else:
+                    self._seq_mid(slot, st)
+                if self.overlap_allreduce:
+                    early_allreduce(_lib.BUCKET_REG_LO, self._ev_mid, last=True)
+            elif self.overlap_allreduce:
                 early_allreduce()       # ... under the rest of the backward pass
             if self.use_graph:
                 self._launch(slot.graph["late"], st)
             else:
                 self._seq_late(slot, st)
-            if not self.overlap_allreduce:
-                early_allreduce()       # ... behind it (serialised schedule)
+            if not self.overlap_allreduce:      # ... behind it (serialised schedule)
+                if self.halves:
+                    early_allreduce(_lib.BUCKET_REG_HI, self._ev_fork, last=False)
+                    early_allreduce(_lib.BUCKET_REG_LO, self._ev_mid, last=True)
+                else:
+                    early_allreduce()
             if oig:
                 torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
                 self._opt(_lib.BUCKET_PE, st)

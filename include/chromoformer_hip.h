@@ -148,6 +148,19 @@ int cf_backward_reduce(cf_handle* h, int B, void* stream);
  *   cf_backward_reduce_part -- cf_backward_reduce restricted to a bucket mask. */
 #define CF_BUCKET_REG 1
 #define CF_BUCKET_PE 2
+/* Round 5: the Regulation bucket in two halves, for a data-parallel caller that wants bytes on the wire while the backward pass still runs.
+ * Trainable tensors lie [Embedding | Pairwise | Regulation layers below n_layers / 2 (every resolution) | the layers from there up | fc_head]
+ * in the flat buffers (cf_param_layout reports every offset; the state_dict order of the table is unchanged):
+ *   CF_BUCKET_REG_HI = upper Regulation layers + fc_head -- complete after cf_backward_part(parts = 1 | CF_PART_REG_HI);
+ *   CF_BUCKET_REG_LO = lower Regulation layers           -- complete after cf_backward_part(parts = CF_PART_REG_LO);
+ *   CF_BUCKET_REG    = both (one adjacent range), as before.
+ * cf_reg_halves(h) returns the first layer of the upper half when the model's Regulation backward can run as two launches (the fused
+ * kernels, two layers or more), else 0: then only CF_BUCKET_REG / parts = 2 exist. */
+#define CF_BUCKET_REG_HI 4
+#define CF_BUCKET_REG_LO 8
+#define CF_PART_REG_HI 8
+#define CF_PART_REG_LO 16
+int cf_reg_halves(cf_handle* h);
 int cf_grad_bucket(cf_handle* h, int bucket, long long* offset, long long* numel);
 int cf_backward_reduce_part(cf_handle* h, int B, int buckets, void* stream);
 /* cf_backward_chain in pieces (bit mask `parts`: 1 = loss + head, 2 = Regulation stack, 4 = Pairwise +

@@ -92,6 +92,7 @@ def test_graph_embedded_events_time_every_replay():
 
 
 def test_grad_buckets_partition_the_active_range():
+    import ctypes as C
     from chromoformer_amd import ChromoformerClassifier, _lib
     from chromoformer_amd.engine import Trainer
     model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
@@ -103,6 +104,20 @@ def test_grad_buckets_partition_the_active_range():
     names = [d["name"] for d in model._table if d["trainable"] and d["offset"] >= pe.numel()]
     assert names and all(n.startswith(("regulation.", "fc_head.")) for n in names)
     assert reg.numel() > 3 * pe.numel()          # the early bucket carries most of the bytes
+    # ... and the Regulation + head bucket in halves: [lower layers | upper layers + head], adjacent, the upper half named by layer index
+    L, off, n = _lib.lib(), C.c_longlong(), C.c_longlong()
+    half = L.cf_reg_halves(model._handle)
+    assert half == 3
+    _lib.check(L.cf_grad_bucket(model._handle, _lib.BUCKET_REG_LO, C.byref(off), C.byref(n)), "cf_grad_bucket")
+    lo = (off.value, n.value)
+    _lib.check(L.cf_grad_bucket(model._handle, _lib.BUCKET_REG_HI, C.byref(off), C.byref(n)), "cf_grad_bucket")
+    hi = (off.value, n.value)
+    assert lo[0] == pe.numel() and hi[0] == lo[0] + lo[1] and hi[0] + hi[1] == model.active_grads().numel()
+    for d in model._table:
+        if not d["trainable"] or not d["name"].startswith(("regulation.", "fc_head.")):
+            continue
+        upper = d["name"].startswith("fc_head.") or int(d["name"].split(".transformer.layers.")[1].split(".")[0]) >= half
+        assert (d["offset"] >= hi[0]) == upper, d["name"]
 
 
 def test_one_rank_rccl_all_reduce_in_the_step():
@@ -120,12 +135,21 @@ def test_one_rank_rccl_all_reduce_in_the_step():
         # serialised schedule: both all-reduces behind the whole backward pass (Trainer(overlap_allreduce=False) / CF_DP_OVERLAP=0)
         got4, loss4 = _run(use_graph=True, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=False)
         got5, loss5 = _run(use_graph=False, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=False, opt_in_graph=True)
+        # the schedules above send the Regulation + head bucket in two halves (round 5: the upper layers' gradients are on the wire while the
+        # lower half of the Regulation backward runs); the two-bucket schedule of rounds 2-4, overlapped and serialised, eager and replayed
+        more = [_run(use_graph=g, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=o, dp_halves=False)
+                for g, o in ((True, True), (False, True), (True, False))]
+        more.append(_run(use_graph=False, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=True))      # halves, eager
     finally:
         dist.destroy_process_group()
     assert loss == ref_loss and loss2 == ref_loss and loss3 == ref_loss and loss4 == ref_loss and loss5 == ref_loss
     for k in ref:
         assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], got2[k]) and torch.equal(ref[k], got3[k]), k
         assert torch.equal(ref[k], got4[k]) and torch.equal(ref[k], got5[k]), k
+    for sd, ls in more:
+        assert ls == ref_loss
+        for k in ref:
+            assert torch.equal(ref[k], sd[k]), k
 
 
 def test_riders_must_be_followed_by_the_fused_reduction_of_the_same_step():
