@@ -237,6 +237,7 @@ struct cf_handle {
     bool reg_row0 = true;                // ... whose last layer computes only what token 0 of its output needs (CF_REG_ROW0=0: all rows, the cross-check)
     bool keep_tiled_ok = false;          // (build_tables: the reduction tiles cover every tensor of that group)
     bool keep_tiled = false;             // cf_keep_tiled: the fused optimiser keeps the Embedding + Pairwise tiled copies fresh, forward passes do not re-tile them
+    int* tiled_map = nullptr;            // [bucket_split / 4]: where each flat float4 of the Embedding + Pairwise range lies in the tiled buffer (k_adamw_tiled)
     bool tiled_pe_fresh = false;         // ... and they ARE fresh (cleared by whatever else writes parameters: cf_bind, cf_params_changed, the separate AdamW launches)
     // Embedding stack over ALL promoter bins (cf_embed_full.h + the dense transformer layer): used by the model path when
     // embed.n_layers > 1 and by cf_embed_full; device buffers outside the arena, allocated on first need
@@ -733,6 +734,23 @@ static int build_tables(cf_handle* h) {
             if (covered != p.numel) h->keep_tiled_ok = false;
         }
     }
+    if (h->keep_tiled_ok) {      // the float4 map of the separate AdamW launch (data parallel): flat -> tiled, for the same tensors
+        std::vector<int> map((size_t)h->bucket_split / 4, -1);
+        for (const PDesc& p : h->table) {
+            const bool is_late = p.name.rfind("regulation.", 0) == 0 || p.name.rfind("fc_head.", 0) == 0;
+            if (is_late || !(p.ndim == 2 && p.shape[0] % 16 == 0 && p.shape[1] % 16 == 0 && p.trainable)) continue;
+            const int N = p.shape[0], K = p.shape[1];
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; k += 4) {
+                    const long long flat = p.offset + (long long)n * K + k;
+                    const long long til = p.offset + ((long long)(n / 16) * (K / 16) + k / 16) * 256 + (((k % 16) / 4) * 16 + n % 16) * 4;
+                    map[(size_t)(flat / 4)] = (int)(til / 4);
+                }
+        }
+        if (h->tiled_map) (void)hipFree(h->tiled_map);
+        HIP_TRY(hipMalloc(&h->tiled_map, map.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(h->tiled_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     h->n_wg_hi = (int)wgHi.size();
     h->n_cs_hi = (int)csHi.size();
     h->n_wg_r = (int)(wgHi.size() + wgLo.size());
@@ -930,6 +948,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
     if (h->wg_tiles) (void)hipFree(h->wg_tiles);
+    if (h->tiled_map) (void)hipFree(h->tiled_map);
     if (h->cs_tiles) (void)hipFree(h->cs_tiles);
     if (h->lp_jobs) (void)hipFree(h->lp_jobs);
     if (h->reg_tab) (void)hipFree(h->reg_tab);
@@ -2286,10 +2305,17 @@ extern "C" int cf_adamw_step_part(cf_handle* h, float lr, float beta1, float bet
     long long lo, n4;
     int grid;
     if (adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, hy) || adam_range(h, buckets, lo, n4, grid)) return -1;
-    if (buckets & CF_BUCKET_PE) h->tiled_pe_fresh = false;      // (this launch steps the parameters only, not their tiled copies)
+    // cf_keep_tiled: a launch over exactly the Embedding + Pairwise bucket writes the tiled copies of what it steps (k_adamw_tiled); any other
+    // range that touches that bucket steps the parameters only and leaves the copies stale
+    const bool tiled = h->keep_tiled && h->tiled_map && buckets == CF_BUCKET_PE;
+    if (buckets & CF_BUCKET_PE) h->tiled_pe_fresh = tiled;
     h->time_mark("k_adamw", (hipStream_t)stream);
-    hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
-                       h->v + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps);
+    if (tiled)
+        hipLaunchKernelGGL(k_adamw_tiled, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
+                           h->v + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps, (const int*)h->tiled_map, h->tiled);
+    else
+        hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, h->params + lo, (const float*)h->grads + lo, h->m + lo,
+                           h->v + lo, n4, hy.decay, hy.one_m_b1, hy.b2, hy.one_m_b2, hy.step_size, hy.bc2_sqrt, hy.eps);
     h->time_mark("k_adamw", (hipStream_t)stream);
     LAUNCH_CHECK("k_adamw");
     h->n_opt += 1;      // (reset when a backward pass starts: the optimiser launches of a step add up)

@@ -2228,6 +2228,33 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     adamw_range(p, g, m, v, n4, decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps, (long long)blockIdx.x * blockDim.x + threadIdx.x,
                 (long long)gridDim.x * blockDim.x);
 }
+// The same stream over the Embedding + Pairwise range with the stepped parameters ALSO written into their tiled copies (cf_keep_tiled
+// under data parallelism, where AdamW is a launch of its own behind the all-reduce): tmap[i] = float4 index of flat float4 i in the tiled
+// buffer, -1 where the tensor has no tiled copy.  A flat float4 W[n][4 j .. 4 j + 3] is one float4 of the tiled layout too (element
+// [q][r][0..3] of a 16 x 16 block), so the copy costs one 4-byte index load and one 16-byte store per float4.
+__global__ __launch_bounds__(256) void k_adamw_tiled(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, long long n4, float decay, float one_m_b1, float b2,
+                                                     float one_m_b2, float step_size, float bc2_sqrt, float eps, const int* __restrict__ tmap,
+                                                     float* __restrict__ tiled) {
+    const AdamFuse o{nullptr, nullptr, nullptr, nullptr, decay, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps, 0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        const int t = tmap[i];
+        float* pa = reinterpret_cast<float*>(&pp);
+        const float* ga = reinterpret_cast<const float*>(&gg);
+        float* ma = reinterpret_cast<float*>(&mm);
+        float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) adamw_elem(pa[k], ga[k], ma[k], va[k], o);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (t >= 0) reinterpret_cast<float4*>(tiled)[t] = pp;
+    }
+}
 // The gradient reductions of one bucket and the AdamW update of ANOTHER bucket's (already reduced) range in one launch: workgroups
 // [0, n_red) take the weight-gradient / column-sum tiles, the rest stream the optimiser state.  The Embedding + Pairwise bucket's
 // reduction is a launch of ~300 latency-bound tiles (21 us with most of the chip idle), the Regulation + head bucket's AdamW a pure

@@ -288,7 +288,10 @@ class Trainer:
         if keep_tiled is None:
             import os
             keep_tiled = os.environ.get("CF_KEEP_TILED", "1") != "0"
-        self.keep_tiled = model.keep_tiled(True) if (keep_tiled and self.fuse_opt) else (model.keep_tiled(False) and False)
+        # Data parallel (round 5): the separate AdamW launch over the Embedding + Pairwise bucket writes the tiled copies as well
+        # (k_adamw_tiled), so the mode -- and the step without a re-tiling launch in front -- holds there too.
+        tiled_dp = self.dp and not self.opt_in_graph
+        self.keep_tiled = model.keep_tiled(True) if (keep_tiled and (self.fuse_opt or tiled_dp)) else (model.keep_tiled(False) and False)
         self._t_ms, self._t_n = 0.0, 0
         _lib.check(self._L.cf_timing_select(model._handle, timed_kernel.encode() if timed_kernel else None), "cf_timing_select")
 

@@ -15,8 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path):
+@pytest.mark.parametrize("regression", [False, True], ids=["classifier", "regressor"])
+def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path, regression):
+    """(regressor: BASELINE.json configs[4], `--regression` through the sweep -- Chromoformer-reg per cell line and fold)"""
     from chromoformer_amd import sweep, train
+    extra = ["--regression"] if regression else []
     cfg = yaml.safe_load(open(os.path.join(ROOT, "chromoformer_amd", "configs", "default.yaml")))
     cfg["bsz"], cfg["num_epoch"] = 8, 2
     cfg_path = str(tmp_path / "cfg.yaml")
@@ -28,7 +31,7 @@ def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path):
     out_dir = str(tmp_path / "ckpts")
     argv = ["--meta-template", str(tmp_path / "data" / "{eid}" / "train.csv"), "--npy-dir-template", str(tmp_path / "data" / "{eid}" / "npy"),
             "-c", cfg_path, "--exp-id", "exp", "--conf", "1", "--eids", "E003", "E004", "--folds", "1", "--gpus", "1",
-            "--out-dir", out_dir, "--poll", "0.2"]
+            "--out-dir", out_dir, "--poll", "0.2"] + extra
     env_before = os.environ.get("PYTHONPATH")
     os.environ["PYTHONPATH"] = ROOT + (os.pathsep + env_before if env_before else "")
     try:
@@ -43,7 +46,7 @@ def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path):
         assert os.path.exists(ck) and os.path.exists(ck + ".done"), open(ck + ".log").read()[-2000:]
         direct = str(tmp_path / ("direct-%s.pt" % eid))
         assert train.main(["-o", direct, "-c", cfg_path, "--exp-id", "exp", "-m", str(tmp_path / "data" / eid / "train.csv"),
-                           "-d", str(tmp_path / "data" / eid / "npy"), "--fold", "1"]) == 0
+                           "-d", str(tmp_path / "data" / eid / "npy"), "--fold", "1"] + extra) == 0
         a, b = torch.load(ck, map_location="cpu", weights_only=False), torch.load(direct, map_location="cpu", weights_only=False)
         assert a["epoch"] == b["epoch"] == 1 and list(a["net"]) == list(b["net"])
         for k in a["net"]:
@@ -51,6 +54,6 @@ def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path):
         assert np.array_equal(a["val_score"], b["val_score"])
     # a second sweep finds both jobs finished and launches nothing
     launched = []
-    args = type("A", (), dict(config=cfg_path, exp_id="exp", meta_template="", npy_dir_template="", binsizes=None, regression=False, gpus=1, poll=0.0))
+    args = type("A", (), dict(config=cfg_path, exp_id="exp", meta_template="", npy_dir_template="", binsizes=None, regression=regression, gpus=1, poll=0.0))
     done = sweep.run(sweep.plan(["E003", "E004"], ["1"], "exp", "1", out_dir), args, launch=lambda *a, **k: launched.append(a))
     assert not launched and set(done.values()) == {0}
