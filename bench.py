@@ -402,7 +402,7 @@ def main():
         if world == 1 and not args.graph:      # the same step replayed as ONE hipGraph + AdamW (what train_epoch does), no events inside
             tg = Trainer(model, lr=3e-5)
             sg = tg.stage(batch)
-            for _ in range(args.warmup):
+            for _ in range(max(args.warmup, 50)):      # (capture + the first replays of a new graph: un-timed, as the headline leg's pre-warm)
                 tg.step(sg)
             torch.cuda.synchronize()
             tg0 = time.perf_counter()

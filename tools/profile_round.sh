@@ -43,6 +43,12 @@ CF_TRUNK=0 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baselin
 timeout 100 python3 tools/trunk_stamps.py > $OUT/trunk_stamps.txt 2> /dev/null
 timeout 100 python3 tools/bin_bench.py 2> /dev/null | tail -1 > $OUT/binning.json
 timeout 200 python3 tools/stress_bench.py 2> /dev/null | tail -1 > $OUT/stress_attention.json
-[ -x build/team_exchange ] && timeout 60 build/team_exchange 64 > $OUT/team_exchange.txt 2>&1
+timeout 100 python3 tools/reg_stamps.py fwd 2 > $OUT/reg_stamps_fwd.txt 2> /dev/null
+timeout 100 python3 tools/reg_stamps.py bwd 2 > $OUT/reg_stamps_bwd.txt 2> /dev/null
+# the driver's own command on this box (20 steps behind the disclosed pre-warm)
+timeout 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> /dev/null
+# attention-kernel HBM evidence on the current code (north_star clause) and the data-parallel step's kernel timeline on a one-rank RCCL group
+timeout 600 tools/attc_bandwidth.sh $TAG > /dev/null 2>&1
+( cd /tmp && for m in eager graph; do rm -rf /tmp/pd; timeout 200 rocprofv3 --kernel-trace -d /tmp/pd --output-format csv -- python3 $R/tools/dp_probe.py $m 100 2> /dev/null | tail -1 > $OUT/dp_timeline_$m.txt; python3 $R/tools/timeline.py $(find /tmp/pd -name "*kernel_trace.csv" | head -1) 60 k_trunk_fwd >> $OUT/dp_timeline_$m.txt; done )
 timeout 200 python3 tools/epoch_evidence.py --bench-genes-per-s $(python3 -c "import json; print(json.load(open('$OUT/bench.json'))['train_loop']['value'])" 2> /dev/null || echo 0) > $OUT/epoch_18955.txt 2>&1
 ls -la $OUT
