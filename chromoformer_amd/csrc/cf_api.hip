@@ -101,9 +101,14 @@ static void add_ffn(std::vector<PDesc>& v, const std::string& pre, int d_emb, in
 static int check_config(const cf_config& c) {
     // (net.py:277-278 leave d_emb and d_head free; every kernel of this library is written for 128-wide rows -- one MFMA row tile
     //  of 16 x 128 in LDS, eight waves x 16 columns -- so other widths are refused here, by name, instead of failing later)
-    if (c.d_emb != kD)
-        return fail("d_emb = %d is not supported: the HIP path implements d_emb = 128 only (the reference's default, net.py:277; "
-                    "configs/default.yaml embed.d_model); use the reference implementation for other widths", c.d_emb);
+    // round 5: d_emb = 256 as well, through the stand-alone kernels (row-tile chains, one-sequence attention, layer-by-layer Regulation, the
+    // vector-ALU head), which carry the row width as a template parameter; the fused kernels are written for 128-wide rows
+    if (c.d_emb != 128 && c.d_emb != 256)
+        return fail("d_emb = %d is not supported: the HIP path implements d_emb = 128 (the reference's default, net.py:277; every fused kernel) and "
+                    "256 (stand-alone kernels)", c.d_emb);
+    if (c.d_emb != 128 && (c.embed_layers != 1 || c.embed_heads > 2 || c.pair_heads > 2))
+        return fail("d_emb = %d: one Embedding layer and at most two heads in the Embedding / Pairwise stacks are implemented at this width "
+                    "(got embed.n_layers = %d, n_heads = %d / %d)", c.d_emb, c.embed_layers, c.embed_heads, c.pair_heads);
     if (c.d_head < 4 || c.d_head > kHeadGenMaxDH || (c.d_head & 3))
         return fail("d_head = %d is not supported (net.py:278): multiples of 4 in 4..%d (128, the reference's default, runs the matrix-core head "
                     "kernels, other widths a vector-ALU head)", c.d_head, kHeadGenMaxDH);
@@ -116,10 +121,11 @@ static int check_config(const cf_config& c) {
     // (heads: 2 is what the fused trunk and the gene-batched attention kernels are written for; 1 and 4 run the stand-alone chain
     //  kernels instantiated for that head count and the one-sequence-per-workgroup attention)
     auto heads_ok = [](int n) { return n == 1 || n == 2 || n == 4; };
-    if (!heads_ok(c.embed_heads) || c.embed_dmodel != 128)
-        return fail("embed: n_heads in {1, 2, 4} and d_model = 128 (= d_emb, net.py:305) are supported (got n_heads = %d, d_model = %d)", c.embed_heads, c.embed_dmodel);
-    if (!heads_ok(c.pair_heads) || c.pair_dmodel != 128)
-        return fail("pairwise_interaction: n_heads in {1, 2, 4} and d_model = 128 are supported (got n_heads = %d, d_model = %d)", c.pair_heads, c.pair_dmodel);
+    if (!heads_ok(c.embed_heads) || c.embed_dmodel != c.d_emb)
+        return fail("embed: n_heads in {1, 2, 4} and d_model = d_emb (net.py:305) are supported (got n_heads = %d, d_model = %d)", c.embed_heads, c.embed_dmodel);
+    if (!heads_ok(c.pair_heads) || c.pair_dmodel != c.d_emb)
+        return fail("pairwise_interaction: n_heads in {1, 2, 4} and d_model = d_emb = %d are supported -- the Pairwise rows are concatenated with the promoter "
+                    "embedding (net.py:361-370), so the two widths must agree (got n_heads = %d, d_model = %d)", c.d_emb, c.pair_heads, c.pair_dmodel);
     if (c.embed_layers > 1 && c.embed_heads != 2)
         return fail("embed: n_layers > 1 (the all-rows path) is implemented for n_heads = 2 only (got n_heads = %d)", c.embed_heads);
     if (c.pair_layers < 1 || 2 * c.pair_layers > kLpMaxSeg) return fail("pairwise_interaction.n_layers must be in 1..%d (got %d)", kLpMaxSeg / 2, c.pair_layers);
@@ -386,6 +392,7 @@ struct cf_handle {
 };
 
 static void plan_centre(cf_handle* h, CentreBuf& b, const std::string& pre, size_t N, int L, int dff, bool own_out, bool own_xin, int nh) {
+    const size_t kD = h->cfg.d_emb;      // (row width: shadows cf::kD in this function)
     const size_t tiles = (N + kTile - 1) / kTile;
     b.q = h->ws_get(pre + "q", N * kD);
     b.qt = h->ws_get(pre + "qt", N * nh * kD);
@@ -411,12 +418,13 @@ static void plan_centre(cf_handle* h, CentreBuf& b, const std::string& pre, size
     b.du = h->ws_get(d + "u", N * nh * 8);
     b.dq = h->ws_get(d + "q", N * kD);
     b.dx = h->ws_get(d + "x", N * kD);
-    b.partial = h->ws_get(d + "partial", std::max(tiles, (size_t)h->cfg.max_batch) * post_partial_width(dff));      // (the fused trunk writes one row per gene)
+    b.partial = h->ws_get(d + "partial", std::max(tiles, (size_t)h->cfg.max_batch) * post_partial_width(dff, (int)kD));      // (the fused trunk writes one row per gene)
 }
 
 // executed twice: once to size the arena, once to hand out pointers
 static void plan_workspace(cf_handle* h) {
     const cf_config& c = h->cfg;
+    const size_t kD = c.d_emb;      // (row width: shadows cf::kD in this function)
     const size_t MB = c.max_batch, S = c.i_max, T = S + 1;
     const size_t NE = MB, NP = MB * S, NR = MB * T;
     for (int r = 0; r < c.n_res; ++r) {
@@ -463,7 +471,7 @@ static void plan_workspace(cf_handle* h) {
             b.dt1 = h->ws_get(d + "t1", NR * kD);
             b.da = h->ws_get(d + "a", NR * RDm);
             b.dqkvg = h->ws_get(d + "qkvg", NR * RW);
-            b.partial = h->ws_get(d + "partial", std::max((NR + kTile - 1) / kTile, MB) * post_partial_width(dff));
+            b.partial = h->ws_get(d + "partial", std::max((NR + kTile - 1) / kTile, MB) * post_partial_width(dff, (int)kD));
             b.dgam = h->ws_get(d + "gam", MB * RH);
             b.hq = h->ws_get(pre + "hq", MB * RH * kHqFloats);
             b.dy1 = h->ws_get(d + "y1", NR * kD);
@@ -525,19 +533,21 @@ static void push_cs(std::vector<CsTile>& out, const float* src, int ld, int ncol
 // (rows of the partial buffer: one per 16-row tile, M = ceil(rpg * batch / 16); one per gene with the fused trunk: rpg = div = 1)
 static void push_post_cs(std::vector<CsTile>& out, const cf_handle* h, const float* part, int dff, int rpg,
                          const std::string& att_pre, const std::string& ff_pre, int div = kTile) {
-    const int pw = post_partial_width(dff);
+    const int kD = h->cfg.d_emb;      // (row width: shadows cf::kD in this function)
+    const int pw = post_partial_width(dff, kD);
     push_cs(out, part + 0, pw, kD, rpg, div, h->G_(ff_pre + "ln.weight"));
-    push_cs(out, part + 128, pw, kD, rpg, div, h->G_(ff_pre + "ln.bias"));
-    push_cs(out, part + 256, pw, kD, rpg, div, h->G_(ff_pre + "l2.bias"));
-    push_cs(out, part + 384, pw, dff, rpg, div, h->G_(ff_pre + "l1.bias"));
-    push_cs(out, part + 384 + dff, pw, kD, rpg, div, h->G_(att_pre + "ln.weight"));
-    push_cs(out, part + 512 + dff, pw, kD, rpg, div, h->G_(att_pre + "ln.bias"));
-    push_cs(out, part + 640 + dff, pw, kD, rpg, div, h->G_(att_pre + "ff.bias"));
+    push_cs(out, part + kD, pw, kD, rpg, div, h->G_(ff_pre + "ln.bias"));
+    push_cs(out, part + 2 * kD, pw, kD, rpg, div, h->G_(ff_pre + "l2.bias"));
+    push_cs(out, part + 3 * kD, pw, dff, rpg, div, h->G_(ff_pre + "l1.bias"));
+    push_cs(out, part + 3 * kD + dff, pw, kD, rpg, div, h->G_(att_pre + "ln.weight"));
+    push_cs(out, part + 4 * kD + dff, pw, kD, rpg, div, h->G_(att_pre + "ln.bias"));
+    push_cs(out, part + 5 * kD + dff, pw, kD, rpg, div, h->G_(att_pre + "ff.bias"));
 }
 // weight gradients of one centre-row layer (q / k / v projections, out-projection, FFN)
 static void push_centre_wg(std::vector<WgTile>& out, const cf_handle* h, const CentreBuf& b, const float* xin, int ldxin,
                            int rpg, int dff, float* gWq, float* gWk, float* gWv, const std::string& att_pre,
                            const std::string& ff_pre, int nh) {
+    const int kD = h->cfg.d_emb;      // (row width: shadows cf::kD in this function)
     const int dh = kD / nh, qw = nh * kD;
     push_wg(out, wg1(b.dq, kD, xin, ldxin, rpg, gWq, kD, kD, kD));
     for (int hd = 0; hd < nh; ++hd) {
@@ -620,6 +630,7 @@ static int build_reg_table(cf_handle* h) {
 
 static int build_tables(cf_handle* h) {
     const cf_config& c = h->cfg;
+    const int kD = c.d_emb;      // (row width: shadows cf::kD in this function)
     const int S = c.i_max, T = S + 1, F = c.n_feats;
     // two gradient buckets: `wg` / `cs` take Embedding + Pairwise (ready after the whole backward chain), `wgR` / `csR`
     // the Regulation stacks and the head (ready after k_reg_bwd, i.e. before Pairwise + Embedding backward starts)
@@ -882,6 +893,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     for (const auto& en : h->ws) h->ws_names += en.name + "\n";
     for (int r = 0; r < h->cfg.n_res; ++r) {
         const int L = h->cfg.n_bins[r];
+        const int kD = h->cfg.d_emb;      // (row width of the positional table: shadows cf::kD here)
         h->edx0[r] = h->E[r].dx;
         std::vector<float> t((size_t)L * kD);
         for (int j = 0; j < L; ++j)
@@ -905,7 +917,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
         // on the stand-alone kernels instead (k_attr + the row-tile chains: what every other shape runs) -- the cross-check implementation
         h->reg_row0 = getenv_int("CF_REG_ROW0", 1) != 0;
         const size_t need = std::max(reg8_fwd_smem(c.reg_dff), reg8_bwd_smem(c.reg_dff));
-        h->reg_fused = T <= kTile && need <= 160 * 1024 && c.reg_heads == kRH && c.reg_dmodel == kRDm && getenv_int("CF_REG_FUSED", 1) != 0;
+        h->reg_fused = T <= kTile && need <= 160 * 1024 && c.reg_heads == kRH && c.reg_dmodel == kRDm && c.d_emb == kD && getenv_int("CF_REG_FUSED", 1) != 0;
         if (h->reg_fused) {
             const size_t sf = reg8_fwd_smem(c.reg_dff), sb = reg8_bwd_smem(c.reg_dff);
             hipError_t e1 = hipFuncSetAttribute(reg_kernel(false, c.reg_dff), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf);
@@ -918,7 +930,7 @@ extern "C" int cf_create(const cf_config* cfg, const float* const* pe_host, cf_h
     {   // gene-batched attention kernel when its LDS image (8 regions of features + 16 score rows) fits
         size_t need = 0;
         for (int r = 0; r < c.n_res; ++r) need = std::max(need, attc2_smem(c.n_bins[r], c.n_feats, kAGMax));
-        h->attc2 = need <= 160 * 1024;
+        h->attc2 = need <= 160 * 1024 && c.d_emb == kD;      // (and the default row width: cf_attc1.h / cf_attc2.h are written for 128)
         if (h->attc2) {
             for (int ag = 1; ag <= kAGMax; ag *= 2) {
                 size_t nd = 0;
@@ -988,8 +1000,9 @@ static int embed_dense_backward(cf_handle* h, const cf_batch* bt, hipStream_t st
 // launch helpers
 // ------------------------------------------------------------------------------------
 static inline int tiles_of(int n) { return (n + kTile - 1) / kTile; }
-static size_t attc_smem(int L, int F, bool bwd, int nh = 2) {
-    return (size_t)(2 * nh * kD + 20 * nh + nh * L + (bwd ? nh * L : 0) + L * F) * sizeof(float);
+static size_t attc_smem(int L, int F, bool bwd, int nh = 2, int D = kD) {
+    const int parts = 256 / D > 2 ? 256 / D - 1 : 1;
+    return (size_t)((1 + parts) * nh * D + 20 * nh + nh * L + (bwd ? nh * L : 0) + L * F) * sizeof(float);
 }
 static size_t attr_smem(int T, int H, int DM, bool bwd) {
     return (size_t)(T * 4 * DM + H * T * T + (bwd ? H * T * T + T * DM + H * T : 0)) * sizeof(float);
@@ -999,8 +1012,13 @@ static size_t attr_smem(int T, int H, int DM, bool bwd) {
 #define CF_POST_WAVES 8
 #endif
 constexpr int kPostWaves = CF_POST_WAVES;      // waves per workgroup of the row-tile chains (k_post_*, k_qchain_*): 4 or 8
-template <bool VPROJ, int DM>
+template <bool VPROJ, int DM, int D = 128>
 static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& a) {
+    if constexpr (D != 128) {      // (rows of another width: the eight-wave chain kernels with the width as a template parameter)
+        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8, false, 2, D>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8, false, 2, D>), grid, dim3(512), 0, st, a);
+        return;
+    }
     if constexpr (VPROJ && DM == 128) {      // the hosting instantiation (eight waves; the Embedding layer's launch asks for it, nobody else)
         if (a.rt_units) {
             if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8, true>), grid, dim3(512), 0, st, a);
@@ -1012,36 +1030,43 @@ static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& 
     if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
     else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
 }
-template <bool VPROJ, int DM>
+template <bool VPROJ, int DM, int D = 128>
 static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArgs& a) {
+    if constexpr (D != 128) {
+        if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, 8, 2, D>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, 8, 2, D>), grid, dim3(512), 0, st, a);
+        return;
+    }
     if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
     else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
 }
 
 // The stand-alone stages of one centre-row layer for a head count other than 2 (eight-wave chain kernels, the one-sequence-per-workgroup
 // attention): the same argument structures as the default launches, [N, NH, .] arrays.
-template <int NH>
+// D: the row width (d_emb; the Embedding / Pairwise attention width is the same, net.py:305 / 361-370).  Every shape but the default
+// (two heads, 128) takes this route.
+template <int NH, int D = 128>
 static int centre_fwd_heads(hipStream_t st, int N, int nres, int dff, bool q_done, const QChainArgs& q, const AttcArgs& at, size_t smem,
                             const PostArgs& po) {
     if (!q_done) {
-        hipLaunchKernelGGL((k_qchain_fwd<8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, q);
+        hipLaunchKernelGGL((k_qchain_fwd<8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, q);
         LAUNCH_CHECK("k_qchain_fwd");
     }
-    hipLaunchKernelGGL((k_attc<false, NH>), dim3(N, nres), dim3(256), smem, st, at);
+    hipLaunchKernelGGL((k_attc<false, NH, D>), dim3(N, nres), dim3(256), smem, st, at);
     LAUNCH_CHECK("k_attc<fwd>");
-    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<true, 128, 128, 8, false, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
-    else hipLaunchKernelGGL((k_post_fwd<true, 128, 256, 8, false, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
+    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<true, D, 128, 8, false, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
+    else hipLaunchKernelGGL((k_post_fwd<true, D, 256, 8, false, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
     LAUNCH_CHECK("k_post_fwd<centre>");
     return 0;
 }
-template <int NH>
+template <int NH, int D = 128>
 static int centre_bwd_heads(hipStream_t st, int N, int nres, int dff, const PostBwdArgs& pb, const AttcArgs& at, size_t smem, const QBwdArgs& qb) {
-    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<true, 128, 128, 8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
-    else hipLaunchKernelGGL((k_post_bwd<true, 128, 256, 8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
+    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<true, D, 128, 8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
+    else hipLaunchKernelGGL((k_post_bwd<true, D, 256, 8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
     LAUNCH_CHECK("k_post_bwd<centre>");
-    hipLaunchKernelGGL((k_attc<true, NH>), dim3(N, nres), dim3(256), smem, st, at);
+    hipLaunchKernelGGL((k_attc<true, NH, D>), dim3(N, nres), dim3(256), smem, st, at);
     LAUNCH_CHECK("k_attc<bwd>");
-    hipLaunchKernelGGL((k_qchain_bwd<8, NH>), dim3(tiles_of(N), nres), dim3(512), 0, st, qb);
+    hipLaunchKernelGGL((k_qchain_bwd<8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, qb);
     LAUNCH_CHECK("k_qchain_bwd");
     return 0;
 }
@@ -1079,12 +1104,14 @@ static CentreParams centre_params(const cf_handle* h, const std::string& att_pre
 static CentreParams embed_params(const cf_handle* h, int r) {
     const std::string pre = fmt("embed.%d.", h->cfg.binsizes[r]), lp = pre + "transformer.layers.0.";
     const float* att = h->P_(lp + "self_att.att.weight");
+    const size_t kD = h->cfg.d_emb;      // (row width: shadows cf::kD)
     return centre_params(h, lp + "self_att.", lp + "ff.", att, att + (size_t)kD * kD, att + (size_t)2 * kD * kD,
                          h->P_(pre + "lin_proj.weight"));
 }
 static CentreParams pair_params(const cf_handle* h, int r, int l) {
     const std::string pre = fmt("pairwise_interaction.%d.", h->cfg.binsizes[r]), lp = pre + fmt("transformer.layers.%d.", l);
     const float* c_att = h->P_(lp + "self_att.c_att.weight");
+    const size_t kD = h->cfg.d_emb;      // (row width: shadows cf::kD)
     return centre_params(h, lp + "self_att.", lp + "ff.", h->P_(lp + "self_att.p_att.weight"), c_att, c_att + (size_t)kD * kD,
                          h->P_(pre + "lin_proj_pcre.weight"));
 }
@@ -1107,7 +1134,7 @@ static int build_trunk_table(cf_handle* h) {
     const cf_config& c = h->cfg;
     h->trunk = false;
     if (h->embed_dense || !h->attc2 || c.i_max > kAGMax || c.pair_layers > kMaxPairLayers || kPostWaves != 8) return 0;
-    if (c.embed_heads != 2 || c.pair_heads != 2) return 0;      // (the fused kernels are written for two heads)
+    if (c.embed_heads != 2 || c.pair_heads != 2 || c.d_emb != kD) return 0;      // (the fused kernels are written for two heads and 128-wide rows)
     if (!trunk_kernel(false, c.embed_dff, c.pair_dff, c.pair_layers)) return 0;
     if (const char* e = getenv("CF_TRUNK"))      // CF_TRUNK=0: the stand-alone kernels (A/B runs, cross-checks in the tests)
         if (atoi(e) == 0) return 0;
@@ -1213,6 +1240,7 @@ static void head_gen_args(const cf_handle* h, int B, float* logits_user, HeadGen
     a.dlogits = h->dlogits, a.dh1 = h->dh1, a.dhin = h->dhin;
     a.loss = h->loss, a.loss_part = h->loss_part;
     a.B = B, a.T = c.i_max + 1, a.n_res = c.n_res, a.n_out = c.n_out, a.DH = c.d_head;
+    a.D = c.d_emb;
 }
 static void head_fwd_args(const cf_handle* h, int B, float* logits_user, HeadFwdArgs& a) {
     const cf_config& c = h->cfg;
@@ -1254,11 +1282,12 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
     hipStream_t st = (hipStream_t)stream;
     const long long launches0 = g_launches;
     const cf_config& c = h->cfg;
+    const int kD = c.d_emb;      // (row width: shadows cf::kD in this function; 128, or 256 through the stand-alone kernels)
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
     CentreParams ep[kMaxRes], pp[kMaxRes];
     for (int r = 0; r < nres; ++r) ep[r] = embed_params(h, r);
-    const bool defer = h->defer_retile && !h->embed_dense && kPostWaves == 8 && c.embed_heads == 2;      // Regulation + head units ride in the Embedding layer's chain launch
+    const bool defer = h->defer_retile && !h->embed_dense && kPostWaves == 8 && c.embed_heads == 2 && c.d_emb == 128;      // (kD is shadowed in this function) Regulation + head units ride in the Embedding layer's chain launch
     const bool trunk = h->trunk;                                                   // Embedding + Pairwise stage as ONE launch (cf_trunk.h)
     int* adv_cursor = nullptr;
     {   // refresh the tiled weight copies (the parameters may have been changed by anyone since the last call) and, in the same
@@ -1298,8 +1327,12 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             LAUNCH_CHECK("k_prologue_gather");
         } else if (n_now + (trunk ? 0 : B * nres) > 0) {      // (nothing to re-tile and nothing to gather: no launch)
             // (the fused trunk computes the Embedding input row itself: no x0 workgroups then)
-            hipLaunchKernelGGL(k_fwd_prologue, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
-                               h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
+            if (kD == 256)
+                hipLaunchKernelGGL(k_fwd_prologue<256>, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
+                                   h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
+            else
+                hipLaunchKernelGGL(k_fwd_prologue<128>, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
+                                   h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
             LAUNCH_CHECK("k_fwd_prologue");
         }
         if (mine) h->pend_gather = false;
@@ -1376,7 +1409,7 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             at.w[r] = b.w;
             at.vout[r] = b.xbar;
             at.L[r] = c.n_bins[r];
-            smem = std::max(smem, attc_smem(c.n_bins[r], F, false, nh));
+            smem = std::max(smem, attc_smem(c.n_bins[r], F, false, nh, kD));
             po.x[r] = xin[r];
             po.ain[r] = b.xbar;
             po.wv[r] = prm[r].wv_t;
@@ -1407,6 +1440,10 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         po.omap = omap;
         po.N = N;
         po.save = save;
+        if (kD == 256) {      // (rows of 256: the stand-alone kernels with the width as a template parameter; one or two heads)
+            if (smem > 64 * 1024) return fail("cf_forward: a region of %d bins does not fit the one-sequence attention at d_emb = 256", c.n_bins[nres - 1]);
+            return nh == 1 ? centre_fwd_heads<1, 256>(st, N, nres, dff, q_done, q, at, smem, po) : centre_fwd_heads<2, 256>(st, N, nres, dff, q_done, q, at, smem, po);
+        }
         if (nh == 1) return centre_fwd_heads<1>(st, N, nres, dff, q_done, q, at, smem, po);
         if (nh == 4) return centre_fwd_heads<4>(st, N, nres, dff, q_done, q, at, smem, po);
         if (!q_done) {
@@ -1612,14 +1649,17 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         LAUNCH_CHECK("k_linear_fwd<qkvg>");
         hipLaunchKernelGGL((k_attr<false>), dim3(B, nres), dim3(256), attr_smem(T, at.H, RDm, false), st, at);
         LAUNCH_CHECK("k_attr<fwd>");
-        if (RDm == 128) launch_post_fwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+        if (kD == 256) {
+            if (RDm == 128) launch_post_fwd<false, 128, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+            else launch_post_fwd<false, 256, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+        } else if (RDm == 128) launch_post_fwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         else launch_post_fwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         LAUNCH_CHECK("k_post_fwd<reg>");
     }
     h->head_deferred = save == 2 && !ride;
     h->head_done = ride != nullptr;
     h->deferred_logits_user = logits;
-    if (save != 2 && c.d_head != kD) {
+    if (save != 2 && (c.d_head != 128 || c.d_emb != 128)) {
         HeadGenArgs a;
         head_gen_args(h, B, logits, a);
         hipLaunchKernelGGL(k_head_gen_fwd, dim3(B), dim3(256), 0, st, a);
@@ -1645,7 +1685,7 @@ extern "C" int cf_forward(cf_handle* h, const cf_batch* bt, float* logits, int s
 // default head width; CF_HEAD_RIDE=0 at cf_create switches it off: A/B runs, cross-checks.)
 extern "C" int cf_head_rides(cf_handle* h) {
     if (!h) return 0;
-    return h->reg_fused && h->cfg.n_res == kMaxRes && h->cfg.d_head == kD && h->head_ride ? 1 : 0;
+    return h->reg_fused && h->cfg.n_res == kMaxRes && h->cfg.d_head == kD && h->cfg.d_emb == kD && h->head_ride ? 1 : 0;
 }
 // cf_forward(save_for_backward = 2) for a training step whose labels are known at forward time: where cf_head_rides(h), the
 // prediction head -- forward, loss, its backward down to the gradient of token 0 of every Regulation output -- runs at the tail of the
@@ -1682,6 +1722,7 @@ extern "C" int cf_forward_train(cf_handle* h, const cf_batch* bt, float* logits,
 static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int parts = 7, const void* labels = nullptr,
                          float loss_scale = 1.f, float* loss_out = nullptr) {
     const cf_config& c = h->cfg;
+    const int kD = c.d_emb;      // (row width: shadows cf::kD in this function)
     const int B = bt->B, S = c.i_max, T = S + 1, nres = c.n_res, F = c.n_feats;
     const int NE = B, NP = B * S, NR = B * T;
     if ((parts & 1) && h->head_done) {         // cf_forward_train has run head forward, loss and head backward already
@@ -1689,7 +1730,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         h->head_loss_due = true;
         parts &= ~1;
     }
-    if ((parts & 1) && c.d_head != kD) {      // loss + head, any hidden width
+    if ((parts & 1) && (c.d_head != 128 || c.d_emb != 128)) {      // loss + head, any hidden width / row width
         if (h->head_deferred && !labels) return fail("cf_backward: cf_forward(save_for_backward = 2) needs the fused loss (labels)");
         HeadGenArgs a;
         head_gen_args(h, B, h->head_deferred ? h->deferred_logits_user : nullptr, a);
@@ -1817,7 +1858,10 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         dg.N = NR;
         dg.K = RW;
         dg.Ncols = kD;
-        if (RDm == 128) launch_post_bwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+        if (kD == 256) {
+            if (RDm == 128) launch_post_bwd<false, 128, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+            else launch_post_bwd<false, 256, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+        } else if (RDm == 128) launch_post_bwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
         else launch_post_bwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
         LAUNCH_CHECK("k_post_bwd<reg>");
         hipLaunchKernelGGL((k_attr<true>), dim3(B, nres), dim3(256), attr_smem(T, at.H, RDm, true), st, at);
@@ -1911,7 +1955,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
             at.w[r] = b.du;
             at.vout[r] = b.dqt;
             at.L[r] = c.n_bins[r];
-            smem = std::max(smem, attc_smem(c.n_bins[r], F, true, nh));
+            smem = std::max(smem, attc_smem(c.n_bins[r], F, true, nh, kD));
             qb.dqt[r] = b.dqt;
             qb.dres[r] = b.dt1;
             qb.wk[r] = prm[r].wk_t;     // NT product in the backward: tiled copy
@@ -1924,6 +1968,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         at.F = F;
         at.scale = scale_c;
         qb.N = N;
+        if (kD == 256) return nh == 1 ? centre_bwd_heads<1, 256>(st, N, nres, dff, pb, at, smem, qb) : centre_bwd_heads<2, 256>(st, N, nres, dff, pb, at, smem, qb);
         if (nh == 1) return centre_bwd_heads<1>(st, N, nres, dff, pb, at, smem, qb);
         if (nh == 4) return centre_bwd_heads<4>(st, N, nres, dff, pb, at, smem, qb);
         launch_post_bwd<true, 128>(dff, dim3(tiles_of(N), nres), st, pb);
@@ -2000,7 +2045,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         a.S = S;
         a.T = T;
         a.n_res = nres;
-        hipLaunchKernelGGL(k_join_dgrad, dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
+        if (kD == 256) hipLaunchKernelGGL(k_join_dgrad<256>, dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_join_dgrad<128>, dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_join_dgrad");
     }
     if (h->embed_dense) {
@@ -2028,7 +2074,7 @@ constexpr bool kMergeReduce = CF_MERGE_REDUCE;
 static int reduce_impl(cf_handle* h, int B, hipStream_t st, int buckets = CF_BUCKET_REG | CF_BUCKET_PE) {
     if (h->rider.done) return fail("gradient reduction: the riders of step %lld have updated part of the Regulation + head bucket; finish the step with cf_reduce_opt_part", h->rider.step);
     if ((buckets & CF_BUCKET_PE) && !h->trunk) {      // (the fused trunk backward writes these partials itself)
-        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
+        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B, h->cfg.d_emb);
         LAUNCH_CHECK("k_wgrad_lp");
     }
     if (buckets & CF_BUCKET_REG) buckets |= CF_BUCKET_REG_HI | CF_BUCKET_REG_LO;
@@ -2229,6 +2275,7 @@ extern "C" double cf_wgrad_flops(cf_handle* h, int B) { return h ? h->wg_flops_p
 extern "C" double cf_kernel_flops(cf_handle* h, const char* kernel, int B) {
     if (!h || !kernel) return 0.0;
     const cf_config& c = h->cfg;
+    const double kD = c.d_emb;      // (row width: shadows cf::kD in this function)
     const double T = c.i_max + 1, dff = c.reg_dff;
     const std::string k = kernel;
     if (k == "k_wgrad") return h->wg_flops_per_gene * B;
@@ -2337,7 +2384,7 @@ extern "C" int cf_reduce_adamw_part(cf_handle* h, int B, int reduce_buckets, flo
     hipStream_t st = (hipStream_t)stream;
     const long long launches0 = g_launches;
     if ((reduce_buckets & CF_BUCKET_PE) && !h->trunk) {
-        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
+        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B, h->cfg.d_emb);
         LAUNCH_CHECK("k_wgrad_lp");
     }
     const bool reg = reduce_buckets == CF_BUCKET_REG;
@@ -2363,7 +2410,7 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
     hipStream_t st = (hipStream_t)stream;
     const long long launches0 = g_launches;
     if ((bucket & CF_BUCKET_PE) && !h->trunk) {
-        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B);
+        hipLaunchKernelGGL(k_wgrad_lp, dim3((B + kLpGenes - 1) / kLpGenes, h->n_lp), dim3(256), 0, st, (const LpJob*)h->lp_jobs, B, h->cfg.d_emb);
         LAUNCH_CHECK("k_wgrad_lp");
     }
     // the tables hold the Regulation + head bucket's tiles first: one bucket is a prefix / suffix, both are everything

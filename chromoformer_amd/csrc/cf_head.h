@@ -263,14 +263,17 @@ struct HeadGenArgs {
     float *loss, *loss_part, *loss_user;
     float gscale;
     int B, T, n_res, n_out, DH;
+    int D;                       // row width of the Regulation rows (d_emb: 128, or 256 since round 5)
 };
 constexpr int kHeadGenMaxDH = 1024;
+constexpr int kHeadGenMaxD = 256;
 __global__ __launch_bounds__(256) void k_head_gen_fwd(HeadGenArgs a) {
-    __shared__ float xs[kMaxRes * kD];
+    __shared__ float xs[kMaxRes * kHeadGenMaxD];
     __shared__ float hs[kHeadGenMaxDH];
+    const int kD = a.D;      // (row width: shadows cf::kD)
     const int g = blockIdx.x, tid = threadIdx.x, K = a.n_res * kD, DH = a.DH;
     for (int k = tid; k < K; k += 256) {
-        const int r = k >> 7, c = k & 127;
+        const int r = k / kD, c = k % kD;
         const size_t o = (size_t)g * a.T * kD + c;
         const float v = ldg(a.xl[r] + o) + ldg(a.x0[r] + o);
         xs[k] = v;
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(256) void k_head_gen_fwd(HeadGenArgs a) {
 __global__ __launch_bounds__(256) void k_head_gen_bwd(HeadGenArgs a) {
     __shared__ float ds[kHeadGenMaxDH];
     __shared__ float dl[2];
+    const int kD = a.D;      // (row width: shadows cf::kD)
     const int g = blockIdx.x, tid = threadIdx.x, K = a.n_res * kD, DH = a.DH;
     if (tid == 0) {      // loss and d loss / d logits of the gene (CrossEntropyLoss / MSELoss, mean over the batch: train.py:156, 193)
         float l = 0.f, d0 = 0.f, d1 = 0.f;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void k_head_gen_bwd(HeadGenArgs a) {
         float s = 0.f;
         for (int j = 0; j < DH; ++j) s = fmaf(ds[j], ldg(a.w1 + (size_t)j * K + k), s);
         stg(a.dhin + (size_t)g * K + k, s);
-        stg(a.dxl[k >> 7] + (size_t)g * a.T * kD + (k & 127), s);
+        stg(a.dxl[k / kD] + (size_t)g * a.T * kD + (k % kD), s);
     }
     if (a.labels && tid == 0) {                // mean loss: summed in gene order by the last workgroup to arrive
         __threadfence();

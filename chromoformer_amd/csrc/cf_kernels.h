@@ -533,6 +533,85 @@ __device__ __forceinline__ void ln_bwd_tile16(const float* src, float* dst, int 
         stg4(dx_g + o + 4, o1);
     }
 }
+// ---- Rows wider than 128 (d_emb = 256, round 5): the same 16-lanes-per-row LayerNorm over D / 128 chunks of 8 floats per lane.  The
+// 128-wide functions above stay as they are (the default shape compiles to the code it always had); the chain bodies pick by `D`.
+template <int D>
+struct LnParamsW {
+    float4 g[D / 64], b[D / 64];      // chunk c: columns 128 c + 8 sub .. + 7  ->  g[2 c], g[2 c + 1]
+};
+template <int D>
+__device__ __forceinline__ LnParamsW<D> ln_params_load_w(const float* g, const float* b) {
+    const int sub = threadIdx.x & 15;
+    LnParamsW<D> p;
+#pragma unroll
+    for (int c = 0; c < D / 128; ++c) {
+        p.g[2 * c] = ldg4(g + c * 128 + sub * 8);
+        p.g[2 * c + 1] = ldg4(g + c * 128 + sub * 8 + 4);
+        p.b[2 * c] = ldg4(b + c * 128 + sub * 8);
+        p.b[2 * c + 1] = ldg4(b + c * 128 + sub * 8 + 4);
+    }
+    return p;
+}
+template <int D>
+__device__ __forceinline__ void ln_fwd_tile16_w(float* ts, int ld, const LnParamsW<D>& P, int row0, int nvalid, float* xhat_g, float* rstd_g,
+                                                float* y_g, const RowMap ymap = RowMap{1, 1, 0, 0}) {
+    constexpr int NV = D / 64;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, row = w * 4 + (lane >> 4), sub = lane & 15;
+    float* tp = ts + row * ld + sub * 8;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(tp + (i >> 1) * 128 + (i & 1) * 4);
+        s += sum4(v[i]);
+    }
+    const float mean = group16_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = f4_sub(v[i], mean);
+        q += sum4(f4_mul(v[i], v[i]));
+    }
+    const float var = group16_sum(q) * (1.0f / D);
+    const float rstd = 1.0f / sqrtf(var + kLnEps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int co = (i >> 1) * 128 + (i & 1) * 4;
+        const float4 x = f4_scale(v[i], rstd), y = f4_fma(x, P.g[i], P.b[i]);
+        *reinterpret_cast<float4*>(tp + co) = y;
+        if (row < nvalid) {
+            if (xhat_g) stg4(xhat_g + (size_t)(row0 + row) * D + sub * 8 + co, x);
+            if (y_g) stg4(y_g + (size_t)map_row(ymap, row0 + row) * D + sub * 8 + co, y);
+        }
+    }
+    if (row < nvalid && xhat_g && sub == 0) stg(rstd_g + row0 + row, rstd);
+}
+template <int D>
+__device__ __forceinline__ void ln_bwd_tile16_w(const float* src, float* dst, int ld, const float* xh, int ldx, const float* __restrict__ g,
+                                                const float* rstd_g, int row0, int nvalid, float* dx_g) {
+    constexpr int NV = D / 64;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, row = w * 4 + (lane >> 4), sub = lane & 15;
+    float4 a[NV], x[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int co = sub * 8 + (i >> 1) * 128 + (i & 1) * 4;
+        a[i] = f4_mul(*reinterpret_cast<const float4*>(src + row * ld + co), ldg4(g + co));
+        x[i] = *reinterpret_cast<const float4*>(xh + row * ldx + co);
+        s1 += sum4(a[i]);
+        s2 += sum4(f4_mul(a[i], x[i]));
+    }
+    const float m1 = group16_sum(s1) * (1.0f / D), m2 = group16_sum(s2) * (1.0f / D);
+    const float rs = row < nvalid ? ldg(rstd_g + row0 + row) : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int co = sub * 8 + (i >> 1) * 128 + (i & 1) * 4;
+        const float4 o = make_float4(rs * (a[i].x - m1 - x[i].x * m2), rs * (a[i].y - m1 - x[i].y * m2), rs * (a[i].z - m1 - x[i].z * m2),
+                                     rs * (a[i].w - m1 - x[i].w * m2));
+        *reinterpret_cast<float4*>(dst + row * ld + co) = o;
+        if (row < nvalid) stg4(dx_g + (size_t)(row0 + row) * D + co, o);
+    }
+}
 // column sums over the first nrows rows of an LDS tile
 __device__ __forceinline__ void colsum_rows(const float* A, int lda, const float* Bt, int ldb, int ncols, int nrows, float* out) {
     for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
@@ -585,7 +664,9 @@ struct X0Args {
     int L[kMaxRes];
     int F;
 };
+template <int D = 128>
 __device__ __forceinline__ void embed_x0_row(const X0Args& a, int r, int n, int e) {
+    constexpr int kD = D;      // (row width: shadows cf::kD)
     const int L = a.L[r], c = L / 2, F = a.F;
     const float* f = a.feats[r] + ((size_t)n * L + c) * F;
     float acc = 0.f;
@@ -593,7 +674,8 @@ __device__ __forceinline__ void embed_x0_row(const X0Args& a, int r, int n, int 
     stg(a.x0[r] + (size_t)n * kD + e, acc + ldg(a.pe[r] + (size_t)c * kD + e));
     if (e < 8) stg(a.featc[r] + (size_t)n * 8 + e, e < F ? ldg(f + e) : 0.f);
 }
-__global__ __launch_bounds__(128) void k_embed_x0(X0Args a) { embed_x0_row(a, blockIdx.y, blockIdx.x, threadIdx.x); }
+template <int D = 128>
+__global__ __launch_bounds__(D) void k_embed_x0(X0Args a) { embed_x0_row<D>(a, blockIdx.y, blockIdx.x, threadIdx.x); }
 
 // =======================================================================================
 // Query chain:  q = x Wq^T ;  qt[h] = q[h] Wk[h]   (the key projection absorbed into the
@@ -613,16 +695,17 @@ struct QChainArgs {
 // passed in) with thin __global__ wrappers: the fused centre-row kernels of cf_trunk.h run the same bodies back to back in one
 // workgroup per gene.
 // NH: heads of the layer (d_head = 128 / NH; the default 2 everywhere but in the stand-alone launches of a configuration with 1 or 4 heads)
-template <int NWV, int NH = 2>
-__device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r, const int row0, float (*xs)[kD + 4], float (*qs)[kD + 4]) {
+template <int NWV, int NH = 2, int D = 128>
+__device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r, const int row0, float (*xs)[D + 4], float (*qs)[D + 4]) {
+    constexpr int kD = D;      // (row width: shadows cf::kD)
     constexpr int DH = kD / NH, QW = NH * kD;
     constexpr int CW = kD / NWV, NTC = CW / 16;           // q columns per wave
     constexpr int EW = QW / NWV, NTE = EW / 16;           // qt columns per wave (NH heads x 128)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
+    const int h = (w * EW) / kD, e0 = (w * EW) % kD;
     TileReq<kD, NWV * 64> tx;
     tile_req(tx, a.x[r], kD, row0, a.N, a.xmap);
-    FragNT<NTC, 8> fq;
+    FragNT<NTC, kD / 16> fq;
     frag_load_nt(fq, a.wq[r] + (size_t)(w * CW) * kD, kD);
     FragNN<NTE, DH / 16> fk;
     frag_load_nn(fk, a.wk[r] + (size_t)(h * DH) * kD + e0, kD);
@@ -630,7 +713,7 @@ __device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r
     __syncthreads();
     if (a.xcopy[r])
         for (int i = threadIdx.x; i < kTile * kD; i += NWV * 64)
-            if (row0 + (i >> 7) < a.N) stg(a.xcopy[r] + (size_t)(row0 + (i >> 7)) * kD + (i & 127), xs[i >> 7][i & 127]);
+            if (row0 + (i / kD) < a.N) stg(a.xcopy[r] + (size_t)(row0 + (i / kD)) * kD + (i % kD), xs[i / kD][i % kD]);
     {
         f32x4 acc[NTC];
         zero_acc(acc);
@@ -662,11 +745,11 @@ __device__ __forceinline__ void qchain_fwd_body(const QChainArgs& a, const int r
     }
 }
 
-template <int NWV, int NH = 2>
+template <int NWV, int NH = 2, int D = 128>
 __global__ __launch_bounds__(NWV * 64) void k_qchain_fwd(QChainArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
-    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
-    qchain_fwd_body<NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, xs, qs);
+    __shared__ __attribute__((aligned(16))) float xs[kTile][D + 4];
+    __shared__ __attribute__((aligned(16))) float qs[kTile][D + 4];
+    qchain_fwd_body<NWV, NH, D>(a, blockIdx.y, blockIdx.x * kTile, xs, qs);
 }
 
 struct QBwdArgs {
@@ -678,17 +761,18 @@ struct QBwdArgs {
     float* dx[kMaxRes];          // [N,128]
     int N;
 };
-template <int NWV, int NH = 2>
-__device__ __forceinline__ void qchain_bwd_body(const QBwdArgs& a, const int r, const int row0, float (*ds)[NH * kD + 4], float (*qs)[kD + 4]) {
+template <int NWV, int NH = 2, int D = 128>
+__device__ __forceinline__ void qchain_bwd_body(const QBwdArgs& a, const int r, const int row0, float (*ds)[NH * D + 4], float (*qs)[D + 4]) {
+    constexpr int kD = D;      // (row width: shadows cf::kD)
     constexpr int DH = kD / NH, QW = NH * kD;
     constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / tiles per wave
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
     const int h = (w * CW) / DH;
     TileReq<QW, NWV * 64> td;
     tile_req(td, a.dqt[r], QW, row0, a.N, identity_map());
-    FragNT<NTC, 8> fk;
+    FragNT<NTC, kD / 16> fk;
     frag_load_nt(fk, a.wk[r] + (size_t)(w * CW) * kD, kD);
-    FragNN<NTC, 8> fq;
+    FragNN<NTC, kD / 16> fq;
     frag_load_nn(fq, a.wq[r] + w * CW, kD);
     tile_put(td, &ds[0][0], QW + 4, row0, a.N);
     __syncthreads();
@@ -727,11 +811,11 @@ __device__ __forceinline__ void qchain_bwd_body(const QBwdArgs& a, const int r, 
     }
 }
 
-template <int NWV, int NH = 2>
+template <int NWV, int NH = 2, int D = 128>
 __global__ __launch_bounds__(NWV * 64) void k_qchain_bwd(QBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float ds[kTile][NH * kD + 4];
-    __shared__ __attribute__((aligned(16))) float qs[kTile][kD + 4];
-    qchain_bwd_body<NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, ds, qs);
+    __shared__ __attribute__((aligned(16))) float ds[kTile][NH * D + 4];
+    __shared__ __attribute__((aligned(16))) float qs[kTile][D + 4];
+    qchain_bwd_body<NWV, NH, D>(a, blockIdx.y, blockIdx.x * kTile, ds, qs);
 }
 
 // =======================================================================================
@@ -782,15 +866,17 @@ __device__ __forceinline__ void block_reduce_heads(float (&v)[NH], float* red) {
 // The stand-alone form of the centre-row attention: one workgroup per sequence, vector ALUs, any bin count the LDS holds, NH heads
 // (vin / vout [N, NH, 128], p [N, NH, L], w [N, NH, 8]).  The default configuration takes the kernels of cf_attc1.h / cf_attc2.h (two
 // heads); this one runs where their LDS image does not fit and for the other head counts (1, 4).
-template <bool BWD, int NH = 2>
+template <bool BWD, int NH = 2, int D = 128>
 __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kD = D;      // (row width: shadows cf::kD)
+    static_assert(D == 64 || D == 128 || D == 256, "the channel-parallel pass splits the bins over 256 / D thread groups");
     const int r = blockIdx.y, n = blockIdx.x, tid = threadIdx.x;
     const int L = a.L[r], F = a.F;
     constexpr int QW = NH * kD;
-    float* vin_s = smem;              // NH * 128
-    float* half_s = vin_s + QW;       // NH * 128
-    float* u_s = half_s + QW;         // NH * 8  (h*8+f)
+    float* vin_s = smem;              // NH * D
+    float* half_s = vin_s + QW;       // max(1, 256 / D - 1) x NH * D
+    float* u_s = half_s + QW * (256 / kD > 2 ? 256 / kD - 1 : 1);         // NH * 8  (h*8+f)
     float* w_s = u_s + NH * 8;        // NH * 8
     float* red_s = w_s + NH * 8;      // NH * 4
     float* sc_s = red_s + NH * 4;     // NH*L  scores -> p (fwd) / p -> ds (bwd)
@@ -903,9 +989,10 @@ __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
         s = group16_sum(s);
         if (sub == 0) w_s[gh * 8 + gf] = s;
     }
-    // (5) pi[h][e] = sum_j sc[h][j] PE[j][e]   (two halves of the bin range)
-    const int e = tid & 127, half = tid >> 7;
-    const int Lh = (L + 1) >> 1;
+    // (5) pi[h][e] = sum_j sc[h][j] PE[j][e]   (256 / D parts of the bin range: two halves at the default width)
+    constexpr int PARTS = 256 / kD;
+    const int e = tid % kD, half = tid / kD;
+    const int Lh = (L + PARTS - 1) / PARTS;
     const int j0 = half * Lh, j1 = min(L, j0 + Lh);
     const float* pe = a.pe[r];
     float cv[NH];
@@ -917,9 +1004,9 @@ __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) cv[h] = fmaf(sc_s[h * L + j], pv, cv[h]);
     }
-    if (half == 1) {
+    if (half >= 1) {      // (parts 1 .. PARTS - 1 go through LDS, [part - 1][NH * D]; the smem budget reserves (PARTS - 1) x NH x D floats at half_s)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) half_s[h * kD + e] = cv[h];
+        for (int h = 0; h < NH; ++h) half_s[(half - 1) * QW + h * kD + e] = cv[h];
     }
     __syncthreads();
     if (tid < NH * 8) a.w[r][(size_t)n * NH * 8 + tid] = w_s[tid];
@@ -927,7 +1014,8 @@ __global__ __launch_bounds__(256) void k_attc(AttcArgs a) {
         float xv[NH];
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            cv[h] += half_s[h * kD + e];
+#pragma unroll
+            for (int pp = 1; pp < PARTS; ++pp) cv[h] += half_s[(pp - 1) * QW + h * kD + e];
             xv[h] = 0.f;
         }
         for (int f = 0; f < F; ++f) {
@@ -1028,15 +1116,16 @@ struct PostArgs {
 
 // NWV waves per workgroup (4 or 8): wave w owns 128 / NWV output columns of every product (DFF / NWV of the hidden layer), so with
 // eight waves two of them share a SIMD and one's operand waits hide behind the other's products; the LayerNorms run on waves 0..3.
-template <int DFF, int NH = 2>
+template <int DFF, int NH = 2, int D = 128>
 struct PostFwdLds {      // LDS tiles of post_fwd_body
     static constexpr int HW0 = (DFF > 256 ? DFF : 256);
-    static constexpr int HW = (NH * kD > HW0 ? NH * kD : HW0);      // (the hidden tile first holds the NH x 128 attention rows)
+    static constexpr int HW = (NH * D > HW0 ? NH * D : HW0);      // (the hidden tile first holds the NH x D attention rows)
 };
-template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2>
-__device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, const int row0, const int N, float (*xs)[kD + 4],
-                                              float (*as_)[DM + 4], float (*ts)[kD + 4], float (*hs)[PostFwdLds<DFF, NH>::HW + 4]) {
-    constexpr int HW = PostFwdLds<DFF, NH>::HW;
+template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2, int D = 128>
+__device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, const int row0, const int N, float (*xs)[D + 4],
+                                              float (*as_)[DM + 4], float (*ts)[D + 4], float (*hs)[PostFwdLds<DFF, NH, D>::HW + 4]) {
+    constexpr int kD = D;      // (row width: shadows cf::kD)
+    constexpr int HW = PostFwdLds<DFF, NH, D>::HW;
     constexpr int DH = kD / NH, QW = NH * kD;
     constexpr int CW = kD / NWV, NTC = CW / 16;           // output columns / column tiles per wave
     constexpr int CH = DFF / NWV, NT1 = CH / 16;          // hidden columns / tiles per wave
@@ -1046,13 +1135,18 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
     tile_req(tx, a.x[r], kD, row0, N, a.xmap);
     if (VPROJ) tile_req(th, a.ain[r], QW, row0, N, identity_map());
     FragNT<NTC, DM / 16> fo;
-    FragNT<NTC, 8> fv;
+    FragNT<NTC, kD / 16> fv;
     if (VPROJ) frag_load_nt(fv, a.wv[r] + (size_t)(w * CW) * kD, kD);
     frag_load_nt(fo, a.wo[r] + (size_t)(w * CW) * DM, DM);
-    LnParams lnp1, lnp2;
+    typename std::conditional<D == 128, LnParams, LnParamsW<D>>::type lnp1, lnp2;
     if (w < 4) {
-        lnp1 = ln_params_load(a.g1[r], a.be1[r]);
-        lnp2 = ln_params_load(a.g2[r], a.be2[r]);
+        if constexpr (D == 128) {
+            lnp1 = ln_params_load(a.g1[r], a.be1[r]);
+            lnp2 = ln_params_load(a.g2[r], a.be2[r]);
+        } else {
+            lnp1 = ln_params_load_w<D>(a.g1[r], a.be1[r]);
+            lnp2 = ln_params_load_w<D>(a.g2[r], a.be2[r]);
+        }
     }
     tile_put(tx, &xs[0][0], kD + 4, row0, N);
     if (VPROJ) {
@@ -1089,11 +1183,15 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
                 ts[row][col] = acc[t][i] + ldg(a.bo[r] + col) + xs[row][col];
             }
     }
-    FragNT<NT1, 8> f1;      // issued before the LayerNorm so the L2 latency hides behind it
+    FragNT<NT1, kD / 16> f1;      // issued before the LayerNorm so the L2 latency hides behind it
     frag_load_nt(f1, a.w1[r] + (size_t)(w * CH) * kD, kD);
     __syncthreads();
-    if (w < 4)
-        ln_fwd_tile16<(CF_TRUNK_NT & 1) != 0>(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
+    if (w < 4) {
+        if constexpr (D == 128)
+            ln_fwd_tile16<(CF_TRUNK_NT & 1) != 0>(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
+        else
+            ln_fwd_tile16_w<D>(&ts[0][0], kD + 4, lnp1, row0, min(kTile, N - row0), a.save ? a.xh1[r] : nullptr, a.rs1[r], a.save ? a.y1[r] : nullptr);
+    }
     __syncthreads();
     {   // hdn = relu(y1 W1^T + b1)
         f32x4 acc[NT1];
@@ -1128,14 +1226,17 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
             }
     }
     const bool lin = a.lin_w[r] != nullptr, nq = a.nq_wq[r] != nullptr;
-    FragNT<NTC, 8> fl;      // (operand ring of the trailing Linear, or of the next layer's q projection: never both)
+    FragNT<NTC, kD / 16> fl;      // (operand ring of the trailing Linear, or of the next layer's q projection: never both)
     if (lin) frag_load_nt(fl, a.lin_w[r] + (size_t)(w * CW) * kD, kD);
     if (nq) frag_load_nt(fl, a.nq_wq[r] + (size_t)(w * CW) * kD, kD);
     __syncthreads();
-    if (w < 4) ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+    if (w < 4) {
+        if constexpr (D == 128) ln_fwd_tile16(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+        else ln_fwd_tile16_w<D>(&xs[0][0], kD + 4, lnp2, row0, min(kTile, N - row0), a.save ? a.xh2[r] : nullptr, a.rs2[r], a.out[r], a.omap);
+    }
     if (nq) {
-        constexpr int EW = QW / NWV, NTE = EW / 16;           // qt columns per wave (NH heads x 128)
-        const int hq = (w * EW) >> 7, e0 = (w * EW) & 127;
+        constexpr int EW = QW / NWV, NTE = EW / 16;           // qt columns per wave (NH heads x D)
+        const int hq = (w * EW) / kD, e0 = (w * EW) % kD;
         FragNN<NTE, DH / 16> fk;
         frag_load_nn(fk, a.nq_wk[r] + (size_t)(hq * DH) * kD + e0, kD);
         __syncthreads();
@@ -1186,19 +1287,19 @@ __device__ __forceinline__ void post_fwd_body(const PostArgs& a, const int r, co
 
 // RT: the instantiation that hosts tiled-copy units (PostArgs::rt_units) -- a template parameter, so that the other instantiations
 // keep their code (the extra path cost k_post_fwd<true, 128, 256, 8> 2.4 us per launch when it was a run-time branch in all of them)
-template <bool VPROJ, int DM, int DFF, int NWV, bool RT = false, int NH = 2>
+template <bool VPROJ, int DM, int DFF, int NWV, bool RT = false, int NH = 2, int D = 128>
 __global__ __launch_bounds__(NWV * 64) void k_post_fwd(PostArgs a) {
-    constexpr int HW = PostFwdLds<DFF, NH>::HW;
-    __shared__ __attribute__((aligned(16))) float xs[kTile][kD + 4];
+    constexpr int HW = PostFwdLds<DFF, NH, D>::HW;
+    __shared__ __attribute__((aligned(16))) float xs[kTile][D + 4];
     __shared__ __attribute__((aligned(16))) float as_[kTile][DM + 4];
-    __shared__ __attribute__((aligned(16))) float ts[kTile][kD + 4];
+    __shared__ __attribute__((aligned(16))) float ts[kTile][D + 4];
     __shared__ __attribute__((aligned(16))) float hs[kTile][HW + 4];
     if (RT && (int)blockIdx.y >= a.rt_y0) {      // a tiled-copy unit riding in this launch
         const int u = ((int)blockIdx.y - a.rt_y0) * gridDim.x + blockIdx.x;
         if (u < a.rt_n) retile_unit<NWV>(a.rt_params, a.rt_tiled, a.rt_tiledT, a.rt_units[u]);
         return;
     }
-    post_fwd_body<VPROJ, DM, DFF, NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, a.N, xs, as_, ts, hs);
+    post_fwd_body<VPROJ, DM, DFF, NWV, NH, D>(a, blockIdx.y, blockIdx.x * kTile, a.N, xs, as_, ts, hs);
 }
 
 // backward of the chain.  Per tile it also emits the column sums that make up the
@@ -1225,41 +1326,45 @@ struct PostBwdArgs {
     float* partial[kMaxRes];
     int N;
 };
-__host__ __device__ constexpr int post_partial_width(int dff) { return 768 + dff; }
+__host__ __device__ constexpr int post_partial_width(int dff, int d = 128) { return 6 * d + dff; }
 
 // part_row: row of the partial buffer this tile's column sums go to (the tile index; the gene in the fused kernels)
-template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2>
+template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2, int D = 128>
 __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r, const int row0, const int N, const int part_row,
-                                              float (*ds)[kD + 4], float (*xh)[kD + 4], float (*t2)[kD + 4],
+                                              float (*ds)[D + 4], float (*xh)[D + 4], float (*t2)[D + 4],
                                               float (*wide)[(DFF > DM ? DFF : DM) + 4]) {
+    constexpr int kD = D;      // (row width: shadows cf::kD)
     constexpr int WW = (DFF > DM ? DFF : DM);
     constexpr int CW = kD / NWV, NTC = CW / 16;           // columns / tiles per wave of a 128-wide product
     constexpr int CH = DFF / NWV, NT2 = CH / 16;          // ... of the hidden layer
     constexpr int CO = DM / NWV, NTO = CO / 16;           // ... of the attention output
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    float* part = a.partial[r] + (size_t)part_row * post_partial_width(DFF);
+    float* part = a.partial[r] + (size_t)part_row * post_partial_width(DFF, kD);
     // With eight waves the LayerNorm backwards run on waves 0..3 while waves 4..7 take the column sums of the same phase.
     constexpr bool SPLIT = NWV == 8;
     TileReq<kD, NWV * 64> td, tx, tx1;
     tile_req(td, a.dout[r], kD, row0, N, a.dmap);
     tile_req(tx, a.xh2[r], kD, row0, N, identity_map());
-    FragNN<NT2, 8> fw2;
+    FragNN<NT2, kD / 16> fw2;
     frag_load_nn(fw2, a.w2[r] + w * CH, DFF);
     tile_req(tx1, a.xh1[r], kD, row0, N, identity_map());      // xhat1 rows: needed three phases later, requested now
     tile_put(td, &ds[0][0], kD + 4, row0, N);
     tile_put(tx, &xh[0][0], kD + 4, row0, N);
     __syncthreads();
     colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 0, SPLIT ? 256 : 0);      // d ln2.weight  (waves 4, 5)
-    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 128, SPLIT ? 384 : 0);           // d ln2.bias    (waves 6, 7)
+    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + kD, SPLIT ? 384 : 0);            // d ln2.bias    (waves 6, 7)
     if (w < 4) {
         const int sub = threadIdx.x & 15;
-        ln_bwd_tile16(&ds[0][0], &t2[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g2[r] + sub * 8), ldg4(a.g2[r] + sub * 8 + 4), a.rs2[r], row0,
-                      min(kTile, N - row0), a.dt2[r]);   // t2 = dt2
+        if constexpr (D == 128)
+            ln_bwd_tile16(&ds[0][0], &t2[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g2[r] + sub * 8), ldg4(a.g2[r] + sub * 8 + 4), a.rs2[r], row0,
+                          min(kTile, N - row0), a.dt2[r]);   // t2 = dt2
+        else
+            ln_bwd_tile16_w<D>(&ds[0][0], &t2[0][0], kD + 4, &xh[0][0], kD + 4, a.g2[r], a.rs2[r], row0, min(kTile, N - row0), a.dt2[r]);
     }
     FragNN<NTC, DFF / 16> fw1;      // (RING = 8 for this K = 256 product: measured, no change)
     frag_load_nn(fw1, a.w1[r] + w * CW, kD);
     __syncthreads();
-    colsum16q(&t2[0][0], kD + 4, nullptr, 0, kD, part + 256);          // d l2.bias
+    colsum16q(&t2[0][0], kD + 4, nullptr, 0, kD, part + 2 * kD);       // d l2.bias
     {   // dpre1 = (dt2 W2) * (hdn > 0)
         f32x4 acc[NT2];
         zero_acc(acc);
@@ -1283,10 +1388,10 @@ __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r,
         }
     }
     tile_put(tx1, &xh[0][0], kD + 4, row0, N);   // xhat2 is dead now
-    FragNN<NTO, 8> fwo;
+    FragNN<NTO, kD / 16> fwo;
     frag_load_nn(fwo, a.wo[r] + w * CO, DM);
     __syncthreads();
-    colsum16q(&wide[0][0], WW + 4, nullptr, 0, DFF, part + 384);       // d l1.bias
+    colsum16q(&wide[0][0], WW + 4, nullptr, 0, DFF, part + 3 * kD);    // d l1.bias
     {   // dy1 = dt2 + dpre1 W1
         f32x4 acc[NTC];
         zero_acc(acc);
@@ -1299,17 +1404,20 @@ __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r,
         }
     }
     __syncthreads();
-    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 384 + DFF, SPLIT ? 256 : 0);   // d ln1.weight
-    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 512 + DFF, SPLIT ? 384 : 0);          // d ln1.bias
+    colsum16(&ds[0][0], kD + 4, &xh[0][0], kD + 4, kD, part + 3 * kD + DFF, SPLIT ? 256 : 0);   // d ln1.weight
+    colsum16(&ds[0][0], kD + 4, nullptr, 0, kD, part + 4 * kD + DFF, SPLIT ? 384 : 0);          // d ln1.bias
     float (*d1)[kD + 4] = SPLIT ? t2 : ds;      // dt1: into the dead dt2 tile when the sums above still read dy1, else in place
     if (!SPLIT) __syncthreads();
     if (w < 4) {
         const int sub = threadIdx.x & 15;
-        ln_bwd_tile16(&ds[0][0], &d1[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g1[r] + sub * 8), ldg4(a.g1[r] + sub * 8 + 4), a.rs1[r], row0,
-                      min(kTile, N - row0), a.dt1[r]);
+        if constexpr (D == 128)
+            ln_bwd_tile16(&ds[0][0], &d1[0][0], kD + 4, &xh[0][0], kD + 4, ldg4(a.g1[r] + sub * 8), ldg4(a.g1[r] + sub * 8 + 4), a.rs1[r], row0,
+                          min(kTile, N - row0), a.dt1[r]);
+        else
+            ln_bwd_tile16_w<D>(&ds[0][0], &d1[0][0], kD + 4, &xh[0][0], kD + 4, a.g1[r], a.rs1[r], row0, min(kTile, N - row0), a.dt1[r]);
     }
     __syncthreads();
-    colsum16q(&d1[0][0], kD + 4, nullptr, 0, kD, part + 640 + DFF);    // d out-proj bias
+    colsum16q(&d1[0][0], kD + 4, nullptr, 0, kD, part + 5 * kD + DFF);    // d out-proj bias
     {   // da = dt1 Wo
         f32x4 acc[NTO];
         zero_acc(acc);
@@ -1328,7 +1436,7 @@ __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r,
     if (VPROJ) {   // dxbar[:, h, e] = sum_d da[:, h*dh+d] Wv[h*dh+d, e]
         constexpr int DH = kD / NH, QW = NH * kD;
         constexpr int EW = QW / NWV, NTE = EW / 16;
-        const int h = (w * EW) >> 7, e0 = (w * EW) & 127;
+        const int h = (w * EW) / kD, e0 = (w * EW) % kD;
         FragNN<NTE, DH / 16> fwv;
         frag_load_nn(fwv, a.wv[r] + (size_t)(h * DH) * kD + e0, kD);
         __syncthreads();
@@ -1348,14 +1456,14 @@ __device__ __forceinline__ void post_bwd_body(const PostBwdArgs& a, const int r,
     }
 }
 
-template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2>
+template <bool VPROJ, int DM, int DFF, int NWV, int NH = 2, int D = 128>
 __global__ __launch_bounds__(NWV * 64) void k_post_bwd(PostBwdArgs a) {
     constexpr int WW = (DFF > DM ? DFF : DM);
-    __shared__ __attribute__((aligned(16))) float ds[kTile][kD + 4];    // dout -> dy1 -> dt1
-    __shared__ __attribute__((aligned(16))) float xh[kTile][kD + 4];    // xhat2 -> xhat1
-    __shared__ __attribute__((aligned(16))) float t2[kTile][kD + 4];    // dt2
+    __shared__ __attribute__((aligned(16))) float ds[kTile][D + 4];    // dout -> dy1 -> dt1
+    __shared__ __attribute__((aligned(16))) float xh[kTile][D + 4];    // xhat2 -> xhat1
+    __shared__ __attribute__((aligned(16))) float t2[kTile][D + 4];    // dt2
     __shared__ __attribute__((aligned(16))) float wide[kTile][WW + 4];  // dpre1 -> da
-    post_bwd_body<VPROJ, DM, DFF, NWV, NH>(a, blockIdx.y, blockIdx.x * kTile, a.N, blockIdx.x, ds, xh, t2, wide);
+    post_bwd_body<VPROJ, DM, DFF, NWV, NH, D>(a, blockIdx.y, blockIdx.x * kTile, a.N, blockIdx.x, ds, xh, t2, wide);
 }
 
 // =======================================================================================
@@ -1632,7 +1740,9 @@ struct JoinArgs {
     float* resid[kMaxRes];       // [B,128]
     int S, T, n_res;
 };
-__global__ __launch_bounds__(128) void k_join(JoinArgs a) {
+template <int D = 128>
+__global__ __launch_bounds__(D) void k_join(JoinArgs a) {
+    constexpr int kD = D;      // (row width: shadows cf::kD)
     const int g = blockIdx.x, r = blockIdx.y, e = threadIdx.x;
     float s = 0.f;
     for (int i = 0; i < a.S; ++i) s += a.dxp[r][((size_t)g * a.S + i) * kD + e];
@@ -1653,22 +1763,24 @@ struct JoinDgradArgs {
     float* dx[kMaxRes];          // [B,128]
     int B, S, T, n_res;
 };
+template <int D = 128>
 __global__ __launch_bounds__(256) void k_join_dgrad(JoinDgradArgs a) {
+    constexpr int kD = D, KB = D / 64;      // (row width: shadows cf::kD; 16-deep k-blocks per wave)
     __shared__ __attribute__((aligned(16))) float red[4][kTile][32 + 1];
     const int r = blockIdx.z, row0 = blockIdx.x * kTile, col0 = blockIdx.y * 32;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int kw = w * 32;                            // this wave's slice of K = 128
+    const int kw = w * (kD / 4);                      // this wave's slice of K = D
     const bool rv = row0 + lr < a.B;
     const int g = rv ? row0 + lr : 0;
     const float* bp = a.w[r] + (size_t)(kw + lq * 4) * kD + col0 + 2 * lr;
-    float2 rb[2][4];
+    float2 rb[KB][4];
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < KB; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i) rb[k][i] = ldg2(bp + (size_t)(k * 16 + i) * kD);
-    float4 ra[2];
+    float4 ra[KB];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < KB; ++k) {
         const float* ap = a.dxp[r] + (size_t)g * a.S * kD + kw + k * 16 + lq * 4;
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = 0; i < a.S; ++i) {
@@ -1681,7 +1793,7 @@ __global__ __launch_bounds__(256) void k_join_dgrad(JoinDgradArgs a) {
     f32x4 acc[2];
     zero_acc(acc);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < KB; ++k) {
         const float a4[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -2098,10 +2210,11 @@ struct LpJob {
 };
 constexpr int kLpGenes = 1;
 // the partial of genes [g0, g0 + kLpGenes) of one job, by 256 threads (t256 = 0 .. 255)
-__device__ __forceinline__ void wgrad_lp_body(const LpJob& j, const int chunk, const int batch, const int t256) {
+__device__ __forceinline__ void wgrad_lp_body(const LpJob& j, const int chunk, const int batch, const int t256, const int D = kD) {
     const int g0 = chunk * kLpGenes, g1 = min(batch, g0 + kLpGenes);
     if (g0 >= batch) return;
-    const int e = t256 & 127, fh = t256 >> 7;
+    const int fh = t256 >> 7;
+    for (int e = t256 & 127; e < D; e += 128) {      // (one pass at the default row width)
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < j.nseg; ++s) {
         const WgSeg& sg = j.seg[s];
@@ -2116,13 +2229,14 @@ __device__ __forceinline__ void wgrad_lp_body(const LpJob& j, const int chunk, c
             acc[3] = fmaf(av, bv.w, acc[3]);
         }
     }
-    float* out = j.partial + (size_t)chunk * (kD * j.F) + e * j.F;
+    float* out = j.partial + (size_t)chunk * (D * j.F) + e * j.F;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (fh * 4 + k < j.F) stg(out + fh * 4 + k, acc[k]);
+    }
 }
-__global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs, int batch) {
-    wgrad_lp_body(jobs[blockIdx.y], blockIdx.x, batch, threadIdx.x);
+__global__ __launch_bounds__(256) void k_wgrad_lp(const LpJob* __restrict__ jobs, int batch, int D) {
+    wgrad_lp_body(jobs[blockIdx.y], blockIdx.x, batch, threadIdx.x, D);
 }
 
 // Deferred column sums (bias / LayerNorm / gamma gradients): out[c] = sum_m src[m][c] (* src2[m][c])
@@ -2305,13 +2419,14 @@ __global__ __launch_bounds__(256) void k_retile(const float* __restrict__ params
 }
 // First launch of a forward pass: the tiled weight copies (workgroups [0, n_units)) and, independent of them, the Embedding's
 // centre-row input x0 (one workgroup per (gene, resolution) behind them) -- one launch boundary less
+template <int D = 128>
 __global__ __launch_bounds__(256) void k_fwd_prologue(const float* __restrict__ params, float* __restrict__ tiled, float* __restrict__ tiledT,
                                                       const RetileUnit* __restrict__ units, int n_units, X0Args a, int B) {
     if ((int)blockIdx.x < n_units) {
         retile_unit(params, tiled, tiledT, units[blockIdx.x]);
-    } else if (threadIdx.x < 128) {
+    } else if (threadIdx.x < D) {
         const int i = blockIdx.x - n_units;
-        embed_x0_row(a, i / B, i % B, threadIdx.x);
+        embed_x0_row<D>(a, i / B, i % B, threadIdx.x);
     }
 }
 // the same tiling of a stand-alone row-major matrix W[rows][K] (rows, K multiples of 16): workgroup b takes rows 16 b ..

@@ -39,6 +39,13 @@ VARIANTS = {
     # L = 20 / 80 / 800: eight 800-bin regions do not fit the LDS image of the gene-batched attention kernel, every centre-row attention
     # takes the one-sequence-per-workgroup kernel (k_attc) -- with two heads here, with four in the next
     "long_rows": dict(binsizes=[2000, 500, 50], w_max=40000),
+    # d_emb = 256 (net.py:277 leaves it free; the Pairwise d_model has to follow it, net.py:361-370): the stand-alone kernels with the row width as a
+    # template parameter -- row-tile chains, one-sequence attention, layer-by-layer Regulation, the vector-ALU head
+    "d_emb_256": dict(d_emb=256, embed=dict(n_layers=1, n_heads=2, d_model=256, d_ff=128),
+                      pairwise_interaction=dict(n_layers=2, n_heads=2, d_model=256, d_ff=256)),
+    "d_emb_256_one_head": dict(d_emb=256, d_head=96, embed=dict(n_layers=1, n_heads=1, d_model=256, d_ff=256),
+                               pairwise_interaction=dict(n_layers=1, n_heads=1, d_model=256, d_ff=128),
+                               regulation=dict(n_layers=2, n_heads=4, d_model=128, d_ff=128)),
     "long_rows_4_heads": dict(binsizes=[2000, 500, 50], w_max=40000, embed=dict(n_layers=1, n_heads=4, d_model=128, d_ff=128),
                               pairwise_interaction=dict(n_layers=2, n_heads=4, d_model=128, d_ff=256)),
 }
@@ -102,7 +109,8 @@ def test_forward_and_gradients_match_oracle(name, reg):
             assert e64 <= GRAD_TOL * ref.abs().max().item() + 1e-9, (k, "against the fp32 oracle", err, "against the fp64 oracle", e64, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths", "d_head_96", "reg_4_heads_d_model_128", "mixed_heads"])
+@pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths", "d_head_96", "reg_4_heads_d_model_128", "mixed_heads",
+                                  "d_emb_256"])
 def test_fused_optimiser_and_riders_equal_the_separate_launches(name):
     """Away from the default shapes: AdamW in the reduction epilogues, both buckets in one launch, part of the tiles riding in the trunk's
     backward launch where the fused trunk kernels exist (elsewhere the trainer falls back) -- same parameters and moments, bit for bit,

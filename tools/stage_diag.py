@@ -17,10 +17,19 @@ from oracle import restructured as rst
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     reg = len(sys.argv) > 2 and sys.argv[2] == "reg"
-    batch = orc.synthetic_batch(B, seed=3, regime="realistic", regression=reg)
+    # CF_DIAG_VARIANT=<name of a tests/test_config_variants_gpu.py variant>: another configuration than the default
+    cfg = None
+    if os.environ.get("CF_DIAG_VARIANT"):
+        from tests.test_config_variants_gpu import VARIANTS
+        cfg = orc._cfg(VARIANTS[os.environ["CF_DIAG_VARIANT"]])
+    batch = orc.synthetic_batch(B, cfg=cfg, seed=3, regime="realistic", regression=reg) if cfg else orc.synthetic_batch(B, seed=3, regime="realistic", regression=reg)
     cls = ChromoformerRegressor if reg else ChromoformerClassifier
-    model = cls(seed=42, max_batch=B).cuda(0)
-    P = orc.init_params(None, 42, reg)
+    if cfg:
+        model = cls(cfg["n_feats"], cfg["d_emb"], cfg["d_head"], cfg["embed"], cfg["pairwise_interaction"], cfg["regulation"],
+                    binsizes=cfg["binsizes"], seed=42, i_max=cfg["i_max"], w_max=cfg["w_max"], max_batch=B).cuda(0)
+    else:
+        model = cls(seed=42, max_batch=B).cuda(0)
+    P = orc.init_params(cfg, 42, reg)
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for k, v in P.items():
@@ -29,7 +38,7 @@ def main():
     for t in P.values():
         t.requires_grad_(True)
     keep = {}
-    logits_ref = rst.forward(P, batch, keep=keep)
+    logits_ref = rst.forward(P, batch, cfg, keep=keep)
     for v in keep.values():
         if v.requires_grad:
             v.retain_grad()
@@ -61,12 +70,12 @@ def main():
                 cmp(tag + nm, keep[kt + nm])
             cmp(tag + "w", keep[kt + "w"], width=(7, 8))
         cmp("P%d.xp0" % r, keep["P%d.xp0" % b])
-        for l in range(2):
+        for l in range((cfg or orc._cfg(None))["pairwise_interaction"]["n_layers"]):
             tag, kt = "P%d.%d." % (r, l), "P%d.%d." % (b, l)
             for nm in ("q", "qt", "p", "xbar", "a", "y1", "hdn"):
                 cmp(tag + nm, keep[kt + nm])
         cmp("R%d.x0" % r, keep["R%d.x0" % b])
-        for l in range(6):
+        for l in range((cfg or orc._cfg(None))["regulation"]["n_layers"]):
             tag, kt = "R%d.%d." % (r, l), "R%d.%d." % (b, l)
             for nm in ("qkvg", "p", "a", "y1", "hdn"):
                 cmp(tag + nm, keep[kt + nm])
@@ -75,12 +84,12 @@ def main():
     cmp("H.h1", keep["H.h1"])
     print("---- backward intermediates")
     for r, b in enumerate(bins):
-        for l in reversed(range(6)):
+        for l in reversed(range((cfg or orc._cfg(None))["regulation"]["n_layers"])):
             tag, kt = "dR%d.%d." % (r, l), "R%d.%d." % (b, l)
             cmp(tag + "a", keep[kt + "a"].grad)
             cmp(tag + "qkvg", keep[kt + "qkvg"].grad)
         cmp("dR%d.x0" % r, keep["R%d.x0" % b].grad)
-        for l in reversed(range(2)):
+        for l in reversed(range((cfg or orc._cfg(None))["pairwise_interaction"]["n_layers"])):
             tag, kt = "dP%d.%d." % (r, l), "P%d.%d." % (b, l)
             for nm in ("a", "xbar", "qt", "q"):
                 cmp(tag + nm, keep[kt + nm].grad)
