@@ -103,9 +103,9 @@ static int check_config(const cf_config& c) {
     //  of 16 x 128 in LDS, eight waves x 16 columns -- so other widths are refused here, by name, instead of failing later)
     // round 5: d_emb = 256 as well, through the stand-alone kernels (row-tile chains, one-sequence attention, layer-by-layer Regulation, the
     // vector-ALU head), which carry the row width as a template parameter; the fused kernels are written for 128-wide rows
-    if (c.d_emb != 128 && c.d_emb != 256)
+    if (c.d_emb != 64 && c.d_emb != 128 && c.d_emb != 256)
         return fail("d_emb = %d is not supported: the HIP path implements d_emb = 128 (the reference's default, net.py:277; every fused kernel) and "
-                    "256 (stand-alone kernels)", c.d_emb);
+                    "64 / 256 (stand-alone kernels)", c.d_emb);
     if (c.d_emb != 128 && (c.embed_layers != 1 || c.embed_heads > 2 || c.pair_heads > 2))
         return fail("d_emb = %d: one Embedding layer and at most two heads in the Embedding / Pairwise stacks are implemented at this width "
                     "(got embed.n_layers = %d, n_heads = %d / %d)", c.d_emb, c.embed_layers, c.embed_heads, c.pair_heads);
@@ -1014,9 +1014,10 @@ static size_t attr_smem(int T, int H, int DM, bool bwd) {
 constexpr int kPostWaves = CF_POST_WAVES;      // waves per workgroup of the row-tile chains (k_post_*, k_qchain_*): 4 or 8
 template <bool VPROJ, int DM, int D = 128>
 static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& a) {
-    if constexpr (D != 128) {      // (rows of another width: the eight-wave chain kernels with the width as a template parameter)
-        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, 8, false, 2, D>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, 8, false, 2, D>), grid, dim3(512), 0, st, a);
+    if constexpr (D != 128) {      // (rows of another width: the chain kernels with the width as a template parameter; four waves at 64)
+        constexpr int NWV = D == 64 ? 4 : 8;
+        if (dff == 128) hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 128, NWV, false, 2, D>), grid, dim3(NWV * 64), 0, st, a);
+        else hipLaunchKernelGGL((k_post_fwd<VPROJ, DM, 256, NWV, false, 2, D>), grid, dim3(NWV * 64), 0, st, a);
         return;
     }
     if constexpr (VPROJ && DM == 128) {      // the hosting instantiation (eight waves; the Embedding layer's launch asks for it, nobody else)
@@ -1033,8 +1034,9 @@ static void launch_post_fwd(int dff, dim3 grid, hipStream_t st, const PostArgs& 
 template <bool VPROJ, int DM, int D = 128>
 static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArgs& a) {
     if constexpr (D != 128) {
-        if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, 8, 2, D>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, 8, 2, D>), grid, dim3(512), 0, st, a);
+        constexpr int NWV = D == 64 ? 4 : 8;
+        if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, NWV, 2, D>), grid, dim3(NWV * 64), 0, st, a);
+        else hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 256, NWV, 2, D>), grid, dim3(NWV * 64), 0, st, a);
         return;
     }
     if (dff == 128) hipLaunchKernelGGL((k_post_bwd<VPROJ, DM, 128, kPostWaves>), grid, dim3(kPostWaves * 64), 0, st, a);
@@ -1048,25 +1050,27 @@ static void launch_post_bwd(int dff, dim3 grid, hipStream_t st, const PostBwdArg
 template <int NH, int D = 128>
 static int centre_fwd_heads(hipStream_t st, int N, int nres, int dff, bool q_done, const QChainArgs& q, const AttcArgs& at, size_t smem,
                             const PostArgs& po) {
+    constexpr int NWV = D == 64 ? 4 : 8;      // (a wave owns at least one 16-column tile of a D-wide product)
     if (!q_done) {
-        hipLaunchKernelGGL((k_qchain_fwd<8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, q);
+        hipLaunchKernelGGL((k_qchain_fwd<NWV, NH, D>), dim3(tiles_of(N), nres), dim3(NWV * 64), 0, st, q);
         LAUNCH_CHECK("k_qchain_fwd");
     }
     hipLaunchKernelGGL((k_attc<false, NH, D>), dim3(N, nres), dim3(256), smem, st, at);
     LAUNCH_CHECK("k_attc<fwd>");
-    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<true, D, 128, 8, false, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
-    else hipLaunchKernelGGL((k_post_fwd<true, D, 256, 8, false, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, po);
+    if (dff == 128) hipLaunchKernelGGL((k_post_fwd<true, D, 128, NWV, false, NH, D>), dim3(tiles_of(N), nres), dim3(NWV * 64), 0, st, po);
+    else hipLaunchKernelGGL((k_post_fwd<true, D, 256, NWV, false, NH, D>), dim3(tiles_of(N), nres), dim3(NWV * 64), 0, st, po);
     LAUNCH_CHECK("k_post_fwd<centre>");
     return 0;
 }
 template <int NH, int D = 128>
 static int centre_bwd_heads(hipStream_t st, int N, int nres, int dff, const PostBwdArgs& pb, const AttcArgs& at, size_t smem, const QBwdArgs& qb) {
-    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<true, D, 128, 8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
-    else hipLaunchKernelGGL((k_post_bwd<true, D, 256, 8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, pb);
+    constexpr int NWV = D == 64 ? 4 : 8;
+    if (dff == 128) hipLaunchKernelGGL((k_post_bwd<true, D, 128, NWV, NH, D>), dim3(tiles_of(N), nres), dim3(NWV * 64), 0, st, pb);
+    else hipLaunchKernelGGL((k_post_bwd<true, D, 256, NWV, NH, D>), dim3(tiles_of(N), nres), dim3(NWV * 64), 0, st, pb);
     LAUNCH_CHECK("k_post_bwd<centre>");
     hipLaunchKernelGGL((k_attc<true, NH, D>), dim3(N, nres), dim3(256), smem, st, at);
     LAUNCH_CHECK("k_attc<bwd>");
-    hipLaunchKernelGGL((k_qchain_bwd<8, NH, D>), dim3(tiles_of(N), nres), dim3(512), 0, st, qb);
+    hipLaunchKernelGGL((k_qchain_bwd<NWV, NH, D>), dim3(tiles_of(N), nres), dim3(NWV * 64), 0, st, qb);
     LAUNCH_CHECK("k_qchain_bwd");
     return 0;
 }
@@ -1330,6 +1334,9 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
             if (kD == 256)
                 hipLaunchKernelGGL(k_fwd_prologue<256>, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
                                    h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
+            else if (kD == 64)
+                hipLaunchKernelGGL(k_fwd_prologue<64>, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
+                                   h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
             else
                 hipLaunchKernelGGL(k_fwd_prologue<128>, dim3(n_now + (trunk ? 0 : B * nres)), dim3(256), 0, st, (const float*)h->params, h->tiled,
                                    h->reg8 ? h->tiledT : (float*)nullptr, units, n_now, a, B);
@@ -1440,9 +1447,10 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         po.omap = omap;
         po.N = N;
         po.save = save;
-        if (kD == 256) {      // (rows of 256: the stand-alone kernels with the width as a template parameter; one or two heads)
-            if (smem > 64 * 1024) return fail("cf_forward: a region of %d bins does not fit the one-sequence attention at d_emb = 256", c.n_bins[nres - 1]);
-            return nh == 1 ? centre_fwd_heads<1, 256>(st, N, nres, dff, q_done, q, at, smem, po) : centre_fwd_heads<2, 256>(st, N, nres, dff, q_done, q, at, smem, po);
+        if (kD != 128) {      // (rows of 64 / 256: the stand-alone kernels with the width as a template parameter; one or two heads)
+            if (smem > 64 * 1024) return fail("cf_forward: a region of %d bins does not fit the one-sequence attention at d_emb = %d", c.n_bins[nres - 1], kD);
+            if (kD == 256) return nh == 1 ? centre_fwd_heads<1, 256>(st, N, nres, dff, q_done, q, at, smem, po) : centre_fwd_heads<2, 256>(st, N, nres, dff, q_done, q, at, smem, po);
+            return nh == 1 ? centre_fwd_heads<1, 64>(st, N, nres, dff, q_done, q, at, smem, po) : centre_fwd_heads<2, 64>(st, N, nres, dff, q_done, q, at, smem, po);
         }
         if (nh == 1) return centre_fwd_heads<1>(st, N, nres, dff, q_done, q, at, smem, po);
         if (nh == 4) return centre_fwd_heads<4>(st, N, nres, dff, q_done, q, at, smem, po);
@@ -1645,13 +1653,17 @@ static int forward_impl(cf_handle* h, const cf_batch* bt, float* logits, int sav
         po.omap = identity_map();
         po.N = NR;
         po.save = save;
-        hipLaunchKernelGGL((k_linear_fwd<4>), dim3(tiles_of(NR), RW / 256, nres), dim3(256), 0, st, la);
+        if (kD == 64) hipLaunchKernelGGL((k_linear_fwd<4, 64>), dim3(tiles_of(NR), RW / 256, nres), dim3(256), 0, st, la);
+        else hipLaunchKernelGGL((k_linear_fwd<4>), dim3(tiles_of(NR), RW / 256, nres), dim3(256), 0, st, la);
         LAUNCH_CHECK("k_linear_fwd<qkvg>");
         hipLaunchKernelGGL((k_attr<false>), dim3(B, nres), dim3(256), attr_smem(T, at.H, RDm, false), st, at);
         LAUNCH_CHECK("k_attr<fwd>");
         if (kD == 256) {
             if (RDm == 128) launch_post_fwd<false, 128, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
             else launch_post_fwd<false, 256, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+        } else if (kD == 64) {
+            if (RDm == 128) launch_post_fwd<false, 128, 64>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
+            else launch_post_fwd<false, 256, 64>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         } else if (RDm == 128) launch_post_fwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         else launch_post_fwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, po);
         LAUNCH_CHECK("k_post_fwd<reg>");
@@ -1861,6 +1873,9 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         if (kD == 256) {
             if (RDm == 128) launch_post_bwd<false, 128, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
             else launch_post_bwd<false, 256, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+        } else if (kD == 64) {
+            if (RDm == 128) launch_post_bwd<false, 128, 64>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
+            else launch_post_bwd<false, 256, 64>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
         } else if (RDm == 128) launch_post_bwd<false, 128>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
         else launch_post_bwd<false, 256>(c.reg_dff, dim3(tiles_of(NR), nres), st, pb);
         LAUNCH_CHECK("k_post_bwd<reg>");
@@ -1969,6 +1984,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         at.scale = scale_c;
         qb.N = N;
         if (kD == 256) return nh == 1 ? centre_bwd_heads<1, 256>(st, N, nres, dff, pb, at, smem, qb) : centre_bwd_heads<2, 256>(st, N, nres, dff, pb, at, smem, qb);
+        if (kD == 64) return nh == 1 ? centre_bwd_heads<1, 64>(st, N, nres, dff, pb, at, smem, qb) : centre_bwd_heads<2, 64>(st, N, nres, dff, pb, at, smem, qb);
         if (nh == 1) return centre_bwd_heads<1>(st, N, nres, dff, pb, at, smem, qb);
         if (nh == 4) return centre_bwd_heads<4>(st, N, nres, dff, pb, at, smem, qb);
         launch_post_bwd<true, 128>(dff, dim3(tiles_of(N), nres), st, pb);
@@ -2046,6 +2062,7 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         a.T = T;
         a.n_res = nres;
         if (kD == 256) hipLaunchKernelGGL(k_join_dgrad<256>, dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
+        else if (kD == 64) hipLaunchKernelGGL(k_join_dgrad<64>, dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_join_dgrad<128>, dim3(tiles_of(NE), kD / 32, nres), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_join_dgrad");
     }

@@ -535,20 +535,24 @@ __device__ __forceinline__ void ln_bwd_tile16(const float* src, float* dst, int 
 }
 // ---- Rows wider than 128 (d_emb = 256, round 5): the same 16-lanes-per-row LayerNorm over D / 128 chunks of 8 floats per lane.  The
 // 128-wide functions above stay as they are (the default shape compiles to the code it always had); the chain bodies pick by `D`.
+// column of the i-th float4 of lane `sub` (16 lanes per row): D = 64: one float4 at 4 sub; D = 128 c: chunks of 128 columns, two float4 at 8 sub each
+template <int D>
+__device__ __forceinline__ int ln_col_w(int sub, int i) {
+    return D == 64 ? sub * 4 : (i >> 1) * 128 + sub * 8 + (i & 1) * 4;
+}
 template <int D>
 struct LnParamsW {
-    float4 g[D / 64], b[D / 64];      // chunk c: columns 128 c + 8 sub .. + 7  ->  g[2 c], g[2 c + 1]
+    float4 g[D / 64], b[D / 64];
 };
 template <int D>
 __device__ __forceinline__ LnParamsW<D> ln_params_load_w(const float* g, const float* b) {
+    static_assert(D == 64 || D % 128 == 0, "row widths: 64 or a multiple of 128");
     const int sub = threadIdx.x & 15;
     LnParamsW<D> p;
 #pragma unroll
-    for (int c = 0; c < D / 128; ++c) {
-        p.g[2 * c] = ldg4(g + c * 128 + sub * 8);
-        p.g[2 * c + 1] = ldg4(g + c * 128 + sub * 8 + 4);
-        p.b[2 * c] = ldg4(b + c * 128 + sub * 8);
-        p.b[2 * c + 1] = ldg4(b + c * 128 + sub * 8 + 4);
+    for (int i = 0; i < D / 64; ++i) {
+        p.g[i] = ldg4(g + ln_col_w<D>(sub, i));
+        p.b[i] = ldg4(b + ln_col_w<D>(sub, i));
     }
     return p;
 }
@@ -557,12 +561,12 @@ __device__ __forceinline__ void ln_fwd_tile16_w(float* ts, int ld, const LnParam
                                                 float* y_g, const RowMap ymap = RowMap{1, 1, 0, 0}) {
     constexpr int NV = D / 64;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, row = w * 4 + (lane >> 4), sub = lane & 15;
-    float* tp = ts + row * ld + sub * 8;
+    float* tp = ts + row * ld;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = *reinterpret_cast<const float4*>(tp + (i >> 1) * 128 + (i & 1) * 4);
+        v[i] = *reinterpret_cast<const float4*>(tp + ln_col_w<D>(sub, i));
         s += sum4(v[i]);
     }
     const float mean = group16_sum(s) * (1.0f / D);
@@ -576,12 +580,12 @@ __device__ __forceinline__ void ln_fwd_tile16_w(float* ts, int ld, const LnParam
     const float rstd = 1.0f / sqrtf(var + kLnEps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int co = (i >> 1) * 128 + (i & 1) * 4;
+        const int co = ln_col_w<D>(sub, i);
         const float4 x = f4_scale(v[i], rstd), y = f4_fma(x, P.g[i], P.b[i]);
         *reinterpret_cast<float4*>(tp + co) = y;
         if (row < nvalid) {
-            if (xhat_g) stg4(xhat_g + (size_t)(row0 + row) * D + sub * 8 + co, x);
-            if (y_g) stg4(y_g + (size_t)map_row(ymap, row0 + row) * D + sub * 8 + co, y);
+            if (xhat_g) stg4(xhat_g + (size_t)(row0 + row) * D + co, x);
+            if (y_g) stg4(y_g + (size_t)map_row(ymap, row0 + row) * D + co, y);
         }
     }
     if (row < nvalid && xhat_g && sub == 0) stg(rstd_g + row0 + row, rstd);
@@ -595,7 +599,7 @@ __device__ __forceinline__ void ln_bwd_tile16_w(const float* src, float* dst, in
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int co = sub * 8 + (i >> 1) * 128 + (i & 1) * 4;
+        const int co = ln_col_w<D>(sub, i);
         a[i] = f4_mul(*reinterpret_cast<const float4*>(src + row * ld + co), ldg4(g + co));
         x[i] = *reinterpret_cast<const float4*>(xh + row * ldx + co);
         s1 += sum4(a[i]);
@@ -605,7 +609,7 @@ __device__ __forceinline__ void ln_bwd_tile16_w(const float* src, float* dst, in
     const float rs = row < nvalid ? ldg(rstd_g + row0 + row) : 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int co = sub * 8 + (i >> 1) * 128 + (i & 1) * 4;
+        const int co = ln_col_w<D>(sub, i);
         const float4 o = make_float4(rs * (a[i].x - m1 - x[i].x * m2), rs * (a[i].y - m1 - x[i].y * m2), rs * (a[i].z - m1 - x[i].z * m2),
                                      rs * (a[i].w - m1 - x[i].w * m2));
         *reinterpret_cast<float4*>(dst + row * ld + co) = o;
@@ -1480,9 +1484,10 @@ struct LinArgs {
     int ldy;
     int N, K, Nout, relu;
 };
-constexpr int kKChunk = 128;   // reduction columns per fragment set / LDS stage
-template <int NT>
+constexpr int kKChunk0 = 128;   // reduction columns per fragment set / LDS stage (KCH = 64 for K = 64: rows of d_emb = 64)
+template <int NT, int KCH = kKChunk0>
 __global__ __launch_bounds__(256) void k_linear_fwd(LinArgs a) {
+    constexpr int kKChunk = KCH;
     __shared__ __attribute__((aligned(16))) float xs[2][kTile][kKChunk + 4];
     const int r = blockIdx.z, row0 = blockIdx.x * kTile, K = a.K;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -1493,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(LinArgs a) {
     zero_acc(acc);
     int buf = 0;
     for (int kc = 0; kc < K; kc += kKChunk, buf ^= 1) {
-        FragNT<NT, 8> f;
+        FragNT<NT, kKChunk / 16> f;
         frag_load_nt(f, wp + (size_t)kc * 16, K);     // tiled layout: reduction offset kc -> (kc/16)*256 floats
         load_tile(&xs[buf][0][0], kKChunk + 4, a.x[r] + kc, a.ldx, kKChunk, row0, a.N, a.xmap);
         __syncthreads();

@@ -57,8 +57,8 @@ def test_unsupported_configs_are_rejected_loudly():
     assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
     assert b"embed.n_layers" in _lib.lib().cf_last_error()
     # widths the reference leaves free (net.py:277-278) and this library does not implement: refused by name, with the reference site
-    # (d_head: any multiple of 4 up to 1024 -- 128 on the matrix cores, other widths on the vector ALUs; d_emb: 128 only)
-    for field, value, site in (("d_emb", 256, b"net.py:277"), ("d_head", 130, b"net.py:278"), ("d_head", 2048, b"net.py:278")):
+    # (d_head: any multiple of 4 up to 1024 -- 128 on the matrix cores, other widths on the vector ALUs; d_emb: 64, 128, 256 since round 5)
+    for field, value, site in (("d_emb", 192, b"net.py:277"), ("d_emb", 512, b"net.py:277"), ("d_head", 130, b"net.py:278"), ("d_head", 2048, b"net.py:278")):
         cfg = _cfg()
         setattr(cfg, field, value)
         assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0
@@ -67,6 +67,15 @@ def test_unsupported_configs_are_rejected_loudly():
     cfg = _cfg()
     cfg.d_head = 96
     assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) == 0
+    # d_emb = 64 / 256: the Embedding and the Pairwise widths follow it (net.py:305, 361-370), one Embedding layer, at most two heads there
+    for d in (64, 256):
+        cfg = _cfg()
+        cfg.d_emb = cfg.embed_dmodel = cfg.pair_dmodel = d
+        assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) == 0, _lib.lib().cf_last_error()
+        cfg.pair_dmodel = 128                                                      # the two widths must agree
+        assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0 and b"d_model = d_emb" in _lib.lib().cf_last_error()
+        cfg.pair_dmodel, cfg.embed_heads = d, 4
+        assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0 and b"at most two heads" in _lib.lib().cf_last_error()
     # head counts: Embedding / Pairwise 1, 2, 4 (d_model = 128), Regulation 4 or 8 heads with d_model 128 or 256; the rest is refused by name
     for field, value, ok in (("embed_heads", 1, True), ("embed_heads", 4, True), ("embed_heads", 8, False), ("pair_heads", 4, True),
                              ("pair_heads", 3, False), ("pair_dmodel", 256, False), ("reg_heads", 4, True), ("reg_heads", 2, False),

@@ -46,6 +46,11 @@ VARIANTS = {
     "d_emb_256_one_head": dict(d_emb=256, d_head=96, embed=dict(n_layers=1, n_heads=1, d_model=256, d_ff=256),
                                pairwise_interaction=dict(n_layers=1, n_heads=1, d_model=256, d_ff=128),
                                regulation=dict(n_layers=2, n_heads=4, d_model=128, d_ff=128)),
+    "d_emb_64": dict(d_emb=64, embed=dict(n_layers=1, n_heads=2, d_model=64, d_ff=128),
+                     pairwise_interaction=dict(n_layers=2, n_heads=2, d_model=64, d_ff=256)),
+    "d_emb_64_one_head": dict(d_emb=64, d_head=256, embed=dict(n_layers=1, n_heads=1, d_model=64, d_ff=256),
+                              pairwise_interaction=dict(n_layers=3, n_heads=1, d_model=64, d_ff=128),
+                              regulation=dict(n_layers=2, n_heads=8, d_model=128, d_ff=256)),
     "long_rows_4_heads": dict(binsizes=[2000, 500, 50], w_max=40000, embed=dict(n_layers=1, n_heads=4, d_model=128, d_ff=128),
                               pairwise_interaction=dict(n_layers=2, n_heads=4, d_model=128, d_ff=256)),
 }
@@ -110,7 +115,7 @@ def test_forward_and_gradients_match_oracle(name, reg):
 
 
 @pytest.mark.parametrize("name", ["i_max4", "i_max12", "shallow_narrow", "deep_reg", "three_pairwise_layers", "odd_lengths", "d_head_96", "reg_4_heads_d_model_128", "mixed_heads",
-                                  "d_emb_256"])
+                                  "d_emb_256", "d_emb_64"])
 def test_fused_optimiser_and_riders_equal_the_separate_launches(name):
     """Away from the default shapes: AdamW in the reduction epilogues, both buckets in one launch, part of the tiles riding in the trunk's
     backward launch where the fused trunk kernels exist (elsewhere the trainer falls back) -- same parameters and moments, bit for bit,
