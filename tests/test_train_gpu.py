@@ -59,15 +59,18 @@ def test_training_run_matches_reference_checkpoint(tmp_path, reg):
     m.load_state_dict(c["net"])
 
 
-def test_an_edited_config_trains(tmp_path):
-    """configs/default.yaml:14-31 with other head counts / Regulation width (the shapes of tests/test_config_variants_gpu.py, checked there against the oracle)
-    through the training entrypoint: constructs, trains, validates, saves a checkpoint of the edited shapes that loads back."""
+@pytest.mark.parametrize("d_emb", [128, 256, 64])
+def test_an_edited_config_trains(tmp_path, d_emb):
+    """configs/default.yaml:14-31 with other head counts / Regulation width / row width (the shapes of tests/test_config_variants_gpu.py, checked there against
+    the oracle) through the training entrypoint: constructs, trains, validates, saves a checkpoint of the edited shapes that loads back.  `d_emb` is the
+    Embedding's d_model in the entrypoint (train.py:266 here, train.py of the reference likewise); the Pairwise d_model has to follow it (net.py:361-370)."""
     from chromoformer_amd import train, ChromoformerClassifier
     meta = make_dataset(str(tmp_path / "npy"), n_genes=48, seed=2024)
     cfg = yaml.safe_load(open(os.path.join(ROOT, "chromoformer_amd", "configs", "default.yaml")))
     cfg["bsz"], cfg["num_epoch"] = 8, 2
-    cfg["embed"]["n_heads"] = 4
+    cfg["embed"]["n_heads"] = 4 if d_emb == 128 else 2
     cfg["pairwise_interaction"]["n_heads"] = 1
+    cfg["embed"]["d_model"] = cfg["pairwise_interaction"]["d_model"] = d_emb
     cfg["regulation"].update(n_heads=4, d_model=128, n_layers=3)
     cfg_path = str(tmp_path / "cfg.yaml")
     yaml.safe_dump(cfg, open(cfg_path, "w"))
@@ -78,7 +81,8 @@ def test_an_edited_config_trains(tmp_path):
     net = c["net"]
     assert net["regulation.2000.transformer.layers.0.self_att.att.weight"].shape == (512, 128)
     assert net["regulation.2000.transformer.layers.0.self_att.gamma_f"].shape == (4,)
-    assert net["embed.100.transformer.layers.0.self_att.gamma_f"].shape == (4,)
+    assert net["embed.100.transformer.layers.0.self_att.gamma_f"].shape == (4 if d_emb == 128 else 2,)
+    assert net["embed.100.transformer.layers.0.self_att.att.weight"].shape[1] == d_emb and net["embed.100.lin_proj.weight"].shape[0] == d_emb
     assert "regulation.2000.transformer.layers.3.ff.l1.weight" not in net
     assert np.isfinite(float(c["last_val_loss"])) and all(torch.isfinite(v).all() for v in net.values())
     m = ChromoformerClassifier(cfg["n_feats"] if "n_feats" in cfg else 7, cfg["embed"]["d_model"], cfg.get("d_head", 128), cfg["embed"], cfg["pairwise_interaction"],
