@@ -2768,6 +2768,21 @@ static int attn_args(const cf_attn_shape* sh, AttnArgs& a) {
     a.rscale = 1.0f / sqrtf((float)kADh);
     return 0;
 }
+// The dense attention forward: k_attn_fwd (round 5: transposed score tiles, 128 query rows per workgroup); CF_ATTN_FWD_V1=1 runs the round-1
+// kernel (64 rows per workgroup, P through a per-wave LDS patch) -- the cross-check of the tests.  Same results up to the order of the fp32
+// additions inside P V.
+static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
+    if (getenv_int("CF_ATTN_FWD_V1", 0)) {
+        hipLaunchKernelGGL(k_attn_fwd_v1, dim3((a.Lq + kABq - 1) / kABq, a.H, a.N), dim3(256), 0, st, a);
+        LAUNCH_CHECK("k_attn_fwd_v1");
+        return 0;
+    }
+    const dim3 grid((a.Lq + kABq2 - 1) / kABq2, a.H, a.N);
+    if (a.mask) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, st, a);
+    LAUNCH_CHECK("k_attn_fwd");
+    return 0;
+}
 extern "C" int cf_op_attention_fwd(const cf_attn_shape* sh, const float* q, const float* k, const float* v, const unsigned char* qvalid,
                                    const unsigned char* kvalid, const unsigned char* mask, float* o, float* stats, void* stream) {
     AttnArgs a;
@@ -2781,8 +2796,7 @@ extern "C" int cf_op_attention_fwd(const cf_attn_shape* sh, const float* q, cons
     a.mask = mask;
     a.o = o;
     a.stats = stats;
-    hipLaunchKernelGGL(k_attn_fwd, dim3((a.Lq + kABq - 1) / kABq, a.H, a.N), dim3(256), 0, (hipStream_t)stream, a);
-    LAUNCH_CHECK("k_attn_fwd");
+    if (attn_fwd_launch(a, (hipStream_t)stream)) return -1;
     return 0;
 }
 // dQ, dK, dV of the dense attention core (delta = rowsum(dO * O) is in a.delta already).  One fused pass per (sequence, head)
@@ -2979,8 +2993,7 @@ static int dense_layer_fwd(const cf_dense_layer* w, const float* x_q, const floa
         a.mask = mask;
         a.o = ws + L.o;
         a.stats = train ? ws + L.stats : nullptr;
-        hipLaunchKernelGGL(k_attn_fwd, dim3((Lq + kABq - 1) / kABq, 2, N), dim3(256), 0, st, a);
-        LAUNCH_CHECK("k_attn_fwd<dense layer>");
+        if (attn_fwd_launch(a, st)) return -1;
     }
     {
         PostArgs p;

@@ -68,6 +68,15 @@ __device__ __forceinline__ void attn_put(float* dst, const AttnTileRegs& t) {
     }
 }
 
+// the same fetch as (scalar base of the (sequence, head)) + (32-bit lane offset): no 64-bit per-lane address lives across the tile loop
+__device__ __forceinline__ void attn_fetch_s(AttnTileRegs& t, const float* seq, int ld, int r0, int rows) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = threadIdx.x + 256 * p, j = r0 + (i >> 4), d4 = i & 15;
+        const float4 v = ldg4(lane_at(sbase(seq, 0), (unsigned)(min(j, rows - 1) * ld + d4 * 4) * 4u));
+        t.v[p] = f4_keep_if(j < rows, v);
+    }
+}
 // acc[t] (16 x 16 tiles, t = 0..3) += A[16 x 64] . B^T where B is a [64 x 64] LDS tile read along its rows:
 // out column 16t + r <-> B row 16t + r, reduction over the 64 columns of A and B (float4 reads, permuted k order).
 __device__ __forceinline__ void attn_mma_nt(const float4 (&af)[4], const float* Bs, f32x4 (&acc)[4]) {
@@ -106,7 +115,7 @@ __device__ __forceinline__ void attn_store_d(float* Ps, const f32x4 (&acc)[4]) {
         for (int g = 0; g < 4; ++g) Ps[(4 * q + g) * kALd + 16 * t + r] = acc[t][g];
 }
 
-__global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void k_attn_fwd_v1(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Ps[4][16 * kALd];
@@ -208,6 +217,206 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
         if (a.stats && r == 0) {
             float* sp = a.stats + (((size_t)n * a.H + h) * a.Lq + rowi[g]) * 2;
             sp[0] = m[g];
+            sp[1] = inv;
+        }
+    }
+}
+
+// Round 5: the forward on TRANSPOSED score tiles.  S^T = K Q^T puts, in the accumulator layout, query row r of a 16-row block into
+// lanes (r, quarter q) with keys 4 q + g of a 16-key block in its four registers -- which is exactly the B operand of the second
+// product when that one is written transposed as well, O^T[dh x queries] += V^T[dh x keys] . P^T[keys x queries], with the reduction
+// walking the keys of a block in the order (4 q + g: g outer, q across the lanes) instead of (4 g' + q).  P never leaves its registers:
+// no per-wave LDS patch, no store / wave barrier / reload between the softmax and the second product (k_attn_fwd_v1 above: 16 stores +
+// 4 wide loads per tile and wave, 17 KB of LDS per workgroup).  A query row's statistics are one value per lane (the maximum is
+// combined over the four quarter lanes with two cross-lane steps, the sum stays a per-lane partial until the end), the output leaves as
+// 16-byte stores.  A wave owns TWO 16-row blocks (a workgroup 128 query rows): every K row / V element read from LDS feeds two MFMAs.
+// Key blocks beyond the tensor (the last tile of L = 800 holds 32 keys) and waves without a live row issue no products.
+constexpr int kABq2 = 128;      // query rows per workgroup of k_attn_fwd
+__device__ __forceinline__ float quarter_max(float v) {      // over the four lanes (r, q = 0..3) of a query row
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quarter_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+// HAS_MASK: the arbitrary byte mask [N, Lq, Lk] (one byte load per score); without it the mask is the outer product of the two validity vectors and
+// the whole replacement is ONE fused multiply-add per score: x = s * sel + bias with, per key, (sel, bias) = (1 / sqrt(dh), 0) for a real bin,
+// (0, -1e9) for a padded one, (0, -inf) beyond the tensor -- the pair travels with the K / V tile -- and, per query row, sel *= 0 / bias = min(bias, -1e9)
+// where the row itself is padding.  (The per-score form of this -- `a.mask ? byte : !(qv && kv)` inside the loops -- compiled to a scalar branch
+// sequence per score, 34 of them per tile and wave whether a mask was there or not: a fifth of the kernel's time.)
+template <bool HAS_MASK>
+__global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
+    __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
+    __shared__ __attribute__((aligned(16))) float Ksel[kABk];      // per key of the tile: the score's factor ...
+    __shared__ __attribute__((aligned(16))) float Kbias[kABk];     // ... and what is added (see above)
+    const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * kABq2;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
+    const int qw = q0 + 32 * w;                           // first row of this wave
+    const bool live_w = qw < a.Lq;
+    float4 qf[2][4];                                      // row qw + 16 b + r, head columns 16 u + 4 qd ..: the B operand of S^T
+    int row[2];
+    float qsel[2], qbias[2];                              // a padded query row (or one beyond the tensor, never stored): every score is the mask fill
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        row[b] = qw + 16 * b + r;
+        const float* qp = a.q + ((size_t)n * a.Lq + min(row[b], a.Lq - 1)) * a.ldq + h * kADh + 4 * qd;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qf[b][u] = row[b] < a.Lq ? ldg4(qp + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool qv = row[b] < a.Lq && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + row[b]] != 0 : true);
+        qsel[b] = qv ? 1.f : 0.f;
+        qbias[b] = qv ? 0.f : kMaskFill;
+    }
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    f32x4 o[2][4];                                        // O^T: lane (r, qd) holds head columns 16 t' + 4 qd + g of row r
+    zero_acc(o[0]);
+    zero_acc(o[1]);
+    const float* kbase = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
+    const float* vbase = a.v + (size_t)n * a.Lk * a.ldv + h * kADh;
+    AttnTileRegs kr, vr;
+    attn_fetch_s(kr, kbase, a.ldk, 0, a.Lk);
+    attn_fetch_s(vr, vbase, a.ldv, 0, a.Lk);
+    const auto kv_fetch = [&](int k0n) {                  // 1: real bin, 0: padded, -1: beyond the tensor
+        const int j = k0n + (int)threadIdx.x;
+        if (threadIdx.x >= kABk || j >= a.Lk) return -1.f;
+        return (HAS_MASK || attn_kvalid(a, n, j)) ? 1.f : 0.f;
+    };
+    float kvn = kv_fetch(0);
+    for (int k0 = 0; k0 < a.Lk; k0 += kABk) {
+        __syncthreads();
+        attn_put(Ks, kr);
+        attn_put(Vs, vr);
+        if (threadIdx.x < kABk) {
+            Ksel[threadIdx.x] = kvn > 0.f ? a.rscale : 0.f;
+            Kbias[threadIdx.x] = kvn > 0.f ? 0.f : (kvn < 0.f ? -INFINITY : kMaskFill);
+        }
+        __syncthreads();
+        const int nkb = min(4, (a.Lk - k0 + 15) >> 4);    // key blocks of this tile that hold a key
+        f32x4 s[2][4];
+        zero_acc(s[0]);
+        zero_acc(s[1]);
+        // (the sched barriers keep the LDS reads of ONE key block in front of its products: left alone the scheduler issues all 16 wide reads
+        //  of the tile first -- 64 registers -- and the kernel spills)
+        if (live_w) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nkb) {
+                    float4 kk[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kk[u] = *reinterpret_cast<const float4*>(Ks + (16 * t + r) * kALd + 16 * u + 4 * qd);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            s[b][t] = mfma4(kk[u].x, qf[b][u].x, s[b][t]);
+                            s[b][t] = mfma4(kk[u].y, qf[b][u].y, s[b][t]);
+                            s[b][t] = mfma4(kk[u].z, qf[b][u].z, s[b][t]);
+                            s[b][t] = mfma4(kk[u].w, qf[b][u].w, s[b][t]);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the next tile is requested between the softmax and the second product: in front of the score products its 32 registers meet the K rows
+        // of a key block, in front of the softmax the per-key factors
+        const auto prefetch = [&]() {
+            if (k0 + kABk < a.Lk) {
+                attn_fetch_s(kr, kbase, a.ldk, k0 + kABk, a.Lk);
+                attn_fetch_s(vr, vbase, a.ldv, k0 + kABk, a.Lk);
+                kvn = kv_fetch(k0 + kABk);
+            }
+        };
+        if (!live_w) {                                    // (uniform per wave; the barriers above are the loop's only ones)
+            prefetch();
+            continue;
+        }
+        float mxs[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 ks4 = *reinterpret_cast<const float4*>(Ksel + 16 * t + 4 * qd);
+            const float4 kb4 = *reinterpret_cast<const float4*>(Kbias + 16 * t + 4 * qd);
+            const float ksel[4] = {ks4.x, ks4.y, ks4.z, ks4.w}, kbias[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float x = fmaf(s[b][t][g], ksel[g] * qsel[b], fminf(kbias[g], qbias[b]));
+                    if (HAS_MASK) {                       // (the byte decides; beyond the tensor stays -inf)
+                        const int j = k0 + 16 * t + 4 * qd + g;
+                        if (j < a.Lk && row[b] < a.Lq && a.mask[((size_t)n * a.Lq + row[b]) * a.Lk + j] != 0) x = kMaskFill;
+                    }
+                    s[b][t][g] = x;
+                    mxs[b] = fmaxf(mxs[b], x);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float mx = quarter_max(mxs[b]);
+            const float mn = fmaxf(m[b], mx);             // (finite from the first tile on: it holds a key of the tensor)
+            const float alpha = __expf(m[b] - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float p = __expf(s[b][t][g] - mn);
+                    s[b][t][g] = p;
+                    ps += p;
+                }
+            l[b] = l[b] * alpha + ps;                     // this lane's keys only; the quarters are summed behind the loop
+            m[b] = mn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[b][t] *= alpha;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prefetch();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < nkb) {
+#pragma unroll
+                for (int gh = 0; gh < 2; ++gh) {
+                    float av[2][4];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) av[g][tp] = Vs[(16 * t + 4 * qd + 2 * gh + g) * kALd + r + 16 * tp];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) {
+                            o[0][tp] = mfma4(av[g][tp], s[0][t][2 * gh + g], o[0][tp]);
+                            o[1][tp] = mfma4(av[g][tp], s[1][t][2 * gh + g], o[1][tp]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    if (!live_w) return;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float lt = quarter_sum(l[b]);
+        if (row[b] >= a.Lq) continue;
+        const float inv = 1.0f / lt;
+        float* op = a.o + ((size_t)n * a.Lq + row[b]) * a.ldo + h * kADh + 4 * qd;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const float4 v = make_float4(o[b][tp][0] * inv, o[b][tp][1] * inv, o[b][tp][2] * inv, o[b][tp][3] * inv);
+            if ((a.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(a.o) & 15) == 0) {
+                stg4(op + 16 * tp, v);
+            } else {
+                op[16 * tp] = v.x;
+                op[16 * tp + 1] = v.y;
+                op[16 * tp + 2] = v.z;
+                op[16 * tp + 3] = v.w;
+            }
+        }
+        if (a.stats && qd == 0) {
+            float* sp = a.stats + (((size_t)n * a.H + h) * a.Lq + row[b]) * 2;
+            sp[0] = m[b];
             sp[1] = inv;
         }
     }
