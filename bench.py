@@ -187,8 +187,9 @@ def stress_main(args, json_out):
     section 8-d defines it (the reference cannot run it): the roofline run of the DENSE attention core, all L x L rows,
     forward + backward, on the N = 128 * 17 sequences of a batch (cf_op_attention_fwd / _bwd, csrc/cf_attn.h).  A step is
     one forward + backward over the batch; `value` is genes/s of that core alone, `roofline` its algorithmic flops
-    (4 N H L^2 dh forward, 10 N H L^2 dh backward: S and dP are recomputed once in the one-pass backward and counted once) against
-    the f32 MFMA peak, from HIP events on the launch stream."""
+    (4 N H L^2 dh forward, 10 N H L^2 dh backward -- the usual accounting of attention kernels: dV, dP, dQ, dK and the QK^T that a backward
+    without a stored P executes again, once, in the one-pass kernel; `frac_no_recompute` leaves that re-execution out: 12 instead of 14)
+    against the f32 MFMA peak, from HIP events on the launch stream."""
     import ctypes as C
     from chromoformer_amd import _lib
     B, S, H, L = 128, 16, 2, 800
@@ -238,7 +239,7 @@ def stress_main(args, json_out):
                                   "N = 128 x 17 = %d sequences x %d heads, L = %d, dh = 64 -- attention kernels only, not a training step" % (N, H, L),
                       "parallelism": "dp1", "global_batch": B},
            "roofline": {"kernel": "k_attn_fwd + k_attn_delta + k_attn_bwd (dQ, dK, dV in one pass per (sequence, head))", "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3,
-                        "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None, "avg_launch_us": round(dev_ms * 1e3, 1),
+                        "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "frac_no_recompute": round(ach * 12.0 / 14.0 / 157.3, 4), "traffic": None, "avg_launch_us": round(dev_ms * 1e3, 1),
                         "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}}
     json_out.write(json.dumps(out) + "\n")
     json_out.flush()

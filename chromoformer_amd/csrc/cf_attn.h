@@ -60,6 +60,17 @@ __device__ __forceinline__ void attn_fetch(AttnTileRegs& t, const float* __restr
         t.v[p] = r0 + j < rows ? ldg4(src + (size_t)(r0 + j) * ld + d4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+// (NT: streaming loads -- the one-pass backward walks 615 KB of Q / dO / dQ per workgroup once per key tile, 768 workgroups at a time: nothing it
+//  fetches is found again in a cache)
+template <bool NT>
+__device__ __forceinline__ void attn_fetch_t(AttnTileRegs& t, const float* __restrict__ src, int ld, int r0, int rows) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = threadIdx.x + 256 * p, j = i >> 4, d4 = i & 15;
+        const float* sp = src + (size_t)min(r0 + j, rows - 1) * ld + d4 * 4;
+        t.v[p] = f4_keep_if(r0 + j < rows, NT ? ldg4_nt(sp) : ldg4(sp));
+    }
+}
 __device__ __forceinline__ void attn_put(float* dst, const AttnTileRegs& t) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -246,11 +257,13 @@ __device__ __forceinline__ float quarter_sum(float v) {
 // where the row itself is padding.  (The per-score form of this -- `a.mask ? byte : !(qv && kv)` inside the loops -- compiled to a scalar branch
 // sequence per score, 34 of them per tile and wave whether a mask was there or not: a fifth of the kernel's time.)
 template <bool HAS_MASK>
-__global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
+__global__ __launch_bounds__(256, HAS_MASK ? 2 : 3) void k_attn_fwd(AttnArgs a) {      // (the byte-mask form keeps 64-bit mask addresses: two workgroups per CU, no scratch)
     __shared__ __attribute__((aligned(16))) float Ks[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Vs[kABk * kALd];
     __shared__ __attribute__((aligned(16))) float Ksel[kABk];      // per key of the tile: the score's factor ...
     __shared__ __attribute__((aligned(16))) float Kbias[kABk];     // ... and what is added (see above)
+    // (an XCD-aware order of the workgroups -- the query tiles of one (sequence, head), which stream the same K / V, on one L2 -- changed nothing:
+    //  6.89-6.92 ms either way, gpurun_out/r05h_attn_xcd.txt)
     const int n = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * kABq2;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, qd = lane >> 4;
     const int qw = q0 + 32 * w;                           // first row of this wave
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
         const float* qp = a.q + ((size_t)n * a.Lq + min(row[b], a.Lq - 1)) * a.ldq + h * kADh + 4 * qd;
 #pragma unroll
         for (int u = 0; u < 4; ++u) qf[b][u] = row[b] < a.Lq ? ldg4(qp + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool qv = row[b] < a.Lq && (a.qvalid ? a.qvalid[(size_t)n * a.Lq + row[b]] != 0 : true);
+        const bool qv = row[b] < a.Lq && (!HAS_MASK && a.qvalid ? a.qvalid[(size_t)n * a.Lq + row[b]] != 0 : true);      // (a byte mask takes precedence)
         qsel[b] = qv ? 1.f : 0.f;
         qbias[b] = qv ? 0.f : kMaskFill;
     }
@@ -396,12 +409,16 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
         }
     }
     if (!live_w) return;
+    // (the output addresses are formed HERE from a fresh read of the thread index, which the optimiser cannot see through (CF_TID_OPAQUE): formed
+    //  from r / qd it computes them in front of the loop and keeps them, or r / qd themselves, in scratch across it)
+    const int le = threadIdx.x & 63, re = le & 15, qe = le >> 4, qwe = q0 + 32 * (int)(threadIdx.x >> 6);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const float lt = quarter_sum(l[b]);
-        if (row[b] >= a.Lq) continue;
+        const int rowe = qwe + 16 * b + re;
+        if (rowe >= a.Lq) continue;
         const float inv = 1.0f / lt;
-        float* op = a.o + ((size_t)n * a.Lq + row[b]) * a.ldo + h * kADh + 4 * qd;
+        float* op = a.o + ((size_t)n * a.Lq + rowe) * a.ldo + h * kADh + 4 * qe;
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
             const float4 v = make_float4(o[b][tp][0] * inv, o[b][tp][1] * inv, o[b][tp][2] * inv, o[b][tp][3] * inv);
@@ -414,8 +431,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_fwd(AttnArgs a) {
                 op[16 * tp + 3] = v.w;
             }
         }
-        if (a.stats && qd == 0) {
-            float* sp = a.stats + (((size_t)n * a.H + h) * a.Lq + row[b]) * 2;
+        if (a.stats && qe == 0) {
+            float* sp = a.stats + (((size_t)n * a.H + h) * a.Lq + rowe) * 2;
             sp[0] = m[b];
             sp[1] = inv;
         }
@@ -639,6 +656,9 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd_q(AttnArgs a) {
 // arithmetic kept alive across the loops (cf_kernels.h, CF_TID_OPAQUE) and 64-bit per-lane base addresses (now scalar base + 32-bit lane
 // offset).  Stress configuration: backward 24.2 (split kernels) -> 21.0 (one pass) -> 19.4 (statistics in LDS) -> 18.2 ms (three per CU):
 // 73.5 -> 98 TFLOP/s of algorithmic work.
+#ifndef CF_ATTN_NT
+#define CF_ATTN_NT 1      // 1: the Q / dO tile fetches (17.6 against 18.1 ms), 2: dQ's old values, 4: dQ's stores (no change: off)
+#endif
 __global__ __launch_bounds__(256, 3) void k_attn_bwd(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[kABq * kALd];
     __shared__ __attribute__((aligned(16))) float Gs[kABq * kALd];      // dO tile
@@ -701,8 +721,8 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd(AttnArgs a) {
         zero_acc(dv);
         {   // first query tile of this key tile (the barrier that ended the previous key tile's last pair has freed Qs / Gs)
             AttnTileRegs qr, gr;
-            attn_fetch(qr, qbase, a.ldq, 0, a.Lq);
-            attn_fetch(gr, gbase, a.ldo, 0, a.Lq);
+            attn_fetch_t<CF_ATTN_NT & 1>(qr, qbase, a.ldq, 0, a.Lq);
+            attn_fetch_t<CF_ATTN_NT & 1>(gr, gbase, a.ldo, 0, a.Lq);
             const float4 sv = stat_fetch(0);
             attn_put(Qs, qr);
             attn_put(Gs, gr);
@@ -744,7 +764,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd(AttnArgs a) {
             float4 dqo[4];
             if (k0 > 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dqo[t] = ldg4(dqb + (size_t)min(q0 + 16 * t + r, a.Lq - 1) * a.ldq);
+                for (int t = 0; t < 4; ++t) dqo[t] = (CF_ATTN_NT & 2) ? ldg4_nt(dqb + (size_t)min(q0 + 16 * t + r, a.Lq - 1) * a.ldq) : ldg4(dqb + (size_t)min(q0 + 16 * t + r, a.Lq - 1) * a.ldq);
             }
             __builtin_amdgcn_wave_barrier();
             attn_mma_nn(&Pt[w][0], Qs, dk);                   // dK += dS^T . Q
@@ -769,12 +789,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd(AttnArgs a) {
                 if (row < a.Lq) {
                     float4 v = make_float4(dq[t][0], dq[t][1], dq[t][2], dq[t][3]);
                     if (k0 > 0) v = make_float4(v.x + dqo[t].x, v.y + dqo[t].y, v.z + dqo[t].z, v.w + dqo[t].w);
-                    stg4(dqb + (size_t)row * a.ldq, v);
+                    if (CF_ATTN_NT & 4) stg4_nt(dqb + (size_t)row * a.ldq, v); else stg4(dqb + (size_t)row * a.ldq, v);
                 }
             }
             if (more) {      // (a register prefetch of the next tile under the dQ^T product lost in rounds 4 and 5: 19.1 against 18.2 ms)
-                attn_fetch(qr, qbase, a.ldq, q0 + kABq, a.Lq);
-                attn_fetch(gr, gbase, a.ldo, q0 + kABq, a.Lq);
+                attn_fetch_t<CF_ATTN_NT & 1>(qr, qbase, a.ldq, q0 + kABq, a.Lq);
+                attn_fetch_t<CF_ATTN_NT & 1>(gr, gbase, a.ldo, q0 + kABq, a.Lq);
                 attn_put(Qs, qr);
                 attn_put(Gs, gr);
                 if (threadIdx.x < kABq) *reinterpret_cast<float4*>(Ss + threadIdx.x * 4) = svn;

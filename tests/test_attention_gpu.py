@@ -115,3 +115,34 @@ def test_bit_reproducible():
     b = _run(q, k, v, 2, None, None, None, d_o)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("N,H,Lq,Lk,masked", [(3, 2, 800, 800, False), (2, 1, 37, 150, False), (4, 2, 130, 65, False), (2, 2, 96, 200, True)])
+def test_transposed_forward_equals_the_round_1_kernel(N, H, Lq, Lk, masked, monkeypatch):
+    """k_attn_fwd (round 5: transposed score tiles, P in registers, the mask as one fused multiply-add per score, 128 query rows per workgroup,
+    key blocks beyond the tensor skipped) against k_attn_fwd_v1 (CF_ATTN_FWD_V1=1: 64 rows per workgroup, P through LDS, per-score mask test):
+    same outputs and the same row statistics (maximum bit for bit; 1 / sum to fp32 rounding -- the sums add the same terms in another order) --
+    padded keys, padded and fully masked query rows, lengths that are no multiple of any tile, with and without a byte mask."""
+    from chromoformer_amd import _lib
+    gen = torch.Generator().manual_seed(Lq * 7 + Lk)
+    q, k, v = (torch.randn(N, L, H * 64, generator=gen).cuda() for L in (Lq, Lk, Lk))
+    qv, kv = _valid(N, Lq, gen).cuda(), _valid(N, Lk, gen, full_rows=(N - 1,)).cuda()
+    mask = (torch.rand(N, Lq, Lk, generator=gen) < 0.4).to(torch.uint8)
+    mask[0, 3] = 1
+    mask = mask.cuda() if masked else None
+    out = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("CF_ATTN_FWD_V1", form)
+        L = _lib.lib()
+        sh = _lib.cf_attn_shape(N, H, Lq, Lk, q.stride(1), k.stride(1), v.stride(1), H * 64)
+        o = torch.full((N, Lq, H * 64), float("nan"), device=q.device)
+        stats = torch.full((N, H, Lq, 2), float("nan"), device=q.device)
+        _lib.check(L.cf_op_attention_fwd(C.byref(sh), _ptr(q), _ptr(k), _ptr(v), _ptr(qv), _ptr(kv), _ptr(mask), _ptr(o), _ptr(stats),
+                                         torch.cuda.current_stream().cuda_stream), "cf_op_attention_fwd")
+        torch.cuda.synchronize()
+        out[form] = (o, stats)
+    (o0, s0), (o1, s1) = out["0"], out["1"]
+    assert torch.isfinite(o0).all() and torch.isfinite(s0).all()
+    assert (o0 - o1).abs().max() < 2e-6
+    assert torch.equal(s0[..., 0], s1[..., 0])
+    assert ((s0[..., 1] - s1[..., 1]).abs() <= 2e-6 * s1[..., 1].abs()).all()

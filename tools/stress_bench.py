@@ -2,8 +2,9 @@
 sequences, all L x L rows, forward + backward, timed with HIP (torch) events on the launch stream.
     python tools/stress_bench.py [--n-seq 2176] [--reps 5]
 i_max = 16, bsz = 128 -> N = 128 * (1 + 16) = 2176 sequences, h = 2, dh = 64, L = 800.
-Algorithmic flops: forward 4 N H L^2 dh (QK^T and PV), backward 10 N H L^2 dh (dV, dP, dS.K, dS^T.Q + the recomputed
-QK^T is NOT counted: it is re-execution, not algorithmic work).  Also timed: whole dense layers, forward
+Flops, the usual accounting of attention kernels: forward 4 N H L^2 dh (QK^T and PV), backward 10 N H L^2 dh = 2.5 x forward (dV, dP, dQ, dK and
+the QK^T that a backward without a stored P has to execute again).  `frac` uses these 14; `frac_no_recompute` counts the backward without that
+re-execution (8 N H L^2 dh: SURVEY.md section 8d's "training = 3 x forward").  Also timed: whole dense layers, forward
 (cf_op_dense_layer_fwd: projections, attention, out-projection, LN, FFN, LN over all rows)."""
 import argparse, ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -98,6 +99,6 @@ print(json.dumps({"workload": "dense attention core, N=%d sequences x %d heads, 
                   "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3),
                   "fwd_tflops": round(ff / tf / 1e9, 2), "bwd_tflops": round(fb / tb / 1e9, 2),
                   "fwd_bwd_tflops": round((ff + fb) / (tf + tb) / 1e9, 2), "peak_tflops_f32_mfma": 157.3,
-                  "frac": round((ff + fb) / (tf + tb) / 1e9 / 157.3, 4),
+                  "frac": round((ff + fb) / (tf + tb) / 1e9 / 157.3, 4), "frac_no_recompute": round((ff + 0.8 * fb) / (tf + tb) / 1e9 / 157.3, 4),
                   "embedding_layer_fwd (N=%d, d_ff 128)" % max(1, N // 17): layer_bench(max(1, N // 17), 128),
                   "pairwise_layer_fwd (N=%d, d_ff 256)" % (N - max(1, N // 17)): layer_bench(N - max(1, N // 17), 256)}))
