@@ -79,7 +79,7 @@ def test_an_edited_config_trains(tmp_path, d_emb):
                        "--binsizes", "2000", "500", "100"]) == 0
     c = torch.load(out, map_location="cpu", weights_only=False)
     net = c["net"]
-    assert net["regulation.2000.transformer.layers.0.self_att.att.weight"].shape == (512, 128)
+    assert net["regulation.2000.transformer.layers.0.self_att.att.weight"].shape == (512, d_emb)      # (4 chunks x d_model 128 rows; the input is d_emb wide)
     assert net["regulation.2000.transformer.layers.0.self_att.gamma_f"].shape == (4,)
     assert net["embed.100.transformer.layers.0.self_att.gamma_f"].shape == (4 if d_emb == 128 else 2,)
     assert net["embed.100.transformer.layers.0.self_att.att.weight"].shape[1] == d_emb and net["embed.100.lin_proj.weight"].shape[0] == d_emb
