@@ -67,3 +67,25 @@ def test_unfinished_and_failed_jobs_are_run_again(tmp_path):
     started.clear()
     done = sweep.run(jobs, args, launch=launch)                               # only the failed job runs again
     assert [p.cmd[p.cmd.index("-o") + 1] for p in started] == [jobs[1][2]]
+
+
+def test_two_jobs_per_gpu(tmp_path):
+    """`--jobs-per-gpu 2`: two replicas share a device at a time (measured +25 % sweep throughput on one MI355X); every GPU gets its first job
+    before any gets a second one, and never more than two run on one device."""
+    jobs = sweep.plan(["E003", "E004"], ["1", "2", "3", "4"], "exp", "1", str(tmp_path / "ckpts"))
+    args = argparse.Namespace(config="c.yaml", exp_id="exp", meta_template="d/{eid}/train.csv", npy_dir_template="d/{eid}/npy",
+                              binsizes=None, regression=False, gpus=2, jobs_per_gpu=2, poll=0.0)
+    started, peak = [], {}
+
+    def launch(cmd, env, stdout, stderr):
+        p = _Proc(cmd, env, stdout)
+        started.append(p)
+        live = [q for q in started if q.polls < 2]
+        for g in ("0", "1"):
+            peak[g] = max(peak.get(g, 0), sum(q.env["HIP_VISIBLE_DEVICES"] == g for q in live))
+        return p
+
+    done = sweep.run(jobs, args, launch=launch)
+    assert len(done) == 8 and set(done.values()) == {0}
+    assert [p.env["HIP_VISIBLE_DEVICES"] for p in started[:4]] == ["0", "1", "0", "1"]
+    assert peak == {"0": 2, "1": 2}

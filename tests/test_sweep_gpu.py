@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("regression", [False, True], ids=["classifier", "regressor"])
-def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path, regression):
-    """(regressor: BASELINE.json configs[4], `--regression` through the sweep -- Chromoformer-reg per cell line and fold)"""
+@pytest.mark.parametrize("regression,per_gpu", [(False, 1), (True, 1), (False, 2)], ids=["classifier", "regressor", "classifier_two_jobs_at_once"])
+def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path, regression, per_gpu):
+    """(regressor: BASELINE.json configs[4], `--regression` through the sweep -- Chromoformer-reg per cell line and fold;
+    two_jobs_at_once: `--jobs-per-gpu 2`, both trainings share the device while they run -- each still equals its direct run bit for bit)"""
     from chromoformer_amd import sweep, train
     extra = ["--regression"] if regression else []
     cfg = yaml.safe_load(open(os.path.join(ROOT, "chromoformer_amd", "configs", "default.yaml")))
@@ -31,7 +32,7 @@ def test_sweep_runs_jobs_and_names_checkpoints_like_the_snakefile(tmp_path, regr
     out_dir = str(tmp_path / "ckpts")
     argv = ["--meta-template", str(tmp_path / "data" / "{eid}" / "train.csv"), "--npy-dir-template", str(tmp_path / "data" / "{eid}" / "npy"),
             "-c", cfg_path, "--exp-id", "exp", "--conf", "1", "--eids", "E003", "E004", "--folds", "1", "--gpus", "1",
-            "--out-dir", out_dir, "--poll", "0.2"] + extra
+            "--out-dir", out_dir, "--poll", "0.2", "--jobs-per-gpu", str(per_gpu)] + extra
     env_before = os.environ.get("PYTHONPATH")
     os.environ["PYTHONPATH"] = ROOT + (os.pathsep + env_before if env_before else "")
     try:
