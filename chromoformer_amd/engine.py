@@ -194,7 +194,7 @@ class Trainer:
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
                  overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None, rider_tiles=None,
-                 keep_tiled=None, dp_halves=None):
+                 keep_tiled=None, dp_halves=None, dp_early_opt=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -226,6 +226,10 @@ class Trainer:
             import os
             dp_halves = os.environ.get("CF_DP_HALVES", "1") != "0"
         self.halves = bool(dp_halves) and self.dp and not opt_in_graph and int(self._L.cf_reg_halves(model._handle)) > 0
+        if dp_early_opt is None:
+            import os
+            dp_early_opt = os.environ.get("CF_DP_EARLY_OPT", "1") != "0"
+        self.dp_early_opt = bool(dp_early_opt) and self.dp
         self._ev_mid = torch.cuda.Event()
         self._buckets = {}
         for b in (_lib.BUCKET_REG, _lib.BUCKET_PE) + ((_lib.BUCKET_REG_HI, _lib.BUCKET_REG_LO) if self.halves else ()):
@@ -490,6 +494,12 @@ class Trainer:
                 self._launch(slot.graph["first"], st)
             else:
                 self._seq_early(slot, st)
+            # (dp_early_opt: AdamW over the Regulation + head range on the SIDE stream, straight behind that range's last all-reduce -- under the
+            #  Pairwise + Embedding backward -- instead of on the main stream behind everything: its streaming loads and stores (CF_ADAM_NT) no longer
+            #  sweep the L2s the trunk works in, which is what made this lose in round 3)
+            early_opt = self.dp_early_opt and not oig and self.overlap_allreduce
+            hp_next = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step + 1)
+
             def early_allreduce(bucket=_lib.BUCKET_REG, ev=None, last=True):      # an early bucket is complete: all-reduce it on the side stream
                 ev = ev or self._ev_fork
                 ev.record(self.stream)
@@ -499,6 +509,8 @@ class Trainer:
                     if last:
                         if self.overlap_opt:
                             self._opt(_lib.BUCKET_REG, self.side.cuda_stream)
+                        elif early_opt:
+                            _lib.check(L.cf_adamw_step_part(m._handle, *hp_next, _lib.BUCKET_REG, self.side.cuda_stream), "cf_adamw_step_part")
                         self._ev_join.record(self.side)
 
             if self.halves:             # the upper half + head are on the wire while the lower half's backward runs
@@ -528,6 +540,15 @@ class Trainer:
                 self.stream.wait_event(self._ev_join)
                 if not self.overlap_opt:
                     self._opt(_lib.BUCKET_REG, st)
+            elif early_opt:
+                # the Regulation + head range is stepped on the side stream (early_allreduce above): nothing is left for the main stream but the late
+                # bucket, so its all-reduce is issued from HERE -- main -> RCCL's stream -> main instead of main -> side -> RCCL -> side -> main: two
+                # cross-stream event hops less on the tail of every step (the transfers themselves queue behind the early ones on RCCL's stream)
+                torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
+                self.stream.wait_event(self._ev_join)            # early buckets reduced and stepped
+                m._step += 1
+                hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
+                _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_PE, st), "cf_adamw_step_part")
             else:
                 # the late bucket's all-reduce goes to the side stream as well (behind the early one) and the main stream
                 # steps the early bucket meanwhile: only the late bucket's 6 us of AdamW wait for the second all-reduce
@@ -537,10 +558,11 @@ class Trainer:
                     self.side.wait_event(ev_late)
                     torch.distributed.all_reduce(self._buckets[_lib.BUCKET_PE], group=self.pg)
                     ev_done.record(self.side)
-                self.stream.wait_event(self._ev_join)            # early bucket reduced
+                self.stream.wait_event(self._ev_join)            # early bucket reduced (dp_early_opt: and stepped)
                 m._step += 1
                 hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.wd, m._step)
-                _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_REG, st), "cf_adamw_step_part")
+                if not early_opt:
+                    _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_REG, st), "cf_adamw_step_part")
                 self.stream.wait_event(ev_done)                  # late bucket reduced
                 _lib.check(L.cf_adamw_step_part(m._handle, *hp, _lib.BUCKET_PE, st), "cf_adamw_step_part")
         if not oig and not self.dp and not self.merge_opt:

@@ -140,6 +140,9 @@ def test_one_rank_rccl_all_reduce_in_the_step():
         more = [_run(use_graph=g, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=o, dp_halves=False)
                 for g, o in ((True, True), (False, True), (True, False))]
         more.append(_run(use_graph=False, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=True))      # halves, eager
+        # (all of the above step the Regulation + head range on the side stream, straight behind its last all-reduce; the round-4 form, on the main
+        #  stream behind everything: dp_early_opt=False / CF_DP_EARLY_OPT=0)
+        more += [_run(use_graph=g, world_size=1, process_group=dist.group.WORLD, dp_early_opt=False, dp_halves=hv) for g, hv in ((True, True), (False, False))]
     finally:
         dist.destroy_process_group()
     assert loss == ref_loss and loss2 == ref_loss and loss3 == ref_loss and loss4 == ref_loss and loss5 == ref_loss
