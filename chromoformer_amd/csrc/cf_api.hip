@@ -281,6 +281,8 @@ struct cf_handle {
     bool head_ride = true;                     // CF_HEAD_RIDE=0 (read at cf_create): the head stays a launch of its own (k_head_train)
     HeadRide ride;
     int* head_cnt = nullptr;
+    unsigned long long ride_launches = 0;      // launches that added to head_cnt since it was last zero (ride_tick)
+    unsigned long long ride_reset_every = 1ull << 28;
     float* deferred_logits_user = nullptr;
     // riders of the next k_trunk_bwd launch (cf_rider_arm): leading Regulation weight-gradient tiles with AdamW in their epilogues
     struct Rider {
@@ -485,7 +487,8 @@ static void plan_workspace(cf_handle* h) {
     h->dhin = h->ws_get("dH.in", MB * 3 * kD);
     h->loss = h->ws_get("H.loss", 4);
     h->loss_part = h->ws_get("H.loss_part", MB + 1);      // (per 16-gene tile; per gene in the generic-width head)
-    h->head_cnt = reinterpret_cast<int*>(h->ws_get("H.cnt", MB + 1));      // arrivals per gene + genes done (cf_head_ride.h); zero between launches
+    h->head_cnt = reinterpret_cast<int*>(h->ws_get("H.cnt", MB + 1));      // arrivals per gene (cf_head_ride.h): monotonic, see ride_tick
+    h->ride_reset_every = (unsigned long long)std::max(1, getenv_int("CF_RIDE_RESET_EVERY", 1 << 28));
     h->tdbg = h->ws_get("reg_tdbg", 2 * 16 * 64);      // shader-clock stamps (uint64) of the fused Regulation kernels
 }
 
@@ -1704,10 +1707,23 @@ extern "C" int cf_head_rides(cf_handle* h) {
 // Regulation forward launch, by the last of a gene's three workgroups to finish (cf_head_ride.h), and the cf_backward_part /
 // cf_backward call that follows skips the head (its labels / loss arguments are ignored then).  Elsewhere it is cf_forward(save = 2).
 // logits: caller's [B, n_out] buffer (may be null); loss_out: one float (may be null); loss_scale as in cf_backward.
+// The head ride's per-gene arrival counters are monotonic (cf_head_ride.h): every launch adds n_res to each, and 2^32 is no multiple of 3 -- after
+// 1.4e9 launches (eight days of uninterrupted steps) the winner test would drift.  Every 2^28 launches the counters are put back to zero by a
+// stream-ordered memset IN FRONT of a launch: between two launches of a stream every counter is a multiple of n_res and nobody is arriving (zeroing
+// from inside the launch, round 4, raced with the arrivals of a second process on the device).
+static int ride_tick(cf_handle* h, hipStream_t st) {
+    if (h->capturing) return 0;      // (a captured launch is counted when its graph is replayed: cf_graph_launch)
+    if (++h->ride_launches >= h->ride_reset_every) {      // (CF_RIDE_RESET_EVERY at cf_create: the tests run with a handful)
+        HIP_TRY(hipMemsetAsync(h->head_cnt, 0, (size_t)(h->cfg.max_batch + 1) * sizeof(int), st));
+        h->ride_launches = 0;
+    }
+    return 0;
+}
 extern "C" int cf_forward_train(cf_handle* h, const cf_batch* bt, float* logits, const void* labels, float loss_scale, float* loss_out,
                                 void* stream) {
     if (!h) return fail("null handle");
     if (!labels || !cf_head_rides(h)) return forward_impl(h, bt, logits, 2, stream, nullptr);
+    if (ride_tick(h, (hipStream_t)stream)) return -1;
     if (!h->grads) return fail("cf_forward_train: no gradient buffer bound");
     const cf_config& c = h->cfg;
     HeadRide hd;
@@ -2251,6 +2267,7 @@ extern "C" int cf_graph_launch(cf_handle* h, int graph_id, void* stream) {
     }
     if (rp.starts_bwd) h->n_bwd = h->n_opt = 0;
     h->n_bwd += rp.n_bwd;
+    if (rp.n_fwd >= 0 && h->head_cnt && ride_tick(h, st)) return -1;      // (a replayed forward pass may hold a head ride: counted as one)
     HIP_TRY(hipGraphLaunch(rp.first, st));
     if (rp.has_hole) {
         void* kargs[] = {&rp.hole.args};

@@ -34,7 +34,8 @@ struct HeadRide {
 // runs the gene's head -- nobody ever writes a counter but the arrivals themselves.  (Round 4 had workgroup 0 zero them at the start of the
 // launch, "100 us before anybody arrives", and this round first let the last arriver rewind its counter: with two processes on one device --
 // the two-rank tests -- a gene's head was skipped about once in ten runs, stale logits and all; with CF_HEAD_RIDE=0 never.  Zeroed at cf_create;
-// 2^32 is not a multiple of 3, so a counter is good for 1.4e9 launches.)
+// 2^32 is not a multiple of 3, so a counter would drift after 1.4e9 launches: every 2^28 launches the host puts them back to zero with a
+// stream-ordered memset in FRONT of a launch (cf_api.hip, ride_tick), where every counter is a multiple of n_res and nobody is arriving.)
 __device__ __forceinline__ void head_ride_begin(const HeadRide&, const int) {}
 // The Regulation BACKWARD launch, one wave of workgroup 0: the mean loss of the batch, summed in gene order (the genes' losses were
 // written by whichever workgroup ran each gene's head; a launch boundary lies in between).  The first 64 values are requested at the

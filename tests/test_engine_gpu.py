@@ -270,3 +270,16 @@ def test_two_trainers_with_different_tiling_modes_on_one_model():
     assert l0 == l1
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+
+
+def test_head_ride_counters_are_put_back_to_zero_between_launches(monkeypatch):
+    """The head ride's arrival counters are monotonic (no in-kernel zeroing: it raced with a second process on the device) and would drift after 1.4e9
+    launches; every 2^28 launches a stream-ordered memset in front of a launch puts them back.  With CF_RIDE_RESET_EVERY=2 that happens every other step,
+    replayed and eager: same parameters, moments and losses, bit for bit, as without."""
+    ref, ref_loss = _run(steps=6, use_graph=True)
+    monkeypatch.setenv("CF_RIDE_RESET_EVERY", "2")
+    for g in (True, False):
+        got, loss = _run(steps=6, use_graph=g)
+        assert loss == ref_loss
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (g, k)
