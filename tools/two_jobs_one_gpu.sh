@@ -1,10 +1,16 @@
+#!/bin/bash
+# Aggregate training throughput of J independent jobs sharing ONE GPU (the sweep's --jobs-per-gpu): J bench.py processes at once.
+#   tools/two_jobs_one_gpu.sh [J ...]      (default: 1 2 3)
 cd $GRAFT_REPO_ROOT
 B="bench.py --steps 3000 --warmup 50 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --no-val-auroc"
-echo "one job:"; python3 $B 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
-echo "two jobs at once:"
-python3 $B > /tmp/j1.txt 2>/dev/null &
-P1=$!
-python3 $B > /tmp/j2.txt 2>/dev/null &
-P2=$!
-wait $P1 $P2
-for f in /tmp/j1.txt /tmp/j2.txt; do tail -1 $f | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
+for J in ${@:-1 2 3}; do
+  pids=""
+  for j in $(seq $J); do python3 $B > /tmp/j$j.txt 2>/dev/null & pids="$pids $!"; done
+  wait $pids
+  python3 - $J <<'PY'
+import json, sys
+J = int(sys.argv[1])
+v = [json.loads(open("/tmp/j%d.txt" % j).read().strip().split("\n")[-1]) for j in range(1, J + 1)]
+print("%d job(s) at once: %s genes/s each, %.1f k genes/s together, %s ms per step" % (J, " + ".join("%.1f k" % (x["value"] / 1e3) for x in v), sum(x["value"] for x in v) / 1e3, " / ".join("%.4f" % x["ms_per_step"] for x in v)))
+PY
+done
