@@ -313,7 +313,9 @@ def main(argv=None):
                   binsizes=args.binsizes, seed=42, i_max=i_max, w_max=w_max, max_batch=bsz)
     model.cuda(local)
     criterion = nn.MSELoss() if args.regression else nn.CrossEntropyLoss()
-    trainer = Trainer(model, lr=float(config["lr"]), gamma=gamma, world_size=world, process_group=pg)
+    # (single GPU: the step is a replayed graph + two eager launches; data parallel: three graphs with collectives between them replay 4 % SLOWER than the
+    #  same launches issued eagerly -- 0.578 against 0.557 ms on a one-rank RCCL group, profiles/r05j_bench_dp.json --, so the ranks issue eagerly)
+    trainer = Trainer(model, lr=float(config["lr"]), gamma=gamma, world_size=world, process_group=pg, use_graph=(world == 1 and pg is None))
     feed = EpochFeed(model, train_store, bsz)          # batches are gathered from the resident split inside the step graph
     if world > 1:                                      # one line per rank: what it loaded (stderr; stdout stays rank 0's, as in the reference)
         n_steps = (len(train_genes) // world // bsz) if static else (len(train_genes) // (world * bsz))
