@@ -1,3 +1,6 @@
+#!/bin/bash
+# Kernel breakdown (rocprofv3 --kernel-trace --stats) of a training step at d_emb = 256 and 64 (tools/variant_step_time.py): the shapes that run the
+# stand-alone kernels layer by layer.   tools/profile_variants.sh   (run on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 for d in 256 64; do
 rm -rf /tmp/pv; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pv --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/variant_step_time.py $d > /dev/null 2>&1
