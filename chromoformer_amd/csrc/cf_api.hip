@@ -315,6 +315,7 @@ struct cf_handle {
     long long bucket_split = 0;               // flat offset of the first Regulation parameter (bucket boundary)
     long long bucket_split_hi = 0;            // ... of the first parameter of the upper Regulation layers (CF_BUCKET_REG_HI = [this, n_active))
     int n_wg_hi = 0, n_cs_hi = 0;             // tiles of CF_BUCKET_REG_HI at the front of the tables
+    int n_wg_short = 0;                       // ... and, at the front of those, the SHORT ones (64 reduction rows: the head's, the last Regulation layer's one-row gradients)
     float *featc[kMaxRes], *ex0[kMaxRes], *edx0[kMaxRes], *edout[kMaxRes];
     CentreBuf E[kMaxRes];
     float *xp0[kMaxRes], *dxp0[kMaxRes], *resid[kMaxRes];
@@ -637,7 +638,7 @@ static int build_tables(cf_handle* h) {
     const int S = c.i_max, T = S + 1, F = c.n_feats;
     // two gradient buckets: `wg` / `cs` take Embedding + Pairwise (ready after the whole backward chain), `wgR` / `csR`
     // the Regulation stacks and the head (ready after k_reg_bwd, i.e. before Pairwise + Embedding backward starts)
-    std::vector<WgTile> wg, wgHi, wgLo;
+    std::vector<WgTile> wg, wgHi, wgLo, wgShort;
     std::vector<CsTile> cs, csHi, csLo;
     std::vector<LpJob> lpj;
     for (int r = 0; r < c.n_res; ++r) {
@@ -695,10 +696,24 @@ static int build_tables(cf_handle* h) {
             const RegBuf& b = h->R[r][l];
             const int dff = c.reg_dff;
             const int RDm = c.reg_dmodel, RW = 4 * RDm;
+            if (l + 1 == c.reg_layers && h->reg_row0 && h->reg8) {
+                // The last layer, reduced to what token 0 of its output needs (cf_reg8.h: b_run_row0 / b_run_kv_rows): every gradient above the attention
+                // -- out-projection, FFN, the query and gate quarters of the input projection -- has ONE live row per gene, the rows of tokens 1 .. T - 1
+                // are zeros the kernel writes.  Their reductions walk that row alone (rows_per_gene = 1 at a stride of T rows: 64 reduction rows
+                // instead of 576, a ninth of the operand bytes); the key and value quarters keep all rows.  Same sums: what is left out are exact zeros.
+                float* ga = h->G_(lp + "self_att.att.weight");
+                push_wg(wgShort, wg1(b.dqkvg, T * RW, h->Rx[r][l], T * kD, 1, ga, kD, RDm, kD));                                                            // q
+                push_wg(wgR, wg1(b.dqkvg + RDm, RW, h->Rx[r][l], kD, T, ga + (size_t)RDm * kD, kD, 2 * RDm, kD));                                           // k | v
+                push_wg(wgShort, wg1(b.dqkvg + 3 * RDm, T * RW, h->Rx[r][l], T * kD, 1, ga + (size_t)3 * RDm * kD, kD, RDm, kD));                            // gate
+                push_wg(wgShort, wg1(b.dt1, T * kD, b.a, T * RDm, 1, h->G_(lp + "self_att.ff.weight"), RDm, kD, RDm));
+                push_wg(wgShort, wg1(b.dpre1, T * dff, b.y1, T * kD, 1, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
+                push_wg(wgShort, wg1(b.dt2, T * kD, b.hdn, T * dff, 1, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
+            } else {
             push_wg(wgR, wg1(b.dqkvg, RW, h->Rx[r][l], kD, T, h->G_(lp + "self_att.att.weight"), kD, RW, kD));
             push_wg(wgR, wg1(b.dt1, kD, b.a, RDm, T, h->G_(lp + "self_att.ff.weight"), RDm, kD, RDm));
             push_wg(wgR, wg1(b.dpre1, dff, b.y1, kD, T, h->G_(lp + "ff.l1.weight"), kD, dff, kD));
             push_wg(wgR, wg1(b.dt2, kD, b.hdn, dff, T, h->G_(lp + "ff.l2.weight"), dff, kD, dff));
+            }
             if (h->reg8) {            // column sums straight from the row-level arrays the backward kernel writes anyway
                 const std::string ap = lp + "self_att.", fp = lp + "ff.";
                 push_cs(csR, h->dRx[r][l + 1], kD, kD, T, 1, h->G_(fp + "ln.weight"), b.xh2);
@@ -714,8 +729,12 @@ static int build_tables(cf_handle* h) {
             push_cs(csR, b.dgam, c.reg_heads, c.reg_heads, 1, 1, h->G_(lp + "self_att.gamma_f"));
         }
     }
-    push_wg(wgHi, wg1(h->dh1, c.d_head, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, c.d_head, 3 * kD));
-    push_wg(wgHi, wg1(h->dlogits, c.n_out, h->h1, c.d_head, 1, h->G_("fc_head.2.weight"), c.d_head, c.n_out, c.d_head));
+    push_wg(wgShort, wg1(h->dh1, c.d_head, h->hin, 3 * kD, 1, h->G_("fc_head.0.weight"), 3 * kD, c.d_head, 3 * kD));
+    push_wg(wgShort, wg1(h->dlogits, c.n_out, h->h1, c.d_head, 1, h->G_("fc_head.2.weight"), c.d_head, c.n_out, c.d_head));
+    // the short tiles -- one reduction row per gene -- lead the upper bucket: the riders of k_trunk_bwd take the window BEHIND them (a rider is a
+    // single wave: a long tile each keeps the rider waves equally busy), the reduction launch what lies on either side of that window
+    h->n_wg_short = (int)wgShort.size();
+    wgHi.insert(wgHi.begin(), wgShort.begin(), wgShort.end());
     push_cs(csHi, h->dh1, c.d_head, c.d_head, 1, 1, h->G_("fc_head.0.bias"));
     push_cs(csHi, h->dlogits, c.n_out, c.n_out, 1, 1, h->G_("fc_head.2.bias"));
 
@@ -1922,8 +1941,8 @@ static int backward_impl(cf_handle* h, const cf_batch* bt, hipStream_t st, int p
         const bool riding = h->rider.armed;
         if (riding) {      // (cf_rider_arm) one tile per rider wave at a time: any leading part of the bucket's table
             if (h->capturing) return fail("cf_backward_part: armed riders carry this step's AdamW scalars as launch arguments and cannot be captured");
-            ta.rd_n = std::min(h->rider.max_tiles, h->n_wg_r);
-            ta.rd_tiles = h->wg_tiles;
+            ta.rd_n = std::min(h->rider.max_tiles, h->n_wg_r - h->n_wg_short);
+            ta.rd_tiles = h->wg_tiles + h->n_wg_short;
             ta.rd_opt = h->rider.o;
         }
         void* kargs[] = {&ta};
@@ -2451,9 +2470,10 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
     const bool reg = (bucket & CF_BUCKET_REG) != 0, pe = (bucket & CF_BUCKET_PE) != 0;
     int w0 = reg ? 0 : h->n_wg_r, wn = (reg ? h->n_wg_r : 0) + (pe ? h->n_wg - h->n_wg_r : 0);
     const int c0 = reg ? 0 : h->n_cs_r, cn = (reg ? h->n_cs_r : 0) + (pe ? h->n_cs - h->n_cs_r : 0);
-    if (h->rider.done) {       // tiles the riders of the last k_trunk_bwd launch have reduced and stepped already
+    int2 skip = make_int2(0x7fffffff, 0);
+    if (h->rider.done) {       // tiles the riders of the last k_trunk_bwd launch have reduced and stepped already: the window behind the short tiles
         if (!reg || h->rider.step != step) return fail("cf_reduce_opt_part: riders were armed for step %lld of the Regulation + head bucket; this call must finish that step", h->rider.step);
-        w0 += h->rider.done;
+        skip = make_int2(h->n_wg_short, h->rider.done);
         wn -= h->rider.done;
         h->rider.done = 0;
     }
@@ -2463,12 +2483,12 @@ extern "C" int cf_reduce_opt_part(cf_handle* h, int B, int bucket, float lr, flo
                h->keep_tiled && pe ? h->tiled : nullptr};
     if (h->pend_gnext) {      // the next step's batch gather behind the tiles of this launch (cf_gather_batch_next)
         hipLaunchKernelGGL(k_reduce_opt_gather, dim3(xcd_grid(wn) + cn + h->pend_gn.B * h->pend_gn_n), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn,
-                           (const CsTile*)h->cs_tiles + c0, cn, B, h->xcd_reduce_opt, o, h->pend_gn);
+                           (const CsTile*)h->cs_tiles + c0, cn, B, h->xcd_reduce_opt, o, h->pend_gn, skip);
         h->adv_next = h->pend_gn.cursor;
         h->pend_gnext = false;
     } else {
         hipLaunchKernelGGL(k_reduce_opt, dim3(xcd_grid(wn) + cn), dim3(256), 0, st, (const WgTile*)h->wg_tiles + w0, wn, (const CsTile*)h->cs_tiles + c0, B,
-                           h->xcd_reduce_opt, o);
+                           h->xcd_reduce_opt, o, skip);
     }
     LAUNCH_CHECK("k_reduce_opt");
     if (pe) h->tiled_pe_fresh = h->keep_tiled;      // (every tensor of that bucket with a tiled copy has just been rewritten in both forms -- or in one only)

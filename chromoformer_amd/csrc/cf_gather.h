@@ -68,11 +68,11 @@ __global__ void k_gather_advance(int* cursor) {
 // ... and behind its tiles the gather of the NEXT step's batch (cf_gather_batch_next): nothing in this launch reads the batch buffers, the
 // 4 KB copy blocks fill the CUs the last tiles leave idle, and the next step starts without a launch in front of it
 __global__ __launch_bounds__(256) void k_reduce_opt_gather(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int n_cs, int batch, int xcd,
-                                                           AdamFuse o, GatherArgs ga) {
+                                                           AdamFuse o, GatherArgs ga, int2 skip) {
     const int nb = xcd_grid(n_wg);
     if ((int)blockIdx.x < nb) {
         const int t = xcd_tile(blockIdx.x, n_wg, xcd);
-        if (t < n_wg) wgrad_tile<true>(wg[t], batch, &o);
+        if (t < n_wg) wgrad_tile<true>(wg[t >= skip.x ? t + skip.y : t], batch, &o);
     } else if ((int)blockIdx.x < nb + n_cs) {
         colsum_tile<true>(cs[blockIdx.x - nb], batch, &o);
     } else {

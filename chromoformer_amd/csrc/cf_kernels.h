@@ -2301,11 +2301,13 @@ __global__ __launch_bounds__(256) void k_reduce(const WgTile* __restrict__ wg, i
 }
 
 // The reductions of a bucket with the AdamW update of the same bucket in their epilogues (AdamFuse above)
-__global__ __launch_bounds__(256) void k_reduce_opt(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int batch, int xcd, AdamFuse o) {
+// (skip: the window of the table the riders of k_trunk_bwd have reduced and stepped already -- tile t of this launch is table entry t, or
+//  t + skip.y from entry skip.x on)
+__global__ __launch_bounds__(256) void k_reduce_opt(const WgTile* __restrict__ wg, int n_wg, const CsTile* __restrict__ cs, int batch, int xcd, AdamFuse o, int2 skip) {
     const int nb = xcd_grid(n_wg);
     if ((int)blockIdx.x < nb) {
         const int t = xcd_tile(blockIdx.x, n_wg, xcd);
-        if (t < n_wg) wgrad_tile<true>(wg[t], batch, &o);
+        if (t < n_wg) wgrad_tile<true>(wg[t >= skip.x ? t + skip.y : t], batch, &o);
     } else {
         colsum_tile<true>(cs[blockIdx.x - nb], batch, &o);
     }
