@@ -394,7 +394,7 @@ def main():
             # attention reads its 7-mark features once (the only HBM stream, 7-10.6 % of HBM bandwidth while it runs) and is bound by the matrix pipe of
             # its CU and by a chain of dependent phases (DESIGN.md sections 2, 4, 9); the bound of every kernel reported here is the f32 MFMA peak
             "attention_hbm_note": "centre-row attention is MFMA / latency-bound, not HBM-bound: 7-10.6 % of HBM bandwidth measured on the current kernels run as "
-                                  "launches of their own (CF_TRUNK=0; tools/attc_bandwidth.sh -> profiles/r05b_attc_bandwidth.csv: PMC bytes / duration per launch); "
+                                  "launches of their own (CF_TRUNK=0; tools/attc_bandwidth.sh -> profiles/r05k_attc_bandwidth.csv: PMC bytes / duration per launch); "
                                   "the HBM-bound kernel of the path is the binning of raw signals (profiles/*_binning.json: 70 % of 8 TB/s)",
             "loss": round(float(trainer.last_loss()), 6),
         }
