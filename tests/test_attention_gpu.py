@@ -146,3 +146,43 @@ def test_transposed_forward_equals_the_round_1_kernel(N, H, Lq, Lk, masked, monk
     assert (o0 - o1).abs().max() < 2e-6
     assert torch.equal(s0[..., 0], s1[..., 0])
     assert ((s0[..., 1] - s1[..., 1]).abs() <= 2e-6 * s1[..., 1].abs()).all()
+
+
+def test_stress_length_properties_of_the_forward():
+    """Size-independent properties at the stress configuration's length (L = 800: 6.25 workgroups of 128 query rows, 12.5 key tiles -- the ragged
+    ends of both tilings), where the oracle takes too long for more than a handful of sequences: every output row is a convex combination of the
+    value rows -- V = 1 gives 1, a V that is constant per key block of 16 gives a row inside [min, max] --, the output is linear in V, the saved
+    statistics reproduce the probabilities (sum_j exp(s_ij - m_i) * inv_i = 1 for a sampled set of rows), and padded keys carry no weight."""
+    from chromoformer_amd import _lib
+    gen = torch.Generator().manual_seed(800)
+    N, H, L = 6, 2, 800
+    q, k = (torch.randn(N, L, H * 64, generator=gen).cuda() for _ in range(2))
+    v1, v2 = (torch.randn(N, L, H * 64, generator=gen).cuda() for _ in range(2))
+    kv = _valid(N, L, gen).cuda()
+    qv = torch.ones(N, L, dtype=torch.uint8).cuda()
+
+    def fwd(v):
+        sh = _lib.cf_attn_shape(N, H, L, L, q.stride(1), k.stride(1), v.stride(1), H * 64)
+        o = torch.empty(N, L, H * 64, device=q.device)
+        stats = torch.empty(N, H, L, 2, device=q.device)
+        _lib.check(_lib.lib().cf_op_attention_fwd(C.byref(sh), _ptr(q), _ptr(k), _ptr(v), _ptr(qv), _ptr(kv), None, _ptr(o), _ptr(stats),
+                                                  torch.cuda.current_stream().cuda_stream), "cf_op_attention_fwd")
+        return o, stats
+
+    ones, stats = fwd(torch.ones_like(v1))
+    assert (ones - 1).abs().max() < 2e-6
+    o1, o2, o12 = fwd(v1)[0], fwd(v2)[0], fwd(v1 + 2 * v2)[0]
+    assert (o12 - (o1 + 2 * o2)).abs().max() < 2e-5
+    # padded keys carry no weight: values at padded keys do not matter
+    v3 = v1.clone()
+    v3[(kv == 0)[:, :, None].expand_as(v3)] = 1e6
+    assert torch.equal(fwd(v3)[0], o1)
+    # the saved statistics are the softmax's: recompute a few rows on the host
+    for n, h, i in ((0, 0, 0), (1, 1, 799), (3, 0, 417), (5, 1, 128)):
+        s = (q[n, i, h * 64:(h + 1) * 64].double() @ k[n, :, h * 64:(h + 1) * 64].double().T) / 8.0
+        s[kv[n] == 0] = -1e9
+        p = torch.softmax(s, 0)
+        m, inv = stats[n, h, i].double()
+        assert abs(float(m) - float(s.max())) < 1e-4
+        assert abs(float((torch.exp(s - m) * inv).sum()) - 1) < 1e-5
+        assert (p.float() @ v1[n, :, h * 64:(h + 1) * 64] - o1[n, i, h * 64:(h + 1) * 64]).abs().max() < 2e-5
