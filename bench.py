@@ -2,7 +2,7 @@
 all-reduce + AdamW), default config, bsz = 64 genes per GPU, synthetic 7-mark inputs resident
 in HBM (BASELINE.json: configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]      (N > 1: starts its own N ranks through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for how `roofline` is defined).
@@ -69,11 +69,13 @@ def cpu_baseline(step_guard_s=15.0):
             threads, BSZ, warm, b, el, 3 * b / el, " (guard fired: warm-up > %.0f s)" % step_guard_s if fired else "")
 
     cores = usable_cores()
+    logical = os.cpu_count() or 0
+    limited = " -- cgroup-limited: this process may use %d of the host's %d logical CPUs, so `cores` is NOT all physical cores" % (cores, logical) if cores < logical else ""
     rate_all, txt_all = measure(cores)
     rate_8, txt_8 = measure(min(8, cores))
     return {"value": round(rate_all, 3), "unit": "genes/s", "cores": cores, "kind": "port", "value_8_threads": round(rate_8, 3),
-            "sample": "forward + backward + AdamW of the CPU oracle, default config, dense synthetic batch; %s; %s (host: %d logical CPUs, %s)"
-                      % (txt_all, txt_8, os.cpu_count() or 0, cpu)}
+            "sample": "forward + backward + AdamW of the CPU oracle, default config, dense synthetic batch; %s; %s (host: %d logical CPUs, %s)%s"
+                      % (txt_all, txt_8, logical, cpu, limited)}
 
 
 def train_loop_rate(model, lr, steps, store_genes, regime, dev):
@@ -182,14 +184,14 @@ def dp_path_ms(model, batch, steps, warmup, dev):
     return out
 
 
-def stress_main(args, json_out):
+def stress_record(steps, warmup):
     """BASELINE.json configs[3] -- i_max = 16, one 100-bp resolution over 80 kb (800-bin sequences), bsz 128 -- as SURVEY.md
     section 8-d defines it (the reference cannot run it): the roofline run of the DENSE attention core, all L x L rows,
     forward + backward, on the N = 128 * 17 sequences of a batch (cf_op_attention_fwd / _bwd, csrc/cf_attn.h).  A step is
     one forward + backward over the batch; `value` is genes/s of that core alone, `roofline` its algorithmic flops
     (4 N H L^2 dh forward, 10 N H L^2 dh backward -- the usual accounting of attention kernels: dV, dP, dQ, dK and the QK^T that a backward
     without a stored P executes again, once, in the one-pass kernel; `frac_no_recompute` leaves that re-execution out: 12 instead of 14)
-    against the f32 MFMA peak, from HIP events on the launch stream."""
+    against the f32 MFMA peak, from HIP events on the launch stream; the forward and the backward also timed on their own."""
     import ctypes as C
     from chromoformer_amd import _lib
     B, S, H, L = 128, 16, 2, 800
@@ -211,26 +213,37 @@ def stress_main(args, json_out):
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: C.c_void_p(t.data_ptr())
 
-    def step():
+    def fwd():
         _lib.check(lib.cf_op_attention_fwd(C.byref(sh), p(q), p(k), p(v), p(valid), p(valid), None, p(o), p(stats), st), "cf_op_attention_fwd")
+
+    def bwd():
         _lib.check(lib.cf_op_attention_bwd(C.byref(sh), p(q), p(k), p(v), p(valid), p(valid), None, p(o), p(stats), p(d_o), p(dq), p(dk), p(dv),
                                            p(ws), st), "cf_op_attention_bwd")
 
-    steps, warmup = min(args.steps, 20), min(args.warmup, 3)
+    def step():
+        fwd()
+        bwd()
+
+    def timed(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, e0.elapsed_time(e1) / n
+
+    steps, warmup = min(steps, 20), min(warmup, 3)
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1) / steps
+    el, dev_ms = timed(step, steps)
+    _, fwd_ms = timed(fwd, max(3, steps // 2))
+    _, bwd_ms = timed(bwd, max(3, steps // 2))
     flops = 14.0 * N * H * L * L * 64
     ach = flops / (dev_ms * 1e-3) / 1e12
+    io_gb = 8 * N * L * H * 64 * 4 / 1e9                      # Q, K, V, O, dO read + dQ, dK, dV written, once each
     out = {"metric": "genes/sec through the dense attention core, forward + backward (stress config: bsz=128, i_max=16, 800 bins)",
            "value": round(B * steps / el, 1), "unit": "genes/s", "n_gpus": 1,
            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * el / steps, 4), "higher_is_better": True, "scaling": "weak",
@@ -240,9 +253,110 @@ def stress_main(args, json_out):
                       "parallelism": "dp1", "global_batch": B},
            "roofline": {"kernel": "k_attn_fwd + k_attn_delta + k_attn_bwd (dQ, dK, dV in one pass per (sequence, head))", "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3,
                         "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "frac_no_recompute": round(ach * 12.0 / 14.0 / 157.3, 4), "traffic": None, "avg_launch_us": round(dev_ms * 1e3, 1),
+                        "fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3),
+                        "fwd_tflops": round(4.0 * N * H * L * L * 64 / (fwd_ms * 1e-3) / 1e12, 2),
+                        "bwd_tflops_no_recompute": round(8.0 * N * H * L * L * 64 / (bwd_ms * 1e-3) / 1e12, 2),
+                        "compulsory_io_gb_per_step": round(io_gb, 3),
                         "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}}
-    json_out.write(json.dumps(out) + "\n")
+    del proj, dproj, d_o, o, stats, ws, valid, q, k, v, dq, dk, dv
+    torch.cuda.empty_cache()
+    return out
+
+
+def stress_main(args, json_out):
+    json_out.write(json.dumps(stress_record(args.steps, args.warmup)) + "\n")
     json_out.flush()
+
+
+def binning_record(regions=4096, reps=5):
+    """The HBM-bound kernel of the path: cf_bin_regions_multi, raw fp16 [7, 40000] promoter-sized regions
+    -> mean + log1p bins at 2000 / 500 / 100 bp in ONE pass over the raw bytes.  Algorithmic bytes = 2 B per raw sample + (4 * 7 + 1) B per
+    output bin (features + mask byte); spot-checked against a torch expression of data.py:80-83 on the device."""
+    import ctypes as C
+    import numpy as np
+    from chromoformer_amd import _lib
+    from chromoformer_amd.data import BIN_JOB_MULTI
+    dev = torch.device("cuda", 0)
+    R, F, LEN = regions, 7, 40000
+    raw = torch.empty(R, F, LEN, device=dev, dtype=torch.float16)
+    for lo in range(0, R, 512):                       # (in pieces: the fp32 temporary of the whole array would be 4.6 GB)
+        raw[lo:lo + 512] = (torch.rand(min(512, R - lo), F, LEN, device=dev) * 4).half()
+    bsz = (2000, 500, 100)
+    Ls = [LEN // b for b in bsz]
+    feats = [torch.empty(R, L, F, device=dev) for L in Ls]
+    masks = [torch.empty(R, L, dtype=torch.uint8, device=dev) for L in Ls]
+    mj = np.zeros(R, dtype=BIN_JOB_MULTI)
+    mj["raw"] = raw.data_ptr() + np.arange(R, dtype=np.uint64) * (F * LEN * 2)
+    mj["ld"], mj["col0"], mj["ncols"], mj["flip"] = LEN, 0, LEN, np.arange(R) % 2
+    for r, L in enumerate(Ls):
+        mj["out"][:, r] = feats[r].data_ptr() + np.arange(R, dtype=np.uint64) * (L * F * 4)
+        mj["mask"][:, r] = masks[r].data_ptr() + np.arange(R, dtype=np.uint64) * L
+    tab = torch.from_numpy(mj.view(np.uint8)).to(dev)
+    cb, cl = (C.c_int * 3)(*bsz), (C.c_int * 3)(*Ls)
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    run = lambda: _lib.check(lib.cf_bin_regions_multi(C.c_void_p(tab.data_ptr()), R, F, 3, cb, cl, LEN, st), "cf_bin_regions_multi")
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = R * (F * LEN * 2 + sum(L * F * 4 + L for L in Ls))
+    err = 0.0
+    for r, b in enumerate(bsz):
+        ref = torch.log1p(raw[:8].float().reshape(8, F, Ls[r], b).mean(3)).permute(0, 2, 1)
+        ref[1::2] = ref[1::2].flip(1)
+        err = max(err, float((feats[r][:8] - ref).abs().max()))
+    out = {"kernel": "k_bin_multi", "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+           "frac": round(nbytes / ms / 1e6 / 8000, 4), "avg_launch_us": round(ms * 1e3, 1), "algorithmic_mb_per_launch": round(nbytes / 1e6, 1),
+           "workload": "%d regions x fp16 [7, 40000] -> bins of 2000 / 500 / 100 bp, one launch" % R, "max_abs_err_vs_torch": err}
+    del raw, feats, masks, tab
+    torch.cuda.empty_cache()
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed.run environment: start the N ranks as fresh child processes
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay rank 0's ONE JSON line and the
+    children's exit code.  This parent never initialises the GPU (torch.cuda.device_count() only counts devices) and never replaces itself."""
+    import socket
+    import subprocess
+    share = os.environ.get("CF_SHARE_DEVICE") == "1"
+    n_dev = torch.cuda.device_count()
+    if not share and n_dev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- one rank per GPU (set CF_SHARE_DEVICE=1 CF_DIST_BACKEND=gloo "
+                         "only for the one-device test mode)" % (args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    rc, out = 1, ""
+    for attempt in range(3):                     # a fresh port if the rendezvous itself failed
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        rc, out = r.returncode, r.stdout
+        sys.stderr.write(r.stderr[-20000:])
+        if rc == 0 or not any(k in r.stderr for k in ("EADDRINUSE", "address already in use", "RendezvousConnectionError")):
+            break
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    for ln in out.splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: the ranks printed %d JSON lines, expected 1\n" % len(lines))
+        rc = 1
+    for ln in lines:
+        sys.stdout.write(ln + "\n")
+    sys.stdout.flush()
+    raise SystemExit(rc)
 
 
 def main():
@@ -252,10 +366,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the step as hipGraphs in the timed region (split around the event-bracketed roofline kernel: measured "
-                         "+8..12 us per step).  Default: graph replay under data parallelism (--gpus > 1: the host calls of a step halve -- which matters "
-                         "with eight ranks driving one host, a configuration never run; on the one-rank proxy the eager schedule is 2 %% faster, see "
-                         "`dp_path_ms_per_step`), eager launches on one GPU, where the one-graph "
-                         "replay time is reported beside it as `graph_replay_ms_per_step`")
+                         "+8..12 us per step).  Default: eager launches, on one GPU and under data parallelism (what chromoformer_amd.train runs there: "
+                         "replay with collectives between the graphs measured 4 %% slower on the one-rank proxy, `dp_path_ms_per_step`); on one GPU the "
+                         "one-graph replay time is reported beside it as `graph_replay_ms_per_step`; `config.hip_graph` says which was timed")
     ap.add_argument("--eager", "--no-graph", dest="graph", action="store_false", help="issue the launches of a step one by one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--regime", default="dense", choices=["dense", "realistic"])
@@ -275,7 +388,13 @@ def main():
                     help="un-timed device pre-warm in front of the W warm-up steps: the same step issued for this many seconds of wall clock (a fresh box "
                          "runs its first ~100 ms of kernels 5 %% slower: clock / power state); reported as `prewarm_s` / `prewarm_steps`; 0 = none.  "
                          "--steps / --warmup are honoured as given and what is timed does not change")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `stress` and `binning` sub-records of the default line (~3 s)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no torch.distributed.run environment around it: this process starts the N ranks itself,
+    # BEFORE anything touches the GPU (tests/test_dp_gpu.py::test_bench_launches_its_own_ranks)
+    if args.config == "default" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to file descriptor 1 (RCCL prints a
     # version banner there when a communicator is created, libraries print warnings) is sent to stderr
@@ -289,8 +408,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch %d ranks, or run `python bench.py --gpus %d` on its own: it starts them)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     # test hooks (tests/test_dp_gpu.py drives the multi-process path on a one-GPU box): every rank on device 0, gloo
     # instead of RCCL (RCCL refuses two ranks on one device)
     share = os.environ.get("CF_SHARE_DEVICE") == "1"
@@ -323,18 +442,35 @@ def main():
     from chromoformer_amd.synth import synthetic_batch
 
     if args.graph is None:
-        args.graph = world > 1
+        args.graph = False                 # eager launches: what chromoformer_amd.train runs under data parallelism (train.py:318) and what wins on one GPU
     model = ChromoformerClassifier(seed=42, max_batch=BSZ).cuda(local)
     batch = synthetic_batch(BSZ, seed=1234 + rank, regime=args.regime)
     trainer = Trainer(model, lr=3e-5, world_size=world, process_group=pg, use_graph=args.graph,
                       timed_kernel=args.roofline_kernel)
     slot = trainer.stage(batch)            # inputs resident in HBM before the timed region
 
+    # the same W + K steps on the box as it comes (no pre-warm): what this command timed up to round 4 -- reported beside the headline as
+    # `cold_ms_per_step`, never as `value`
+    for _ in range(args.warmup):
+        trainer.step(slot)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    tc0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(slot)
+    torch.cuda.synchronize()
+    cold_ms = 1e3 * (time.perf_counter() - tc0) / max(1, args.steps)
     # device pre-warm (disclosed, un-timed, wall-clock based): the driver's `--steps 20 --warmup 5` is 14 ms of GPU work on a box that has been
     # idle -- its kernels run ~5 % longer than 100 ms later (BENCH_r04: 134.3 against 128.3 us for k_reg8_bwd)
-    # (under data parallelism every rank must issue the SAME number of steps -- each one is two all-reduces --: a fixed count for the nominal step time)
+    # (under data parallelism every rank must issue the SAME number of steps -- each one is a set of all-reduces --: a count derived from rank 0's
+    # measured cold step time, broadcast)
     prewarm_steps, tp0 = 0, time.perf_counter()
-    fixed = int(args.prewarm_s / 0.6e-3) // 10 * 10 if world > 1 else None
+    fixed = None
+    if world > 1:
+        n = torch.tensor([int(args.prewarm_s / max(cold_ms * 1e-3, 1e-5)) // 10 * 10], device=dev, dtype=torch.int64)
+        torch.distributed.broadcast(n, 0)
+        fixed = min(int(n.item()), 5000)
     while args.prewarm_s > 0 and (prewarm_steps < fixed if fixed is not None else time.perf_counter() - tp0 < args.prewarm_s):
         for _ in range(10):
             trainer.step(slot)
@@ -378,15 +514,16 @@ def main():
     if rank == 0:
         ms = 1e3 * el / args.steps
         value = BSZ * world * args.steps / el
-        roof = trainer.roofline(args.roofline_kernel, kernel_ms, kernel_n, BSZ)
+        roof = trainer.roofline(args.roofline_kernel, kernel_ms, kernel_n, BSZ, steps=args.steps)
         out = {
             "metric": "genes/sec training (bsz=64, default config)", "value": round(value, 1), "unit": "genes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_s": round(prewarm_s, 3), "prewarm_steps": prewarm_steps,
-            "ms_per_step": round(ms, 4),
+            "ms_per_step": round(ms, 4), "cold_ms_per_step": round(cold_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "default config (d_emb 128, i_max 8, binsizes 2000/500/100 -> L 20/80/400), bsz 64 genes per GPU, "
                                    "%s synthetic 7-mark signals, fwd+loss+bwd+allreduce+AdamW" % args.regime,
-                       "parallelism": "dp%d" % world, "global_batch": BSZ * world, "hip_graph": bool(args.graph),
+                       "parallelism": "dp%d" % world, "global_batch": BSZ * world, "hip_graph": bool(trainer.use_graph),
+                       "dp_halves": bool(trainer.halves), "dp_early_opt": bool(trainer.dp_early_opt), "dp_overlap_allreduce": bool(trainer.overlap_allreduce),
                        "launches_per_step": sum(model.launch_counts()),      # (of the last step: counted at the launch sites, graph replays included)
                        "adamw": "in the epilogue of the gradient reductions (cf_reduce_opt_part)" if trainer.fuse_opt else "own launches"},
             "roofline": roof,
@@ -417,6 +554,11 @@ def main():
             out["train_loop"] = train_loop_rate(model, 3e-5, args.train_loop_steps, args.train_loop_genes, args.regime, dev)
         if world == 1 and args.val_auroc:
             out["val_auroc"] = val_auroc_run()
+        if world == 1 and not args.no_extras:
+            # BASELINE configs[3] and the HBM-bound kernel of the path in the SAME driver-run line (each about a second of GPU time)
+            sr = stress_record(10, 2)
+            out["stress"] = dict(sr["roofline"], value=sr["value"], unit=sr["unit"], ms_per_step=sr["ms_per_step"], workload=sr["config"]["workload"])
+            out["binning"] = binning_record()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         json_out.write(json.dumps(out) + "\n")

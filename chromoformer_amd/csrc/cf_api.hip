@@ -283,6 +283,8 @@ struct cf_handle {
     int* head_cnt = nullptr;
     unsigned long long ride_launches = 0;      // launches that added to head_cnt since it was last zero (ride_tick)
     unsigned long long ride_reset_every = 1ull << 28;
+    std::vector<hipStream_t> ride_streams;     // every stream a head-ride launch of this handle was issued on (ride_tick orders its reset against all of them)
+    hipEvent_t ride_ev = nullptr;
     float* deferred_logits_user = nullptr;
     // riders of the next k_trunk_bwd launch (cf_rider_arm): leading Regulation weight-gradient tiles with AdamW in their epilogues
     struct Rider {
@@ -997,6 +999,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     }
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->sync_ev) (void)hipEventDestroy(e);
+    if (h->ride_ev) (void)hipEventDestroy(h->ride_ev);
     if (h->hyper) (void)hipFree(h->hyper);
     delete h;
 }
@@ -1730,10 +1733,36 @@ extern "C" int cf_head_rides(cf_handle* h) {
 // 1.4e9 launches (eight days of uninterrupted steps) the winner test would drift.  Every 2^28 launches the counters are put back to zero by a
 // stream-ordered memset IN FRONT of a launch: between two launches of a stream every counter is a multiple of n_res and nobody is arriving (zeroing
 // from inside the launch, round 4, raced with the arrivals of a second process on the device).
+// The launches of a handle may come in on more than one stream (two Trainers on one model, a caller's own stream): the reset waits for what the
+// OTHER streams have queued so far and they wait for the reset, so it can never land under a ride launch in flight elsewhere.
 static int ride_tick(cf_handle* h, hipStream_t st) {
     if (h->capturing) return 0;      // (a captured launch is counted when its graph is replayed: cf_graph_launch)
+    if (std::find(h->ride_streams.begin(), h->ride_streams.end(), st) == h->ride_streams.end()) {
+        if (h->ride_streams.size() >= 16) h->ride_streams.erase(h->ride_streams.begin());
+        h->ride_streams.push_back(st);
+    }
     if (++h->ride_launches >= h->ride_reset_every) {      // (CF_RIDE_RESET_EVERY at cf_create: the tests run with a handful)
+        if (h->ride_streams.size() > 1) {
+            if (!h->ride_ev) HIP_TRY(hipEventCreateWithFlags(&h->ride_ev, hipEventDisableTiming));
+            for (size_t i = 0; i < h->ride_streams.size();) {
+                hipStream_t o = h->ride_streams[i];
+                if (o != st) {
+                    if (hipEventRecord(h->ride_ev, o) != hipSuccess) {      // a stream its owner has destroyed since: nothing of it can be in flight
+                        (void)hipGetLastError();
+                        h->ride_streams.erase(h->ride_streams.begin() + i);
+                        continue;
+                    }
+                    HIP_TRY(hipStreamWaitEvent(st, h->ride_ev, 0));
+                }
+                ++i;
+            }
+        }
         HIP_TRY(hipMemsetAsync(h->head_cnt, 0, (size_t)(h->cfg.max_batch + 1) * sizeof(int), st));
+        if (h->ride_streams.size() > 1) {
+            HIP_TRY(hipEventRecord(h->ride_ev, st));
+            for (hipStream_t o : h->ride_streams)
+                if (o != st) HIP_TRY(hipStreamWaitEvent(o, h->ride_ev, 0));
+        }
         h->ride_launches = 0;
     }
     return 0;

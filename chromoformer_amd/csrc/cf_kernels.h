@@ -40,8 +40,11 @@ struct TidProxy {
             return t;
         }
     } x;
+    struct Y { __device__ __forceinline__ operator unsigned() const { return __builtin_amdgcn_workitem_id_y(); } } y;
+    struct Z { __device__ __forceinline__ operator unsigned() const { return __builtin_amdgcn_workitem_id_z(); } } z;
 };
 }  // namespace cf
+// (scoped to the kernel headers: #undef'd again at the end of this file, behind the last of them)
 #define threadIdx (cf::TidProxy{})
 #endif
 
@@ -2507,7 +2510,7 @@ __global__ __launch_bounds__(256) void k_dense_cs_tables(DenseCsTab a) {
 
 #include "cf_valu_mv.h"
 #include "cf_head_ride.h"
-#include "cf_reg_fused.h"
+#include "cf_reg_args.h"
 #include "cf_reg8.h"
 #include "cf_attc2.h"
 #include "cf_attc1.h"
@@ -2517,3 +2520,6 @@ __global__ __launch_bounds__(256) void k_dense_cs_tables(DenseCsTab a) {
 #include "cf_attn.h"
 #include "cf_bin.h"
 #include "cf_embed_full.h"
+#if CF_TID_OPAQUE
+#undef threadIdx      // the opaque thread index is a property of the kernels above, not of whatever includes this header
+#endif

@@ -1,9 +1,5 @@
-// cf_reg_fused.h -- argument structures of the fused Regulation kernels (cf_reg8.h; included by cf_kernels.h).
-//
-// One workgroup per (gene, resolution) walks ALL layers; the token embeddings stay in LDS from layer to layer, only what the backward
-// needs is written out (modules.py:28-88, 100-101, 121-124; net.py:148-153).  The 256-thread kernels of round 1 that used to live here
-// were retired in round 5: the 512-thread kernels of cf_reg8.h are the fused implementation, the layer-by-layer stand-alone kernels
-// (k_attr + the row-tile chains; CF_REG_FUSED=0) the cross-check.
+// cf_reg_args.h -- argument structures of the fused Regulation kernels (cf_reg8.h; included by cf_kernels.h): the per-layer device table
+// and the launch arguments, nothing else.  The kernels themselves are in cf_reg8.h (modules.py:28-88, 100-101, 121-124; net.py:148-153).
 #pragma once
 
 namespace cf {

@@ -640,25 +640,33 @@ class Trainer:
         self._t_n += n.value
         return self._t_ms, self._t_n
 
-    def roofline(self, kernel, total_ms, launches, B):
-        """Roofline entry of bench.py for the kernel timed with HIP events."""
+    #: rocprofv3 names of the kernels bench.py can time (the `cf_timing_select` keys are the stage names)
+    ROCPROF_NAMES = {"k_reg_bwd": "k_reg8_bwd", "k_reg_fwd": "k_reg8_fwd", "k_wgrad": "k_reduce_opt / k_reduce (weight-gradient tiles)"}
+
+    def roofline(self, kernel, total_ms, launches, B, steps=None):
+        """Roofline entry of bench.py for the kernel timed with HIP events.  `achieved` is normalised PER STEP when a
+        step launches the kernel more than once (data parallel in halves: the Regulation backward is two launches over half the layers
+        each, the weight-gradient reduction one per bucket) -- the flop count of `cf_kernel_flops` is the whole stack's, so it is divided by
+        the time ALL of a step's launches of that kernel took, not by one launch's."""
         if not launches:
             return None
-        avg_s = total_ms / launches * 1e-3
-        if kernel == "k_wgrad":
-            launches = (launches + 1) // 2            # one launch per gradient bucket; the flop count is the step's
-            avg_s = total_ms / launches * 1e-3
+        per_step = max(1, int(round(launches / steps))) if steps else (2 if kernel == "k_wgrad" else 1)
+        avg_s = total_ms / launches * 1e-3 * per_step            # the kernel's time per step
+        name = self.ROCPROF_NAMES.get(kernel, kernel)
         if kernel in ("k_wgrad", "k_reg_fwd", "k_reg_bwd", "k_trunk_fwd", "k_trunk_bwd"):
             flops = self._L.cf_kernel_flops(self.model._handle, kernel.encode(), B)
             ach = flops / avg_s / 1e12
-            return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
+            return {"kernel": name, "timing_key": kernel, "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(ach / 157.3, 4), "traffic": _pmc_traffic(kernel), "traffic_source": _TRAFFIC_SOURCE,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_gflop_per_launch": round(flops / 1e9, 4)}
+                    "avg_launch_us": round(avg_s * 1e6 / per_step, 2), "launches_per_step": per_step, "us_per_step": round(avg_s * 1e6, 2),
+                    "algorithmic_gflop_per_launch": round(flops / 1e9 / per_step, 4), "algorithmic_gflop_per_step": round(flops / 1e9, 4),
+                    "flop_accounting": "executed flops only: ~0.28 GFLOP/gene for a training step (centre query row, K/V projections absorbed into "
+                                       "the query, last Regulation layer reduced to token 0); SURVEY 8-d's F_alg,train = 1.97 GFLOP/gene does not apply"}
         if kernel == "k_adamw":
             nbytes = 7.0 * 4.0 * self.model._layout.n_active
             ach = nbytes / avg_s / 1e9
-            return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 4), "traffic": _pmc_traffic(kernel), "traffic_source": _TRAFFIC_SOURCE,
                     "avg_launch_us": round(avg_s * 1e6, 2),
                     "algorithmic_mb_per_launch": round(nbytes / 1e6, 3)}
-        return {"kernel": kernel, "avg_launch_us": round(avg_s * 1e6, 2)}
+        return {"kernel": name, "avg_launch_us": round(avg_s * 1e6 / per_step, 2), "launches_per_step": per_step}

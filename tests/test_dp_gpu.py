@@ -75,6 +75,29 @@ def test_bench_contract_under_torchrun_two_ranks():
     assert chk["param_checksum_agree"] is True and len(chk["devices"]) == 2 and chk["rccl_ranks"] == 0 and chk["backend"] == "gloo"
 
 
+def test_bench_launches_its_own_ranks():
+    """The driver's command shape is `python3 bench.py --gpus N ...` with no torch.distributed.run around it: bench.py starts the ranks itself
+    (fresh children, before this parent touches the GPU) and relays rank 0's one JSON line and the exit code."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CF_SHARE_DEVICE="1", CF_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--prewarm-s", "0.05"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["config"]["parallelism"] == "dp2" and d["dp_self_check"]["param_checksum_agree"] is True
+    assert d["config"]["hip_graph"] is False and d["config"]["dp_halves"] is True          # the mode chromoformer_amd.train runs under data parallelism
+    assert d["roofline"]["launches_per_step"] == 2                                         # (k_reg8_bwd in halves: normalised per step)
+    # without the one-device hooks the same command must refuse by naming the visible GPUs -- not with a launcher hint
+    if torch.cuda.device_count() < 2:
+        env.pop("CF_SHARE_DEVICE")
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stdout + r.stderr) and "launch with" not in (r.stdout + r.stderr)
+
+
 def test_bench_refuses_two_ranks_on_one_device_without_the_test_hook():
     """Without CF_SHARE_DEVICE a launch with more ranks than visible GPUs must fail loudly, not report a scaling number."""
     r = _launch(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {"CF_DIST_BACKEND": "gloo"}, timeout=300)

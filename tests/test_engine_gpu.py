@@ -155,6 +155,44 @@ def test_one_rank_rccl_all_reduce_in_the_step():
             assert torch.equal(ref[k], sd[k]), k
 
 
+def test_roofline_of_the_halved_regulation_backward_agrees_with_the_single_launch():
+    """Data parallel in halves launches the Regulation backward twice per step under one timing key; the flop count is the whole stack's.  The
+    roofline entry is normalised per step: it must agree with the single-launch (one-GPU) entry, not read twice its value."""
+    import torch.distributed as dist
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    batch = orc.synthetic_batch(B, seed=7, regime="dense")
+
+    def measure(**kw):
+        model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+        tr = Trainer(model, lr=3e-5, use_graph=False, timed_kernel="k_reg_bwd", **kw)
+        slot = tr.stage(batch)
+        for _ in range(20):
+            tr.step(slot)
+        torch.cuda.synchronize()
+        tr.timing_reset()
+        for _ in range(40):
+            tr.step(slot)
+        torch.cuda.synchronize()
+        ms, n = tr.timing_read()
+        return tr.roofline("k_reg_bwd", ms, n, B, steps=40), tr.halves
+
+    one, _ = measure()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dp, halves = measure(world_size=1, process_group=dist.group.WORLD)
+    finally:
+        dist.destroy_process_group()
+    assert halves and dp["launches_per_step"] == 2 and one["launches_per_step"] == 1
+    assert dp["algorithmic_gflop_per_step"] == one["algorithmic_gflop_per_step"]
+    # two launches over half the layers each take a little longer than one over all of them (a second launch ramp), never half as long
+    assert 0.6 * one["frac"] < dp["frac"] < 1.15 * one["frac"], (one, dp)
+
+
 def test_riders_must_be_followed_by_the_fused_reduction_of_the_same_step():
     """cf_rider_arm hands part of a bucket to the next trunk launch, AdamW included: a plain reduction, or a fused one for another step,
     must be refused afterwards (the bucket would be reduced twice / stepped with two sets of scalars)."""
@@ -283,3 +321,23 @@ def test_head_ride_counters_are_put_back_to_zero_between_launches(monkeypatch):
         assert loss == ref_loss
         for k in ref:
             assert torch.equal(ref[k], got[k]), (g, k)
+    # two Trainers (two streams) driving one handle in turn: the reset is ordered against the other stream's launches as well (ride_tick records /
+    # waits an event per foreign stream) -- same bits again
+    from chromoformer_amd import ChromoformerClassifier
+    from chromoformer_amd.engine import Trainer
+    model = ChromoformerClassifier(seed=42, max_batch=B).cuda(0)
+    trs = [Trainer(model, lr=3e-5, use_graph=False) for _ in range(2)]
+    slots = [[tr.stage(orc.synthetic_batch(B, seed=7 + i, regime="realistic")) for i in range(2)] for tr in trs]
+    losses = []
+    for i in range(6):
+        tr = trs[i % 2]
+        if i:
+            tr.stream.wait_stream(trs[(i - 1) % 2].stream)         # the steps themselves are ordered by the caller (they share the model's workspace)
+        _, loss = tr.step(slots[i % 2][i % 2])
+        with torch.cuda.stream(tr.stream):
+            losses.append(loss.clone())
+    torch.cuda.synchronize()
+    assert [float(x) for x in losses] == ref_loss
+    sd = model.state_dict()
+    for k in sd:
+        assert torch.equal(ref[k], sd[k].cpu()), k
