@@ -557,7 +557,7 @@ def main():
         if world == 1 and not args.no_extras:
             # BASELINE configs[3] and the HBM-bound kernel of the path in the SAME driver-run line (each about a second of GPU time)
             sr = stress_record(10, 2)
-            out["stress"] = dict(sr["roofline"], value=sr["value"], unit=sr["unit"], ms_per_step=sr["ms_per_step"], workload=sr["config"]["workload"])
+            out["stress"] = dict(sr["roofline"], genes_per_s=sr["value"], ms_per_step=sr["ms_per_step"], workload=sr["config"]["workload"])
             out["binning"] = binning_record()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -2874,6 +2874,24 @@ static int attn_bwd_launch(const AttnArgs& a, hipStream_t st) {
     const int mode = getenv_int("CF_ATTN_BWD_SPLIT", 0);
     const bool vec_ok = (a.ldq & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dq) & 15) == 0;      // (the dQ update is 16 bytes per lane)
     if (vec_ok && (mode < 0 || (mode == 0 && (long long)a.N * a.H >= 512))) {
+        // round 6: 128 keys per pass, eight waves, 141 KB of dynamic LDS (k_attn_bwd2); CF_ATTN_BWD_V1=1 runs the 64-key kernel of rounds 4-5 (the
+        // cross-check of the tests: same results up to the order of the fp32 additions inside dQ)
+        const bool v2_ok = ((reinterpret_cast<uintptr_t>(a.dk) | reinterpret_cast<uintptr_t>(a.dv)) & 15) == 0 && getenv_int("CF_ATTN_BWD_V1", 0) == 0;
+        if (v2_ok) {
+            static int ready = 0;      // 0: not tried, 1: attribute set, -1: refused by the runtime (fall through to the 64-key kernel)
+            if (ready == 0) {
+                hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAB2Smem);
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAB2Smem);
+                ready = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+                if (ready < 0) (void)hipGetLastError();
+            }
+            if (ready > 0) {
+                if (a.mask) hipLaunchKernelGGL(k_attn_bwd2<true>, dim3(a.H, a.N), dim3(512), kAB2Smem, st, a);
+                else hipLaunchKernelGGL(k_attn_bwd2<false>, dim3(a.H, a.N), dim3(512), kAB2Smem, st, a);
+                LAUNCH_CHECK("k_attn_bwd2");
+                return 0;
+            }
+        }
         hipLaunchKernelGGL(k_attn_bwd, dim3(a.H, a.N), dim3(256), 0, st, a);
         LAUNCH_CHECK("k_attn_bwd");
         return 0;

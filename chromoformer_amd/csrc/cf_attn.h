@@ -815,4 +815,266 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the one-pass backward with 128 KEYS PER PASS (k_attn_bwd2).  k_attn_bwd above walks Q / dO / dQ of its (sequence, head) once per
+// 64-key tile: 64 KB of HBM traffic per (key tile, query tile) pair, 47 GB per launch at the stress shape, and its timing probes say that this
+// traffic -- not the matrix pipe, not latency -- is what it waits for (LAB_NOTES.md, round 5).  Here a pass covers 128 keys: half the passes,
+// half the bytes.  Eight waves (one workgroup per CU, two waves per SIMD); wave w owns keys 16 w .. 16 w + 15 of the pass.
+//
+//  * NON-transposed score tiles: S = Q K^T with the Q tile as the A operand (LDS) and the wave's K rows as the B operand (registers, loaded once
+//    per pass).  In the accumulator layout a lane then holds S[query 16 t + 4 qd + g][key r] -- which IS the B operand of the transposed
+//    gradient products  dV^T[dh x keys] += dO^T[dh x queries] P[queries x keys],  dK^T += Q^T dS  (reduction over the queries in the order
+//    4 qd + j: j outer, qd across the lanes), so P and dS feed them straight from the registers: no P^T / dS^T patch, no wave barrier between
+//    the softmax and the products; the A operands are scalar reads of the dO / Q tiles in natural layout (conflict-free: lanes r walk a row).
+//  * dS goes to LDS once, as one 16-byte store per lane and 16-row block ([key][query] patches), for the only product that reduces over
+//    the keys:  dQ^T[16 head columns x 32 rows] += K^T[16 x 128 keys] dS^T[128 x 32]  per wave (wave = (column block w & 3, row half w >> 2)),
+//    added to the rows of dQ in global memory as before (one owner per element, fixed order of the passes: no atomics, bit-reproducible).
+//  * ONE workgroup barrier per pair: the Q / dO / statistics tiles and the dS patches are double-buffered in LDS (141 KB), the next pair's
+//    tile is requested into registers two phases ahead (behind the barrier of the previous pair) and written into the other buffer at the
+//    end of this pair's first phase -- its HBM round trip lies under ~10 K cycles of products instead of under the 2 K of the dQ^T product.
+//  * 16-row blocks of the last query tile beyond the tensor issue no products (L = 800: half of tile 13), waves whose keys lie beyond it
+//    skip their first phase (they publish a zero patch).
+#ifndef CF_AB2_SCHED
+#define CF_AB2_SCHED 7      // scheduling fences inside the first phase (1: between the k-chunks of S / dP, 2: behind the softmax, 4: between the row blocks of dV / dK)
+#endif
+#ifndef CF_AB2_PROBE
+#define CF_AB2_PROBE 0      // timing probes (WRONG results): 1 no p / dS arithmetic, 2 no tile transfers after the first, 4 no dQ update in global memory,
+#endif                      // 8 no barriers, 16 no dV / dK products, 32 no dQ^T product, 64 no S / dP products
+constexpr int kAB2K = 128;                                   // keys per pass
+constexpr int kAB2Tile = kABq * kALd;                        // floats of a [64][68] tile
+constexpr int kAB2Patch = 16 * kALd;                         // floats of one wave's dS patch [16 keys][68]
+constexpr int kAB2LdsFloats = 4 * kAB2Tile + 16 * kAB2Patch + 2 * kABq * 4;
+constexpr size_t kAB2Smem = (size_t)kAB2LdsFloats * sizeof(float);
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(512, 1) void k_attn_bwd2(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Qs = smem;                                  // [2][64][68]
+    float* const Gs = smem + 2 * kAB2Tile;                   // [2][64][68]  dO
+    float* const Ds = smem + 4 * kAB2Tile;                   // [2][8][16][68]  dS patches: [key of the wave][query of the tile]
+    float* const Ss = Ds + 16 * kAB2Patch;                   // [2][64][4]  max, 1 / sum (0 beyond the tensor), delta, query valid
+    const int n = blockIdx.y, h = blockIdx.x;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 15, qd = lane >> 4;
+    const int cw = w & 3, t0 = 2 * (w >> 2);                 // dQ^T: head columns 16 cw .. + 15, row blocks t0, t0 + 1 of the query tile
+    const float* qseq = a.q + (size_t)n * a.Lq * a.ldq + h * kADh;
+    const float* gseq = a.d_o + (size_t)n * a.Lq * a.ldo + h * kADh;
+    const float* kseq = a.k + (size_t)n * a.Lk * a.ldk + h * kADh;
+    const float* vseq = a.v + (size_t)n * a.Lk * a.ldv + h * kADh;
+    const float* stp = a.stats + ((size_t)n * a.H + h) * a.Lq * 2;
+    const float* dlp = a.delta + ((size_t)n * a.H + h) * a.Lq;
+    float* dqseq = a.dq + (size_t)n * a.Lq * a.ldq + h * kADh + 16 * cw + 4 * qd;      // this lane's four columns
+    const int NQ = (a.Lq + kABq - 1) / kABq;
+    const int sj = tid >> 4, sd = (tid & 15) * 4;            // staging: rows sj, sj + 32; columns sd .. sd + 3
+
+    // A query tile travels global -> LDS by dword LDS-DMA, one wave instruction per tile row (256 contiguous bytes into a padded LDS row: M0 carries the
+    // row's LDS address), issued from inline assembly: no staging registers, and the compiler -- which does not see the transfer -- puts no
+    // conservative wait in front of the next LDS access; the wait is this kernel's own `s_waitcnt vmcnt(0)` in front of the barrier that publishes
+    // the tile.  Wave w moves rows 8 w .. 8 w + 7 of Q and of dO.  Rows beyond the tensor re-read the last one: their 1 / sum is 0 (below), so
+    // whatever they hold contributes exact zeros.  The statistics of the tile (64 rows x 4 floats) go through one register set of threads 0 .. 63.
+    typedef __attribute__((address_space(3))) float* lds_ptr_t;
+    const unsigned lds_q = (unsigned)(uintptr_t)(lds_ptr_t)Qs, lds_g = (unsigned)(uintptr_t)(lds_ptr_t)Gs;
+    auto dma_row = [&](const float* sb, unsigned voff, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds_byte) : "memory");
+    };
+    auto dma_tile = [&](int q0, int b) {
+        const float* qb = sbase(qseq, 0);
+        const float* gb = sbase(gseq, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = 8 * w + i, row = min(q0 + j, a.Lq - 1);
+            dma_row(qb, (unsigned)(row * a.ldq + lane) * 4u, lds_q + (unsigned)((b * kAB2Tile + j * kALd) * 4));
+            dma_row(gb, (unsigned)(row * a.ldo + lane) * 4u, lds_g + (unsigned)((b * kAB2Tile + j * kALd) * 4));
+        }
+    };
+    float4 ps;
+    auto fetch_stats = [&](int q0) {
+        ps = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < kABq) {
+            const int i = q0 + tid, ic = min(i, a.Lq - 1);
+            const float2 ml = ldg2(stp + 2 * ic);
+            const bool qv = a.qvalid ? a.qvalid[(size_t)n * a.Lq + ic] != 0 : true;
+            // (beyond the tensor: "masked" with maximum 0 and 1 / sum 0, so that p = exp(-1e9 - 0) * 0 = 0 whatever the clamped row holds)
+            ps = i < a.Lq ? make_float4(ml.x, ml.y, ldg(dlp + ic), qv ? 1.f : 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto put_stats = [&](int b) {
+        if (tid < kABq) *reinterpret_cast<float4*>(Ss + b * kABq * 4 + tid * 4) = ps;
+    };
+    auto publish = [&]() {      // this wave's transfers have landed; the barrier makes every wave's visible
+        if (CF_AB2_PROBE & 8) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    fetch_stats(0);
+    dma_tile(0, 0);
+    put_stats(0);
+    publish();
+    if (NQ > 1 || a.Lk > kAB2K) {      // pair 1's tile
+        fetch_stats(NQ > 1 ? kABq : 0);
+        dma_tile(NQ > 1 ? kABq : 0, 1);
+    }
+    int pair = 0;
+    for (int k0 = 0; k0 < a.Lk; k0 += kAB2K) {
+        // ---- this pass's operands: the wave's 16 keys as rows of K and V (B operands of S and dP), column 16 cw + r of the K tile (A operand of dQ^T)
+        const int key = k0 + 16 * w + r;                     // the key of this lane's score column
+        const bool wave_live = k0 + 16 * w < a.Lk, klive = key < a.Lk;
+        const bool kvr = klive && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + min(key, a.Lk - 1)] != 0 : true);
+        float4 kf[4], vf[4], kt[8];
+        {
+            const unsigned ko = (unsigned)(min(key, a.Lk - 1) * a.ldk + 4 * qd) * 4u, vo = (unsigned)(min(key, a.Lk - 1) * a.ldv + 4 * qd) * 4u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kf[u] = f4_keep_if(klive, ldg4(lane_at(sbase(kseq, 0), ko) + 16 * u));
+                vf[u] = f4_keep_if(klive, ldg4(lane_at(sbase(vseq, 0), vo) + 16 * u));
+            }
+            // (scalar base + 32-bit lane offsets, no branch around a load: as 64-bit per-lane addresses these 32 gathers were the kernel's spills)
+            const float* kc = sbase(kseq + 16 * cw, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float v4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = k0 + 16 * u + 4 * qd + i;
+                    const float x = ldg(lane_at(kc, (unsigned)(min(kk, a.Lk - 1) * a.ldk + r) * 4u));
+                    v4[i] = kk < a.Lk ? x : 0.f;
+                }
+                kt[u] = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            }
+        }
+        f32x4 dk[4], dv[4];                                  // dK^T, dV^T: rows = head columns 16 c + 4 qd + g, column = key r of the wave
+        zero_acc(dk);
+        zero_acc(dv);
+        for (int qi = 0; qi < NQ; ++qi, ++pair) {
+            const int b = pair & 1, q0 = qi * kABq;
+            const int nt = min(4, (a.Lq - q0 + 15) >> 4);    // live 16-row blocks of this query tile
+            const float* Qb = Qs + b * kAB2Tile;
+            const float* Gb = Gs + b * kAB2Tile;
+            const float* Sb = Ss + b * kABq * 4;
+            float* Dw = Ds + (b * 8 + w) * kAB2Patch;
+            const bool last_pair = qi + 1 == NQ && k0 + kAB2K >= a.Lk;
+            auto body = [&](auto full_c) {
+                constexpr bool FULL = decltype(full_c)::value;
+                // ---------------- first phase: S, dP, p / dS, dV^T, dK^T of this wave's 16 keys, its dS patch
+                if (wave_live) {
+                    f32x4 s[4], dp[4];
+                    zero_acc(s);
+                    zero_acc(dp);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (CF_AB2_PROBE & 64) break;
+                        if (CF_AB2_SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (!FULL && t >= nt) continue;
+                            const float4 qa = *reinterpret_cast<const float4*>(Qb + (16 * t + r) * kALd + 16 * u + 4 * qd);
+                            const float4 ga = *reinterpret_cast<const float4*>(Gb + (16 * t + r) * kALd + 16 * u + 4 * qd);
+                            s[t] = mfma4(qa.x, kf[u].x, s[t]);
+                            dp[t] = mfma4(ga.x, vf[u].x, dp[t]);
+                            s[t] = mfma4(qa.y, kf[u].y, s[t]);
+                            dp[t] = mfma4(ga.y, vf[u].y, dp[t]);
+                            s[t] = mfma4(qa.z, kf[u].z, s[t]);
+                            dp[t] = mfma4(ga.z, vf[u].z, dp[t]);
+                            s[t] = mfma4(qa.w, kf[u].w, s[t]);
+                            dp[t] = mfma4(ga.w, vf[u].w, dp[t]);
+                        }
+                    }
+                    if (CF_AB2_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!FULL && t >= nt) continue;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            if (CF_AB2_PROBE & 1) break;
+                            const float4 sv = *reinterpret_cast<const float4*>(Sb + (16 * t + 4 * qd + g) * 4);
+                            bool mk;
+                            if (HAS_MASK) mk = a.mask[((size_t)n * a.Lq + min(q0 + 16 * t + 4 * qd + g, a.Lq - 1)) * a.Lk + min(key, a.Lk - 1)] != 0;
+                            else mk = !(sv.w != 0.f && kvr);
+                            const float x = mk ? kMaskFill : s[t][g] * a.rscale;
+                            float p = __expf(x - sv.x) * sv.y;
+                            p = klive ? p : 0.f;
+                            s[t][g] = p;
+                            dp[t][g] = mk ? 0.f : p * (dp[t][g] - sv.z) * a.rscale;      // dS overwrites dP
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!FULL && t >= nt) continue;
+                        if (CF_AB2_SCHED & 4) __builtin_amdgcn_sched_barrier(0);
+                        *reinterpret_cast<float4*>(Dw + r * kALd + 16 * t + 4 * qd) = make_float4(dp[t][0], dp[t][1], dp[t][2], dp[t][3]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (CF_AB2_PROBE & 16) break;
+                            const float* grow = Gb + (16 * t + 4 * qd + j) * kALd + r;
+                            const float* qrow = Qb + (16 * t + 4 * qd + j) * kALd + r;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                dv[c] = mfma4(grow[16 * c], s[t][j], dv[c]);
+                                dk[c] = mfma4(qrow[16 * c], dp[t][j], dk[c]);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(Dw + r * kALd + 16 * t + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (!last_pair) put_stats(b ^ 1);            // the next pair's statistics (its tile was sent off at the end of the previous pair)
+                publish();                                   // every dS patch of this pair and the next tile are in LDS
+                // ---------------- second phase: dQ^T of this wave's (column block, row half); the tile after next is sent off at its end
+                float4 dqo[2];
+                const bool r0 = FULL || t0 < nt, r1 = FULL || t0 + 1 < nt;
+                if (k0 > 0 && !(CF_AB2_PROBE & 4)) {
+                    dqo[0] = ldg4(dqseq + (size_t)min(q0 + 16 * t0 + r, a.Lq - 1) * a.ldq);
+                    dqo[1] = ldg4(dqseq + (size_t)min(q0 + 16 * t0 + 16 + r, a.Lq - 1) * a.ldq);
+                }
+                f32x4 dq[2];
+                zero_acc(dq);
+                const float* Db = Ds + b * 8 * kAB2Patch + 4 * qd * kALd + 16 * t0 + r;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (CF_AB2_PROBE & 32) break;
+                    const float a4[4] = {kt[u].x, kt[u].y, kt[u].z, kt[u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (r0) dq[0] = mfma4(a4[i], Db[u * kAB2Patch + i * kALd], dq[0]);
+                        if (r1) dq[1] = mfma4(a4[i], Db[u * kAB2Patch + i * kALd + 16], dq[1]);
+                    }
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int row = q0 + 16 * (t0 + tt) + r;
+                    if (row < a.Lq && (!(CF_AB2_PROBE & 4) || (qi == 0 && k0 + kAB2K >= a.Lk))) {
+                        float4 v = make_float4(dq[tt][0], dq[tt][1], dq[tt][2], dq[tt][3]);
+                        if (k0 > 0 && !(CF_AB2_PROBE & 4)) v = make_float4(v.x + dqo[tt].x, v.y + dqo[tt].y, v.z + dqo[tt].z, v.w + dqo[tt].w);
+                        stg4(dqseq + (size_t)row * a.ldq, v);
+                    }
+                }
+                {   // pair + 2 (query tile qi + 2 of this pass, or tile 0 / 1 of the next one) into THIS pair's buffers: every wave is past the barrier,
+                    // nobody reads them any more.  Behind the dQ loads on purpose: a compiler-counted wait for those must not cover these transfers.
+                    int nq = qi + 2, nk = k0;
+                    if (nq >= NQ) nq -= NQ, nk += kAB2K;
+                    if (NQ == 1) nq = 0, nk = k0 + 2 * kAB2K;
+                    if (nk < a.Lk && !(CF_AB2_PROBE & 2)) {
+                        fetch_stats(nq * kABq);
+                        dma_tile(nq * kABq, b);
+                    }
+                }
+            };
+            if (nt == 4) body(std::true_type{});
+            else body(std::false_type{});
+        }
+        if (klive) {
+            float* dkp = a.dk + ((size_t)n * a.Lk + key) * a.ldk + h * kADh + 4 * qd;
+            float* dvp = a.dv + ((size_t)n * a.Lk + key) * a.ldv + h * kADh + 4 * qd;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                stg4(dkp + 16 * c, make_float4(dk[c][0], dk[c][1], dk[c][2], dk[c][3]));
+                stg4(dvp + 16 * c, make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]));
+            }
+        }
+    }
+}
+
 }  // namespace cf

@@ -12,11 +12,13 @@ from oracle import chromoformer_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-@pytest.fixture(params=["split", "fused"], autouse=True)
+@pytest.fixture(params=["split", "fused", "fused64"], autouse=True)
 def attention_backward_form(request, monkeypatch):
-    """Every test of this module runs twice: with the backward as two kernels split by output owner (k_attn_bwd_kv + k_attn_bwd_q)
-    and as the one-pass kernel (k_attn_bwd; the library picks it by itself only for launches with >= 512 (sequence, head) pairs)."""
+    """Every test of this module runs three times: with the backward as two kernels split by output owner (k_attn_bwd_kv + k_attn_bwd_q), as the
+    one-pass kernel with 128 keys per pass (k_attn_bwd2, round 6; the library picks a one-pass kernel by itself only for launches with >= 512
+    (sequence, head) pairs) and as the one-pass kernel of rounds 4-5 (k_attn_bwd, 64 keys per pass: CF_ATTN_BWD_V1=1)."""
     monkeypatch.setenv("CF_ATTN_BWD_SPLIT", "1" if request.param == "split" else "-1")
+    monkeypatch.setenv("CF_ATTN_BWD_V1", "1" if request.param == "fused64" else "0")
     return request.param
 
 
