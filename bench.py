@@ -251,7 +251,7 @@ def stress_record(steps, warmup):
            "config": {"workload": "stress config (BASELINE configs[3]): dense attention core forward + backward, all rows, "
                                   "N = 128 x 17 = %d sequences x %d heads, L = %d, dh = 64 -- attention kernels only, not a training step" % (N, H, L),
                       "parallelism": "dp1", "global_batch": B},
-           "roofline": {"kernel": "k_attn_fwd + k_attn_delta + k_attn_bwd (dQ, dK, dV in one pass per (sequence, head))", "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3,
+           "roofline": {"kernel": "k_attn_fwd + k_attn_delta + k_attn_bwd2 (dQ, dK, dV in one pass per (sequence, head), 128 keys per pass)", "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3,
                         "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "frac_no_recompute": round(ach * 12.0 / 14.0 / 157.3, 4), "traffic": None, "avg_launch_us": round(dev_ms * 1e3, 1),
                         "fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3),
                         "fwd_tflops": round(4.0 * N * H * L * L * 64 / (fwd_ms * 1e-3) / 1e12, 2),

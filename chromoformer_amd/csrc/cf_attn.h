@@ -837,6 +837,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_bwd(AttnArgs a) {
 #ifndef CF_AB2_SCHED
 #define CF_AB2_SCHED 7      // scheduling fences inside the first phase (1: between the k-chunks of S / dP, 2: behind the softmax, 4: between the row blocks of dV / dK)
 #endif
+#ifndef CF_AB2_M0_KEEP
+#define CF_AB2_M0_KEEP 0
+#endif
+#ifndef CF_AB2_STAGGER
+#define CF_AB2_STAGGER 1    // waves 4-7 run the two phases of an interval in the opposite order (see the schedule inside the kernel)
+#endif
 #ifndef CF_AB2_PROBE
 #define CF_AB2_PROBE 0      // timing probes (WRONG results): 1 no p / dS arithmetic, 2 no tile transfers after the first, 4 no dQ update in global memory,
 #endif                      // 8 no barriers, 16 no dV / dK products, 32 no dQ^T product, 64 no S / dP products
@@ -873,19 +879,35 @@ __global__ __launch_bounds__(512, 1) void k_attn_bwd2(AttnArgs a) {
     // whatever they hold contributes exact zeros.  The statistics of the tile (64 rows x 4 floats) go through one register set of threads 0 .. 63.
     typedef __attribute__((address_space(3))) float* lds_ptr_t;
     const unsigned lds_q = (unsigned)(uintptr_t)(lds_ptr_t)Qs, lds_g = (unsigned)(uintptr_t)(lds_ptr_t)Gs;
+    // (M0 is written in the statement that uses it and not put back: the compiler keeps nothing in M0 across statements -- no other LDS-DMA, no
+    //  `s_movrel`, no `ds_*_addtid` in this kernel; CF_AB2_M0_KEEP=1: the save / restore form of tools/probes/lds_dma_row.hip)
     auto dma_row = [&](const float* sb, unsigned voff, unsigned lds_byte) {
+#if CF_AB2_M0_KEEP
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds_byte) : "memory");
+#else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sb), "s"(lds_byte) : "memory");
+#endif
     };
     auto dma_tile = [&](int q0, int b) {
         const float* qb = sbase(qseq, 0);
         const float* gb = sbase(gseq, 0);
+        const unsigned lq = lds_q + (unsigned)((b * kAB2Tile + 8 * w * kALd) * 4), lg = lds_g + (unsigned)((b * kAB2Tile + 8 * w * kALd) * 4);
+        if (q0 + kABq <= a.Lq) {      // a whole tile: one lane offset, the row in the (scalar) base
+            const unsigned vq = (unsigned)((q0 + 8 * w) * a.ldq + lane) * 4u, vg = (unsigned)((q0 + 8 * w) * a.ldo + lane) * 4u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = 8 * w + i, row = min(q0 + j, a.Lq - 1);
-            dma_row(qb, (unsigned)(row * a.ldq + lane) * 4u, lds_q + (unsigned)((b * kAB2Tile + j * kALd) * 4));
-            dma_row(gb, (unsigned)(row * a.ldo + lane) * 4u, lds_g + (unsigned)((b * kAB2Tile + j * kALd) * 4));
+            for (int i = 0; i < 8; ++i) {
+                dma_row(qb + (size_t)i * a.ldq, vq, lq + (unsigned)(i * kALd * 4));
+                dma_row(gb + (size_t)i * a.ldo, vg, lg + (unsigned)(i * kALd * 4));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = min(q0 + 8 * w + i, a.Lq - 1);
+                dma_row(qb, (unsigned)(row * a.ldq + lane) * 4u, lq + (unsigned)(i * kALd * 4));
+                dma_row(gb, (unsigned)(row * a.ldo + lane) * 4u, lg + (unsigned)(i * kALd * 4));
+            }
         }
     };
     float4 ps;
@@ -908,163 +930,47 @@ __global__ __launch_bounds__(512, 1) void k_attn_bwd2(AttnArgs a) {
         __syncthreads();
     };
 
-    fetch_stats(0);
-    dma_tile(0, 0);
-    put_stats(0);
-    publish();
-    if (NQ > 1 || a.Lk > kAB2K) {      // pair 1's tile
-        fetch_stats(NQ > 1 ? kABq : 0);
-        dma_tile(NQ > 1 ? kABq : 0, 1);
-    }
-    int pair = 0;
-    for (int k0 = 0; k0 < a.Lk; k0 += kAB2K) {
-        // ---- this pass's operands: the wave's 16 keys as rows of K and V (B operands of S and dP), column 16 cw + r of the K tile (A operand of dQ^T)
-        const int key = k0 + 16 * w + r;                     // the key of this lane's score column
-        const bool wave_live = k0 + 16 * w < a.Lk, klive = key < a.Lk;
-        const bool kvr = klive && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + min(key, a.Lk - 1)] != 0 : true);
-        float4 kf[4], vf[4], kt[8];
-        {
-            const unsigned ko = (unsigned)(min(key, a.Lk - 1) * a.ldk + 4 * qd) * 4u, vo = (unsigned)(min(key, a.Lk - 1) * a.ldv + 4 * qd) * 4u;
+    // ---- the schedule.  Interval p (between the barriers that end pairs p - 1 and p) holds two independent pieces of work: the SECOND phase of
+    // pair p - 1 (dQ^T from the dS patches that barrier published) and the FIRST phase of pair p (S, dP, p / dS, dV^T, dK^T on the tile that barrier
+    // published).  Waves 0-3 run them in that order, waves 4-7 in the opposite one -- a SIMD holds one wave of each group, so while one of them
+    // does the softmax arithmetic, updates dQ in global memory or issues the next tile's transfers, the other one has matrix-core work
+    // (CF_AB2_STAGGER=0: every wave in the first order).  The first interval of a pass runs second-phase-first in every wave: that phase still
+    // needs the previous pass's K^T operand, the first phase the new pass's.
+    const int NK = (a.Lk + kAB2K - 1) / kAB2K, P = NQ * NK;
+    const bool grp_b = CF_AB2_STAGGER && w >= 4;
+    float4 kf[4], vf[4], kt[8];
+    f32x4 dk[4], dv[4];                                      // dK^T, dV^T: rows = head columns 16 c + 4 qd + g, column = key r of the wave
+    int key = 0;
+    bool wave_live = false, klive = false, kvr = false;
+
+    auto load_pass = [&](int k0) {      // the wave's 16 keys as rows of K and V (B operands of S and dP), column 16 cw + r of the K tile (A operand of dQ^T)
+        key = k0 + 16 * w + r;                               // the key of this lane's score column
+        wave_live = k0 + 16 * w < a.Lk;
+        klive = key < a.Lk;
+        kvr = klive && (a.kvalid ? a.kvalid[(size_t)n * a.Lk + min(key, a.Lk - 1)] != 0 : true);
+        const unsigned ko = (unsigned)(min(key, a.Lk - 1) * a.ldk + 4 * qd) * 4u, vo = (unsigned)(min(key, a.Lk - 1) * a.ldv + 4 * qd) * 4u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                kf[u] = f4_keep_if(klive, ldg4(lane_at(sbase(kseq, 0), ko) + 16 * u));
-                vf[u] = f4_keep_if(klive, ldg4(lane_at(sbase(vseq, 0), vo) + 16 * u));
-            }
-            // (scalar base + 32-bit lane offsets, no branch around a load: as 64-bit per-lane addresses these 32 gathers were the kernel's spills)
-            const float* kc = sbase(kseq + 16 * cw, 0);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float v4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int kk = k0 + 16 * u + 4 * qd + i;
-                    const float x = ldg(lane_at(kc, (unsigned)(min(kk, a.Lk - 1) * a.ldk + r) * 4u));
-                    v4[i] = kk < a.Lk ? x : 0.f;
-                }
-                kt[u] = make_float4(v4[0], v4[1], v4[2], v4[3]);
-            }
+        for (int u = 0; u < 4; ++u) {
+            kf[u] = f4_keep_if(klive, ldg4(lane_at(sbase(kseq, 0), ko) + 16 * u));
+            vf[u] = f4_keep_if(klive, ldg4(lane_at(sbase(vseq, 0), vo) + 16 * u));
         }
-        f32x4 dk[4], dv[4];                                  // dK^T, dV^T: rows = head columns 16 c + 4 qd + g, column = key r of the wave
+        // (scalar base + 32-bit lane offsets, no branch around a load: as 64-bit per-lane addresses these 32 gathers were the kernel's spills)
+        const float* kc = sbase(kseq + 16 * cw, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float v4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = k0 + 16 * u + 4 * qd + i;
+                const float x = ldg(lane_at(kc, (unsigned)(min(kk, a.Lk - 1) * a.ldk + r) * 4u));
+                v4[i] = kk < a.Lk ? x : 0.f;
+            }
+            kt[u] = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        }
         zero_acc(dk);
         zero_acc(dv);
-        for (int qi = 0; qi < NQ; ++qi, ++pair) {
-            const int b = pair & 1, q0 = qi * kABq;
-            const int nt = min(4, (a.Lq - q0 + 15) >> 4);    // live 16-row blocks of this query tile
-            const float* Qb = Qs + b * kAB2Tile;
-            const float* Gb = Gs + b * kAB2Tile;
-            const float* Sb = Ss + b * kABq * 4;
-            float* Dw = Ds + (b * 8 + w) * kAB2Patch;
-            const bool last_pair = qi + 1 == NQ && k0 + kAB2K >= a.Lk;
-            auto body = [&](auto full_c) {
-                constexpr bool FULL = decltype(full_c)::value;
-                // ---------------- first phase: S, dP, p / dS, dV^T, dK^T of this wave's 16 keys, its dS patch
-                if (wave_live) {
-                    f32x4 s[4], dp[4];
-                    zero_acc(s);
-                    zero_acc(dp);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (CF_AB2_PROBE & 64) break;
-                        if (CF_AB2_SCHED & 1) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if (!FULL && t >= nt) continue;
-                            const float4 qa = *reinterpret_cast<const float4*>(Qb + (16 * t + r) * kALd + 16 * u + 4 * qd);
-                            const float4 ga = *reinterpret_cast<const float4*>(Gb + (16 * t + r) * kALd + 16 * u + 4 * qd);
-                            s[t] = mfma4(qa.x, kf[u].x, s[t]);
-                            dp[t] = mfma4(ga.x, vf[u].x, dp[t]);
-                            s[t] = mfma4(qa.y, kf[u].y, s[t]);
-                            dp[t] = mfma4(ga.y, vf[u].y, dp[t]);
-                            s[t] = mfma4(qa.z, kf[u].z, s[t]);
-                            dp[t] = mfma4(ga.z, vf[u].z, dp[t]);
-                            s[t] = mfma4(qa.w, kf[u].w, s[t]);
-                            dp[t] = mfma4(ga.w, vf[u].w, dp[t]);
-                        }
-                    }
-                    if (CF_AB2_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (!FULL && t >= nt) continue;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if (CF_AB2_PROBE & 1) break;
-                            const float4 sv = *reinterpret_cast<const float4*>(Sb + (16 * t + 4 * qd + g) * 4);
-                            bool mk;
-                            if (HAS_MASK) mk = a.mask[((size_t)n * a.Lq + min(q0 + 16 * t + 4 * qd + g, a.Lq - 1)) * a.Lk + min(key, a.Lk - 1)] != 0;
-                            else mk = !(sv.w != 0.f && kvr);
-                            const float x = mk ? kMaskFill : s[t][g] * a.rscale;
-                            float p = __expf(x - sv.x) * sv.y;
-                            p = klive ? p : 0.f;
-                            s[t][g] = p;
-                            dp[t][g] = mk ? 0.f : p * (dp[t][g] - sv.z) * a.rscale;      // dS overwrites dP
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (!FULL && t >= nt) continue;
-                        if (CF_AB2_SCHED & 4) __builtin_amdgcn_sched_barrier(0);
-                        *reinterpret_cast<float4*>(Dw + r * kALd + 16 * t + 4 * qd) = make_float4(dp[t][0], dp[t][1], dp[t][2], dp[t][3]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (CF_AB2_PROBE & 16) break;
-                            const float* grow = Gb + (16 * t + 4 * qd + j) * kALd + r;
-                            const float* qrow = Qb + (16 * t + 4 * qd + j) * kALd + r;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                dv[c] = mfma4(grow[16 * c], s[t][j], dv[c]);
-                                dk[c] = mfma4(qrow[16 * c], dp[t][j], dk[c]);
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(Dw + r * kALd + 16 * t + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                if (!last_pair) put_stats(b ^ 1);            // the next pair's statistics (its tile was sent off at the end of the previous pair)
-                publish();                                   // every dS patch of this pair and the next tile are in LDS
-                // ---------------- second phase: dQ^T of this wave's (column block, row half); the tile after next is sent off at its end
-                float4 dqo[2];
-                const bool r0 = FULL || t0 < nt, r1 = FULL || t0 + 1 < nt;
-                if (k0 > 0 && !(CF_AB2_PROBE & 4)) {
-                    dqo[0] = ldg4(dqseq + (size_t)min(q0 + 16 * t0 + r, a.Lq - 1) * a.ldq);
-                    dqo[1] = ldg4(dqseq + (size_t)min(q0 + 16 * t0 + 16 + r, a.Lq - 1) * a.ldq);
-                }
-                f32x4 dq[2];
-                zero_acc(dq);
-                const float* Db = Ds + b * 8 * kAB2Patch + 4 * qd * kALd + 16 * t0 + r;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (CF_AB2_PROBE & 32) break;
-                    const float a4[4] = {kt[u].x, kt[u].y, kt[u].z, kt[u].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (r0) dq[0] = mfma4(a4[i], Db[u * kAB2Patch + i * kALd], dq[0]);
-                        if (r1) dq[1] = mfma4(a4[i], Db[u * kAB2Patch + i * kALd + 16], dq[1]);
-                    }
-                }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int row = q0 + 16 * (t0 + tt) + r;
-                    if (row < a.Lq && (!(CF_AB2_PROBE & 4) || (qi == 0 && k0 + kAB2K >= a.Lk))) {
-                        float4 v = make_float4(dq[tt][0], dq[tt][1], dq[tt][2], dq[tt][3]);
-                        if (k0 > 0 && !(CF_AB2_PROBE & 4)) v = make_float4(v.x + dqo[tt].x, v.y + dqo[tt].y, v.z + dqo[tt].z, v.w + dqo[tt].w);
-                        stg4(dqseq + (size_t)row * a.ldq, v);
-                    }
-                }
-                {   // pair + 2 (query tile qi + 2 of this pass, or tile 0 / 1 of the next one) into THIS pair's buffers: every wave is past the barrier,
-                    // nobody reads them any more.  Behind the dQ loads on purpose: a compiler-counted wait for those must not cover these transfers.
-                    int nq = qi + 2, nk = k0;
-                    if (nq >= NQ) nq -= NQ, nk += kAB2K;
-                    if (NQ == 1) nq = 0, nk = k0 + 2 * kAB2K;
-                    if (nk < a.Lk && !(CF_AB2_PROBE & 2)) {
-                        fetch_stats(nq * kABq);
-                        dma_tile(nq * kABq, b);
-                    }
-                }
-            };
-            if (nt == 4) body(std::true_type{});
-            else body(std::false_type{});
-        }
+    };
+    auto store_pass = [&]() {
         if (klive) {
             float* dkp = a.dk + ((size_t)n * a.Lk + key) * a.ldk + h * kADh + 4 * qd;
             float* dvp = a.dv + ((size_t)n * a.Lk + key) * a.ldv + h * kADh + 4 * qd;
@@ -1074,6 +980,149 @@ __global__ __launch_bounds__(512, 1) void k_attn_bwd2(AttnArgs a) {
                 stg4(dvp + 16 * c, make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]));
             }
         }
+    };
+
+    // ---------------- first phase of pair p: S, dP, p / dS, dV^T, dK^T of this wave's 16 keys, its dS patch
+    auto phase_a = [&](int p, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int b = p & 1, q0 = (p % NQ) * kABq;
+        const int nt = min(4, (a.Lq - q0 + 15) >> 4);        // live 16-row blocks of this query tile
+        const float* Qb = Qs + b * kAB2Tile;
+        const float* Gb = Gs + b * kAB2Tile;
+        const float* Sb = Ss + b * kABq * 4;
+        float* Dw = Ds + (b * 8 + w) * kAB2Patch;
+        if (wave_live) {
+            f32x4 s[4], dp[4];
+            zero_acc(s);
+            zero_acc(dp);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (CF_AB2_PROBE & 64) break;
+                if (CF_AB2_SCHED & 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (!FULL && t >= nt) continue;
+                    const float4 qa = *reinterpret_cast<const float4*>(Qb + (16 * t + r) * kALd + 16 * u + 4 * qd);
+                    const float4 ga = *reinterpret_cast<const float4*>(Gb + (16 * t + r) * kALd + 16 * u + 4 * qd);
+                    s[t] = mfma4(qa.x, kf[u].x, s[t]);
+                    dp[t] = mfma4(ga.x, vf[u].x, dp[t]);
+                    s[t] = mfma4(qa.y, kf[u].y, s[t]);
+                    dp[t] = mfma4(ga.y, vf[u].y, dp[t]);
+                    s[t] = mfma4(qa.z, kf[u].z, s[t]);
+                    dp[t] = mfma4(ga.z, vf[u].z, dp[t]);
+                    s[t] = mfma4(qa.w, kf[u].w, s[t]);
+                    dp[t] = mfma4(ga.w, vf[u].w, dp[t]);
+                }
+            }
+            if (CF_AB2_SCHED & 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!FULL && t >= nt) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (CF_AB2_PROBE & 1) break;
+                    const float4 sv = *reinterpret_cast<const float4*>(Sb + (16 * t + 4 * qd + g) * 4);
+                    bool mk;
+                    if (HAS_MASK) mk = a.mask[((size_t)n * a.Lq + min(q0 + 16 * t + 4 * qd + g, a.Lq - 1)) * a.Lk + min(key, a.Lk - 1)] != 0;
+                    else mk = !(sv.w != 0.f && kvr);
+                    const float x = mk ? kMaskFill : s[t][g] * a.rscale;
+                    float pr = __expf(x - sv.x) * sv.y;
+                    pr = klive ? pr : 0.f;
+                    s[t][g] = pr;
+                    dp[t][g] = mk ? 0.f : pr * (dp[t][g] - sv.z) * a.rscale;      // dS overwrites dP
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!FULL && t >= nt) continue;
+                if (CF_AB2_SCHED & 4) __builtin_amdgcn_sched_barrier(0);
+                *reinterpret_cast<float4*>(Dw + r * kALd + 16 * t + 4 * qd) = make_float4(dp[t][0], dp[t][1], dp[t][2], dp[t][3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (CF_AB2_PROBE & 16) break;
+                    const float* grow = Gb + (16 * t + 4 * qd + j) * kALd + r;
+                    const float* qrow = Qb + (16 * t + 4 * qd + j) * kALd + r;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        dv[c] = mfma4(grow[16 * c], s[t][j], dv[c]);
+                        dk[c] = mfma4(qrow[16 * c], dp[t][j], dk[c]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(Dw + r * kALd + 16 * t + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // ---------------- second phase of pair p: dQ^T of this wave's (column block, row half), added to dQ in global memory
+    auto phase_b = [&](int p) {
+        const int b = p & 1, q0 = (p % NQ) * kABq;
+        const bool first_pass = p < NQ;
+        const int nt = min(4, (a.Lq - q0 + 15) >> 4);
+        const bool r0 = t0 < nt, r1 = t0 + 1 < nt;
+        float4 dqo[2];
+        if (!first_pass && !(CF_AB2_PROBE & 4)) {
+            dqo[0] = ldg4(dqseq + (size_t)min(q0 + 16 * t0 + r, a.Lq - 1) * a.ldq);
+            dqo[1] = ldg4(dqseq + (size_t)min(q0 + 16 * t0 + 16 + r, a.Lq - 1) * a.ldq);
+        }
+        f32x4 dq[2];
+        zero_acc(dq);
+        const float* Db = Ds + b * 8 * kAB2Patch + 4 * qd * kALd + 16 * t0 + r;
+        if (r1) {          // both row blocks live (every tile but a ragged last one)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (CF_AB2_PROBE & 32) break;
+                const float a4[4] = {kt[u].x, kt[u].y, kt[u].z, kt[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dq[0] = mfma4(a4[i], Db[u * kAB2Patch + i * kALd], dq[0]);
+                    dq[1] = mfma4(a4[i], Db[u * kAB2Patch + i * kALd + 16], dq[1]);
+                }
+            }
+        } else if (r0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float a4[4] = {kt[u].x, kt[u].y, kt[u].z, kt[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dq[0] = mfma4(a4[i], Db[u * kAB2Patch + i * kALd], dq[0]);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = q0 + 16 * (t0 + tt) + r;
+            if (row < a.Lq && (!(CF_AB2_PROBE & 4) || p >= P - NQ)) {
+                float4 v = make_float4(dq[tt][0], dq[tt][1], dq[tt][2], dq[tt][3]);
+                if (!first_pass && !(CF_AB2_PROBE & 4)) v = make_float4(v.x + dqo[tt].x, v.y + dqo[tt].y, v.z + dqo[tt].z, v.w + dqo[tt].w);
+                stg4(dqseq + (size_t)row * a.ldq, v);
+            }
+        }
+    };
+    // pair p + 1's tile into the buffers pair p - 1 used (every wave is past the barrier that ended that pair's first phase), its statistics into `ps`
+    auto send_next = [&](int p) {
+        if (p + 1 < P && !((CF_AB2_PROBE & 2) && p > 0)) {
+            const int q0n = ((p + 1) % NQ) * kABq;
+            fetch_stats(q0n);
+            dma_tile(q0n, (p + 1) & 1);
+        }
+    };
+
+    fetch_stats(0);
+    dma_tile(0, 0);
+    put_stats(0);
+    publish();
+    for (int p = 0; p <= P; ++p) {
+        const bool pass_start = p < P && p % NQ == 0;
+        const bool b_first = !grp_b || pass_start || p == P;
+        if (b_first && p > 0) phase_b(p - 1);                // (behind it: a compiler-counted wait for its dQ loads must not cover the transfers below)
+        if (p % NQ == 0 && p > 0) store_pass();              // the previous pass's dK, dV are complete
+        if (p == P) break;
+        if (pass_start) load_pass((p / NQ) * kAB2K);
+        send_next(p);
+        if (a.Lq - (p % NQ) * kABq >= kABq) phase_a(p, std::true_type{});
+        else phase_a(p, std::false_type{});
+        if (!b_first) phase_b(p - 1);
+        if (p + 1 < P) put_stats((p + 1) & 1);
+        publish();                                           // every dS patch of pair p and pair p + 1's tile are in LDS
     }
 }
 

@@ -3,8 +3,9 @@
 #   tools/attn_pmc.sh <out file>      (run on the GPU box)
 # Per kernel and launch: matrix-pipe busy cycles, wave cycles split into parked (s_waitcnt / barrier), issue-stalled and issuing, LDS
 # conflict cycles, and the effective clock (GRBM_GUI_ACTIVE / duration) -- SQ_* wave counters are in quad-cycles (MI355X_MICROARCH.md).
-OUT=${1:-$GRAFT_REPO_ROOT/gpurun_out/attn_pmc.txt}
 R=$GRAFT_REPO_ROOT
+OUT=${1:-$R/gpurun_out/attn_pmc.txt}
+case "$OUT" in /*) ;; *) OUT=$R/$OUT ;; esac      # (the script changes directory: a relative path is relative to the repository)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_attn /tmp/p_attn2
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p_attn --output-format csv -- python3 $R/tools/stress_bench.py --reps 2 > /dev/null 2>&1

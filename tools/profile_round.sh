@@ -43,6 +43,14 @@ CF_TRUNK=0 timeout 200 python3 bench.py --steps 300 --warmup 30 --no-cpu-baselin
 timeout 100 python3 tools/trunk_stamps.py > $OUT/trunk_stamps.txt 2> /dev/null
 timeout 100 python3 tools/bin_bench.py 2> /dev/null | tail -1 > $OUT/binning.json
 timeout 200 python3 tools/stress_bench.py 2> /dev/null | tail -1 > $OUT/stress_attention.json
+CF_ATTN_BWD_V1=1 timeout 200 python3 tools/stress_bench.py 2> /dev/null | tail -1 > $OUT/stress_attention_bwd64.json      # the 64-keys-per-pass backward of rounds 4-5, same box
+# HBM traffic of the dense attention kernels at the stress shape (separate FETCH_SIZE / WRITE_SIZE passes), both backward kernels; issue / stall counters
+( cd /tmp && for v in 0 1; do rm -rf /tmp/pa_f /tmp/pa_w
+    CF_ATTN_BWD_V1=$v timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pa_f --output-format csv -- python3 $R/tools/stress_bench.py --reps 2 > /dev/null 2>&1
+    CF_ATTN_BWD_V1=$v timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pa_w --output-format csv -- python3 $R/tools/stress_bench.py --reps 2 > /dev/null 2>&1
+    python3 $R/tools/pmc_summary.py $(find /tmp/pa_f -name "*counter_collection.csv" | head -1) $(find /tmp/pa_w -name "*counter_collection.csv" | head -1) /tmp/pa.json $OUT/stress_pmc_hbm_traffic_bwdv1_$v.csv "${CF_COMMIT:-unknown}" > /dev/null
+  done )
+timeout 400 tools/attn_pmc.sh $OUT/attn_pmc.txt > /dev/null 2>&1
 timeout 100 python3 tools/reg_stamps.py fwd 2 > $OUT/reg_stamps_fwd.txt 2> /dev/null
 timeout 100 python3 tools/reg_stamps.py bwd 2 > $OUT/reg_stamps_bwd.txt 2> /dev/null
 # the driver's own command on this box (20 steps behind the disclosed pre-warm)
