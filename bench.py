@@ -161,9 +161,11 @@ def dp_path_ms(model, batch, steps, warmup, dev):
     steps, warmup = max(200, steps), max(20, warmup)
     out, worst = {}, {}
     try:
-        for key, overlap, graph in (("overlapped", True, True), ("serialised", False, True), ("overlapped_eager", True, False),
-                                    ("serialised_eager", False, False)):
-            trainer = Trainer(model, lr=3e-5, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=overlap, use_graph=graph)
+        # (overlapped_eager is the schedule chromoformer_amd.train runs: since round 6 with the Regulation halves' weight-gradient reductions on the
+        #  side stream, `overlapped_eager_main_reduce` is the round-5 form of it)
+        for key, overlap, graph, side_red in (("overlapped", True, True, None), ("serialised", False, True, None), ("overlapped_eager", True, False, None),
+                                              ("overlapped_eager_main_reduce", True, False, False), ("serialised_eager", False, False, None)):
+            trainer = Trainer(model, lr=3e-5, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=overlap, use_graph=graph, dp_side_reduce=side_red)
             slot = trainer.stage(batch)
             for _ in range(warmup):
                 trainer.step(slot)
@@ -341,10 +343,23 @@ def self_launch(args, argv):
         s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        rc, out = r.returncode, r.stdout
-        sys.stderr.write(r.stderr[-20000:])
-        if rc == 0 or not any(k in r.stderr for k in ("EADDRINUSE", "address already in use", "RendezvousConnectionError")):
+        # (the ranks get a process group of their own: if they hang -- a collective that never completes -- exactly that group is ended after
+        #  `--launch-timeout-s`, nothing else; the parent itself holds no GPU state)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=args.launch_timeout_s)
+            rc = proc.returncode
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, err = proc.communicate()
+            sys.stderr.write(err[-20000:])
+            raise SystemExit("bench.py --gpus %d: the ranks did not finish within %d s (--launch-timeout-s); their process group was ended" % (args.gpus, args.launch_timeout_s))
+        sys.stderr.write(err[-20000:])
+        if rc == 0 or not any(k in err for k in ("EADDRINUSE", "address already in use", "RendezvousConnectionError")):
             break
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     for ln in out.splitlines():
@@ -388,6 +403,7 @@ def main():
                     help="un-timed device pre-warm in front of the W warm-up steps: the same step issued for this many seconds of wall clock (a fresh box "
                          "runs its first ~100 ms of kernels 5 %% slower: clock / power state); reported as `prewarm_s` / `prewarm_steps`; 0 = none.  "
                          "--steps / --warmup are honoured as given and what is timed does not change")
+    ap.add_argument("--launch-timeout-s", type=int, default=1500, help="--gpus N > 1 started without torch.distributed.run: end the ranks this process started after so many seconds")
     ap.add_argument("--no-extras", action="store_true", help="skip the `stress` and `binning` sub-records of the default line (~3 s)")
     args = ap.parse_args()
 
@@ -524,6 +540,7 @@ def main():
                                    "%s synthetic 7-mark signals, fwd+loss+bwd+allreduce+AdamW" % args.regime,
                        "parallelism": "dp%d" % world, "global_batch": BSZ * world, "hip_graph": bool(trainer.use_graph),
                        "dp_halves": bool(trainer.halves), "dp_early_opt": bool(trainer.dp_early_opt), "dp_overlap_allreduce": bool(trainer.overlap_allreduce),
+                       "dp_side_reduce": bool(trainer.dp_side_reduce),
                        "launches_per_step": sum(model.launch_counts()),      # (of the last step: counted at the launch sites, graph replays included)
                        "adamw": "in the epilogue of the gradient reductions (cf_reduce_opt_part)" if trainer.fuse_opt else "own launches"},
             "roofline": roof,

@@ -194,7 +194,7 @@ class Trainer:
     def __init__(self, model, lr=3e-5, gamma=0.87, world_size=1, process_group=None, use_graph=True,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, timed_kernel=None, opt_in_graph=False, overlap_opt=False,
                  overlap_allreduce=None, merge_opt=True, overlap_reduce=None, fuse_opt=None, keep_grads=False, fuse_one=None, rider_tiles=None,
-                 keep_tiled=None, dp_halves=None, dp_early_opt=None):
+                 keep_tiled=None, dp_halves=None, dp_early_opt=None, dp_side_reduce=None):
         self.model, self.lr, self.gamma = model, float(lr), gamma
         self.world, self.pg, self.use_graph = world_size, process_group, use_graph
         self.dp = world_size > 1 or process_group is not None
@@ -230,6 +230,15 @@ class Trainer:
             import os
             dp_early_opt = os.environ.get("CF_DP_EARLY_OPT", "1") != "0"
         self.dp_early_opt = bool(dp_early_opt) and self.dp
+        # Data parallel, round 6: the weight-gradient reductions of the two Regulation halves run on the SIDE stream, in front of the all-reduce that
+        # ships them -- beside the next backward launch of the main stream (192 workgroups on 256 CUs) instead of between two of them.  The main
+        # stream's chain loses two `k_reduce` launches (2 x 30 us); the all-reduces start where they did (the reduction that precedes each is the
+        # same launch, one stream over).  Same kernels on the same data in the same order per bucket: same bits (tests/test_engine_gpu.py).  Eager
+        # launches only (what chromoformer_amd.train and bench.py run under data parallelism); dp_side_reduce=False / CF_DP_SIDE_REDUCE=0: round 5.
+        if dp_side_reduce is None:
+            import os
+            dp_side_reduce = os.environ.get("CF_DP_SIDE_REDUCE", "1") != "0"
+        self.dp_side_reduce = bool(dp_side_reduce) and self.halves and self.overlap_allreduce and not use_graph and not opt_in_graph
         self._ev_mid = torch.cuda.Event()
         self._buckets = {}
         for b in (_lib.BUCKET_REG, _lib.BUCKET_PE) + ((_lib.BUCKET_REG_HI, _lib.BUCKET_REG_LO) if self.halves else ()):
@@ -336,15 +345,17 @@ class Trainer:
                                       slot.loss.data_ptr(), st), "cf_forward_train")
         if self.halves:      # data parallel: head + upper half of the Regulation layers, and their gradient bucket
             self._part(slot, st, 1 | _lib.PART_REG_HI)
-            self._reduce(slot, st, _lib.BUCKET_REG_HI)
+            if reduce:
+                self._reduce(slot, st, _lib.BUCKET_REG_HI)
             return
         self._part(slot, st, 3)
         if reduce:
             self._reduce(slot, st, _lib.BUCKET_REG)
 
-    def _seq_mid(self, slot, st):       # data parallel in halves: lower half of the Regulation layers and their gradient bucket
+    def _seq_mid(self, slot, st, reduce=True):       # data parallel in halves: lower half of the Regulation layers and their gradient bucket
         self._part(slot, st, _lib.PART_REG_LO)
-        self._reduce(slot, st, _lib.BUCKET_REG_LO)
+        if reduce:
+            self._reduce(slot, st, _lib.BUCKET_REG_LO)
 
     def _seq_main(self, slot, st):      # single GPU, merged optimiser: everything up to the Pairwise + Embedding backward (its bucket is reduced beside AdamW)
         if self.overlap_reduce:
@@ -490,10 +501,11 @@ class Trainer:
             else:
                 self._seq_all(slot, st, opt=oig)
         else:
+            side_red = self.dp_side_reduce and not self.use_graph
             if self.use_graph:
                 self._launch(slot.graph["first"], st)
             else:
-                self._seq_early(slot, st)
+                self._seq_early(slot, st, reduce=not side_red)
             # (dp_early_opt: AdamW over the Regulation + head range on the SIDE stream, straight behind that range's last all-reduce -- under the
             #  Pairwise + Embedding backward -- instead of on the main stream behind everything: its streaming loads and stores (CF_ADAM_NT) no longer
             #  sweep the L2s the trunk works in, which is what made this lose in round 3)
@@ -505,6 +517,8 @@ class Trainer:
                 ev.record(self.stream)
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ev)
+                    if side_red:      # the bucket's weight-gradient tiles, here instead of on the main stream (dp_side_reduce)
+                        self._reduce(slot, self.side.cuda_stream, bucket)
                     torch.distributed.all_reduce(self._buckets[bucket], group=self.pg)     # SUM; dloss carries 1/world
                     if last:
                         if self.overlap_opt:
@@ -519,7 +533,7 @@ class Trainer:
                 if self.use_graph:
                     self._launch(slot.graph["mid"], st)
                 else:
-                    self._seq_mid(slot, st)
+                    self._seq_mid(slot, st, reduce=not side_red)
                 if self.overlap_allreduce:
                     early_allreduce(_lib.BUCKET_REG_LO, self._ev_mid, last=True)
             elif self.overlap_allreduce:

@@ -140,6 +140,10 @@ def test_one_rank_rccl_all_reduce_in_the_step():
         more = [_run(use_graph=g, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=o, dp_halves=False)
                 for g, o in ((True, True), (False, True), (True, False))]
         more.append(_run(use_graph=False, world_size=1, process_group=dist.group.WORLD, overlap_allreduce=True))      # halves, eager
+        # (round 6: that one reduces the two Regulation halves' weight gradients on the side stream, beside the next backward launch; the round-5
+        #  form with every reduction on the main stream: dp_side_reduce=False / CF_DP_SIDE_REDUCE=0)
+        more.append(_run(use_graph=False, world_size=1, process_group=dist.group.WORLD, dp_side_reduce=False))
+        more.append(_run(use_graph=False, world_size=1, process_group=dist.group.WORLD, dp_side_reduce=True, dp_early_opt=False))
         # (all of the above step the Regulation + head range on the side stream, straight behind its last all-reduce; the round-4 form, on the main
         #  stream behind everything: dp_early_opt=False / CF_DP_EARLY_OPT=0)
         more += [_run(use_graph=g, world_size=1, process_group=dist.group.WORLD, dp_early_opt=False, dp_halves=hv) for g, hv in ((True, True), (False, False))]

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="$R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dp-path --train-loop-steps 0"
+B="$R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-dp-path --train-loop-steps 0 --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_stats --output-format csv -- python3 $B > $OUT/stats_bench.json 2> /dev/null
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_fetch --output-format csv -- python3 $B --eager > /dev/null 2>&1
