@@ -406,6 +406,8 @@ def main():
     ap.add_argument("--launch-timeout-s", type=int, default=1500, help="--gpus N > 1 started without torch.distributed.run: end the ranks this process started after so many seconds")
     ap.add_argument("--no-extras", action="store_true", help="skip the `stress` and `binning` sub-records of the default line (~3 s)")
     args = ap.parse_args()
+    # (multi-process GPU work on this platform needs dmabuf IPC: the variable must be in place before the HIP runtime starts in any rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     # `python bench.py --gpus N` with no torch.distributed.run environment around it: this process starts the N ranks itself,
     # BEFORE anything touches the GPU (tests/test_dp_gpu.py::test_bench_launches_its_own_ranks)

@@ -235,6 +235,8 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:      # (multi-process GPU work on this platform needs dmabuf IPC; in place before the HIP runtime starts)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # the same two hooks as bench.py: CF_SHARE_DEVICE=1 puts every rank on device 0 and CF_DIST_BACKEND=gloo replaces RCCL
     # (which refuses two ranks on one device) -- how the multi-process entrypoint is exercised on a one-GPU box
     if os.environ.get("CF_SHARE_DEVICE") == "1":
