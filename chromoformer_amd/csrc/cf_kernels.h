@@ -1887,9 +1887,9 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col,
 // Streaming (nt) loads and stores for the optimiser state in the tile epilogues: every element is touched once per step, and as plain
 // accesses the 128 MB of them sweep the L2s that the operand rows of the other tiles -- and, under the riders, the tables of the trunk --
 // live in.  A/B on one box: riders only 0.568 -> 0.565 ms, all epilogues 0.567 -> 0.558.
-#ifndef CF_RIDER_OPND_NT      // the riders' operand rows as well (151 MB streamed through the L2s the trunk works in: 0.5415 -> 0.5388 ms)
-#define CF_RIDER_OPND_NT 1
-#endif
+#ifndef CF_RIDER_OPND_NT      // the riders' operand rows as well (round 4, 151 MB streamed through the L2s the trunk works in: 0.5415 -> 0.5388 ms).  Round 6, on the
+#define CF_RIDER_OPND_NT 0    // kernels as they are now, the other way round: plain loads 0.5035 -> 0.5006 ms and 40 MB less HBM-side traffic per step; with plain
+#endif                        // accesses for the riders' optimiser state too (CF_RIDER_NT 0) 0.4984 ms, 274 -> 225 MB in `k_trunk_bwd` (profiles/r06k_traffic_ab.txt)
 #ifndef CF_ADAM_NT      // the stand-alone AdamW stream (data-parallel path) likewise
 #define CF_ADAM_NT 1
 #endif
@@ -1897,7 +1897,7 @@ __device__ __forceinline__ float4 wg_load4(const float* __restrict__ p, int col,
 #define CF_OPT_NT 1
 #endif
 #ifndef CF_RIDER_NT
-#define CF_RIDER_NT 1
+#define CF_RIDER_NT 0
 #endif
 #ifndef CF_WG_M
 #define CF_WG_M 32
