@@ -294,7 +294,8 @@ struct cf_handle {
         AdamFuse o;
     } rider;
     int xcd_reduce = 0;                        // XCD-aware order of the weight-gradient tiles (measured slower: cf_kernels.h, xcd_tile)
-    int xcd_reduce_opt = 1;                    // ... in the fused reduction + AdamW launch, which moves 5.5 TB/s: there it pays (0.568 -> 0.563 ms)
+    int xcd_reduce_opt = 0;                    // ... in the fused reduction + AdamW launch it paid in round 3 (0.568 -> 0.563 ms); on the round-6 kernels (riders with
+                                               // cached accesses) the table order wins: 0.5012 -> 0.4892 ms (profiles/r06n_env_ab.txt); CF_XCD_REDUCE=1 forces it on
     int defer_retile = 1;                      // Regulation + head units ride in the Embedding layer's chain launch (CF_DEFER_RETILE=0: all in the prologue)
     // workspace
     float* arena = nullptr;

@@ -2195,7 +2195,8 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& t, int batch, const Ada
 // re-reads the table order causes are served by the 256 MB Infinity Cache anyway (the arrays were written by the kernel in
 // front).  Off by default there (`on` = 0: table order).  In the fused reduction + AdamW launch of the single-GPU step
 // (k_reduce_opt behind the riders: 796 tiles + the optimiser state, 312 MB HBM-side in 56 us = 5.5 TB/s) bytes are what binds, and the
-// same order PAYS: 0.5683 -> 0.5633 ms over two A/B rounds; on by default for that launch.  CF_XCD_REDUCE=0 / 1 forces both.
+// same order PAID in round 3: 0.5683 -> 0.5633 ms over two A/B rounds.  Re-measured in round 6 (riders with cached accesses, 5-launch step): table order
+// 0.4892 against 0.5012 ms -- off by default for that launch too.  CF_XCD_REDUCE=0 / 1 forces both.
 __device__ __forceinline__ int xcd_tile(int b, int n, int on) {
     const int per = (n + 7) >> 3;
     return on ? (b & 7) * per + (b >> 3) : b;

@@ -14,7 +14,7 @@ for rnd in range(rounds):
                 k, v = kv.split("=")
                 env[k] = v
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "30", "--no-cpu-baseline", "--no-dp-path",
-                            "--train-loop-steps", "0", "--no-val-auroc"], env=env, capture_output=True, text=True)
+                            "--train-loop-steps", "0", "--no-val-auroc", "--no-extras"], env=env, capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
             print("round %d  %-40s  %.4f ms  graph %.4f ms  deferred %s  loss %s" % (rnd, spec, d["ms_per_step"], d.get("graph_replay_ms_per_step", float("nan")),
