@@ -245,6 +245,13 @@ def stress_record(steps, warmup):
     _, bwd_ms = timed(bwd, max(3, steps // 2))
     flops = 14.0 * N * H * L * L * 64
     ach = flops / (dev_ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    try:      # HBM-side bytes of one forward + backward (the three kernels), a committed PMC constant like the default line's `roofline.traffic`
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_stress.json")))
+        traffic = float(sum(tj["kernels"][k] for k in ("k_attn_fwd", "k_attn_delta", "k_attn_bwd2")))
+        traffic_src = "profiles/pmc_traffic_stress.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run (committed constant, not measured in this run)"
+    except (OSError, KeyError, ValueError):
+        pass
     io_gb = 8 * N * L * H * 64 * 4 / 1e9                      # Q, K, V, O, dO read + dQ, dK, dV written, once each
     out = {"metric": "genes/sec through the dense attention core, forward + backward (stress config: bsz=128, i_max=16, 800 bins)",
            "value": round(B * steps / el, 1), "unit": "genes/s", "n_gpus": 1,
@@ -254,7 +261,8 @@ def stress_record(steps, warmup):
                                   "N = 128 x 17 = %d sequences x %d heads, L = %d, dh = 64 -- attention kernels only, not a training step" % (N, H, L),
                       "parallelism": "dp1", "global_batch": B},
            "roofline": {"kernel": "k_attn_fwd + k_attn_delta + k_attn_bwd2 (dQ, dK, dV in one pass per (sequence, head), 128 keys per pass)", "bound": "mfma", "achieved": round(ach, 3), "peak": 157.3,
-                        "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "frac_no_recompute": round(ach * 12.0 / 14.0 / 157.3, 4), "traffic": None, "avg_launch_us": round(dev_ms * 1e3, 1),
+                        "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "frac_no_recompute": round(ach * 12.0 / 14.0 / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "avg_launch_us": round(dev_ms * 1e3, 1),
                         "fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3),
                         "fwd_tflops": round(4.0 * N * H * L * L * 64 / (fwd_ms * 1e-3) / 1e12, 2),
                         "bwd_tflops_no_recompute": round(8.0 * N * H * L * L * 64 / (bwd_ms * 1e-3) / 1e12, 2),
