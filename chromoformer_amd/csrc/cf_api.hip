@@ -131,8 +131,10 @@ static int check_config(const cf_config& c) {
     if (c.pair_layers < 1 || 2 * c.pair_layers > kLpMaxSeg) return fail("pairwise_interaction.n_layers must be in 1..%d (got %d)", kLpMaxSeg / 2, c.pair_layers);
     // (the fused Regulation kernels are written for 8 heads x 32; the other shapes run the layer-by-layer kernels, whose attention
     //  stage takes heads and width at run time and whose products are instantiated for both widths)
-    if ((c.reg_heads != 4 && c.reg_heads != 8) || (c.reg_dmodel != 128 && c.reg_dmodel != 256))
-        return fail("regulation: n_heads in {4, 8} and d_model in {128, 256} are supported (got n_heads = %d, d_model = %d)", c.reg_heads, c.reg_dmodel);
+    // (round 6: the layer-by-layer attention stage, k_attr, takes any head count that divides the width; 1, 2 and 16 are tested beside 4 and 8)
+    auto reg_heads_ok = [](int n) { return n == 1 || n == 2 || n == 4 || n == 8 || n == 16; };
+    if (!reg_heads_ok(c.reg_heads) || (c.reg_dmodel != 128 && c.reg_dmodel != 256))
+        return fail("regulation: n_heads in {1, 2, 4, 8, 16} and d_model in {128, 256} are supported (got n_heads = %d, d_model = %d)", c.reg_heads, c.reg_dmodel);
     if (c.reg_layers < 1 || c.reg_layers > 32) return fail("regulation.n_layers must be in 1..32");
     const int dffs[3] = {c.embed_dff, c.pair_dff, c.reg_dff};
     for (int d : dffs)

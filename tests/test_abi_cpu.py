@@ -76,9 +76,9 @@ def test_unsupported_configs_are_rejected_loudly():
         assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0 and b"d_model = d_emb" in _lib.lib().cf_last_error()
         cfg.pair_dmodel, cfg.embed_heads = d, 4
         assert _lib.lib().cf_param_layout(C.byref(cfg), C.byref(lay), None, 0) != 0 and b"at most two heads" in _lib.lib().cf_last_error()
-    # head counts: Embedding / Pairwise 1, 2, 4 (d_model = 128), Regulation 4 or 8 heads with d_model 128 or 256; the rest is refused by name
+    # head counts: Embedding / Pairwise 1, 2, 4 (d_model = 128), Regulation 1, 2, 4, 8 or 16 heads (round 6) with d_model 128 or 256; the rest is refused by name
     for field, value, ok in (("embed_heads", 1, True), ("embed_heads", 4, True), ("embed_heads", 8, False), ("pair_heads", 4, True),
-                             ("pair_heads", 3, False), ("pair_dmodel", 256, False), ("reg_heads", 4, True), ("reg_heads", 2, False),
+                             ("pair_heads", 3, False), ("pair_dmodel", 256, False), ("reg_heads", 4, True), ("reg_heads", 2, True), ("reg_heads", 16, True), ("reg_heads", 3, False), ("reg_heads", 32, False),
                              ("reg_dmodel", 128, True), ("reg_dmodel", 512, False)):
         cfg = _cfg()
         setattr(cfg, field, value)

@@ -32,6 +32,9 @@ VARIANTS = {
     "reg_4_heads": dict(regulation=dict(n_layers=3, n_heads=4, d_model=256, d_ff=256)),
     "reg_d_model_128": dict(regulation=dict(n_layers=3, n_heads=8, d_model=128, d_ff=256)),
     "reg_4_heads_d_model_128": dict(regulation=dict(n_layers=2, n_heads=4, d_model=128, d_ff=128)),
+    "reg_1_head": dict(regulation=dict(n_layers=2, n_heads=1, d_model=128, d_ff=256)),                # round 6: any of 1, 2, 4, 8, 16 heads (modules.py:9-26 takes any divisor)
+    "reg_2_heads": dict(regulation=dict(n_layers=2, n_heads=2, d_model=256, d_ff=256)),
+    "reg_16_heads": dict(regulation=dict(n_layers=3, n_heads=16, d_model=128, d_ff=128)),
     "d_head_96": dict(d_head=96),                                      # fc_head widths other than 128: the vector-ALU head (cf_head.h)
     "d_head_256": dict(d_head=256),
     "other_bins": dict(binsizes=[1000, 250, 50], w_max=20000),          # L = 20 / 80 / 400 again but other PE tables ... and
