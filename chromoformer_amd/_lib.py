@@ -159,7 +159,7 @@ def build(force=False, verbose=False):
            os.path.join(CSRC, "cf_api.hip"), "-o", LIB_PATH]
     cmd[6:6] = flags.split()      # experiments (-DCF_...); the shipped library is built without
     if verbose:
-        why = "forced" if force else ("flags changed: '%s' -> '%s'" % (built_with, flags) if fresh else "sources newer than the library")
+        why = "forced" if force else ("flags changed: '%s' -> '%s'" % (built_with, flags) if fresh else ("no library yet" if not os.path.exists(LIB_PATH) else "sources newer than the library"))
         print("build: compiling (%s): %s" % (why, " ".join(cmd)))
     subprocess.run(cmd, check=True)
     with open(FLAGS_PATH, "w") as f:
